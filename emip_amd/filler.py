@@ -1,0 +1,100 @@
+"""Name-keyed deterministic weight filler.
+
+No checkpoint of the reference can be shipped (426 MB, network-only links:
+/root/reference/configs/configs.yaml:20-21), so parity is pinned on weights
+that any process can regenerate from the ``state_dict`` key names alone
+(SURVEY.md section 8c).  Key names and shapes are the drop-in contract
+(/root/reference/train.py:312-337), therefore the same filler applied to the
+reference modules and to this package yields identical weights.
+
+The generator is ``numpy.random.RandomState`` (legacy MT19937 stream, frozen
+across numpy versions) seeded with CRC32(key) xor the global seed.
+"""
+import re
+import zlib
+
+import numpy as np
+import torch
+
+
+_DECODER_KEY = re.compile(r"(^|\.)(decoder|dr1|dr2|dr3|long_dr)\.")
+
+
+def _rs(key: str, seed: int) -> np.random.RandomState:
+    return np.random.RandomState((zlib.crc32(key.encode()) ^ (seed * 2654435761)) & 0x7FFFFFFF)
+
+
+def fill_tensor(key: str, shape, seed: int = 0) -> np.ndarray:
+    """Value for one state_dict entry (float32 numpy array)."""
+    rs = _rs(key, seed)
+    shape = tuple(shape)
+    leaf = key.rsplit(".", 1)[-1]
+    if leaf == "running_mean":
+        return rs.normal(0.0, 0.1, shape).astype(np.float32)
+    if leaf == "running_var":
+        return (1.0 + rs.uniform(0.0, 0.5, shape)).astype(np.float32)
+    if leaf == "temperature":
+        return (1.0 + rs.normal(0.0, 0.1, shape)).astype(np.float32)
+    if leaf == "bias" or leaf.endswith("_bias"):
+        return rs.normal(0.0, 0.02, shape).astype(np.float32)
+    if len(shape) <= 1:  # LayerNorm / BatchNorm / LayerNorm2d scale
+        return (1.0 + rs.normal(0.0, 0.05, shape)).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    gain = 1.0
+    if len(shape) == 4 and _DECODER_KEY.search(key):
+        # ConvBR stacks + the NCD's triple products shrink activations; a larger
+        # gain keeps the mask logits O(1) so the 1e-3 parity bound is meaningful.
+        gain = 1.7
+    return rs.normal(0.0, gain / np.sqrt(fan_in), shape).astype(np.float32)
+
+
+def filled_state_dict(reference_sd, seed: int = 0):
+    """Return {key: tensor} with the filler applied to every float entry of
+    ``reference_sd`` (only names, shapes and dtypes are read from it)."""
+    out = {}
+    for k in sorted(reference_sd.keys()):
+        v = reference_sd[k]
+        if not torch.is_floating_point(v):
+            out[k] = v.clone()
+            continue
+        out[k] = torch.from_numpy(fill_tensor(k, v.shape, seed)).to(v.dtype)
+    return out
+
+
+def synthetic_pair(batch: int, size: int = 352, seed: int = 1234, shift=(3, -2)):
+    """Seeded smooth-field frame pair, ImageNet-normalised like
+    /root/reference/dataset/dataset.py:76-79.  image2 is image1 shifted by an
+    integer offset plus a little noise (a well-posed flow problem)."""
+    rs = np.random.RandomState(seed)
+    low = rs.uniform(0.0, 1.0, (batch, 3, size // 16 + 2, size // 16 + 2)).astype(np.float32)
+    img = torch.nn.functional.interpolate(torch.from_numpy(low), size=(size + 16, size + 16),
+                                          mode="bilinear", align_corners=True)
+    img = img + torch.from_numpy(rs.normal(0, 0.02, tuple(img.shape)).astype(np.float32))
+    img = img.clamp(0, 1)
+    dy, dx = shift
+    im1 = img[:, :, 8:8 + size, 8:8 + size]
+    im2 = img[:, :, 8 + dy:8 + dy + size, 8 + dx:8 + dx + size]
+    im2 = (im2 + torch.from_numpy(rs.normal(0, 0.005, tuple(im2.shape)).astype(np.float32))).clamp(0, 1)
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return ((im1 - mean) / std).contiguous(), ((im2 - mean) / std).contiguous()
+
+
+def synthetic_gt(batch: int, size: int = 352, seed: int = 99):
+    rs = np.random.RandomState(seed)
+    low = torch.from_numpy(rs.uniform(0, 1, (batch, 1, 8, 8)).astype(np.float32))
+    f = torch.nn.functional.interpolate(low, size=(size, size), mode="bilinear", align_corners=True)
+    return (f > 0.72).float()
+
+
+def state_dict_from_manifest(manifest, seed: int = 0):
+    """Filled state dict from a {key: [shape, dtype]} manifest
+    (tests/golden/*_state_manifest.json) -- no reference module needed."""
+    out = {}
+    for k in sorted(manifest.keys()):
+        shape, dt = manifest[k]
+        if dt != "float32":
+            out[k] = torch.zeros(shape, dtype=getattr(torch, dt))
+        else:
+            out[k] = torch.from_numpy(fill_tensor(k, shape, seed))
+    return out

@@ -1,0 +1,105 @@
+"""The CPU oracle against fixtures produced by the reference itself
+(oracle/make_golden.py).  This is the pin that lets the oracle stand in for the
+reference on the GPU box."""
+import numpy as np
+import torch
+
+from emip_amd.filler import synthetic_gt, synthetic_pair
+from oracle import emip_oracle as O
+
+
+def _stats(t):
+    t = t.detach().double()
+    return np.array([t.mean().item(), t.pow(2).sum().sqrt().item(), t.abs().max().item()])
+
+
+def _close(a, b, atol, rtol=1e-4, name=""):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else a
+    err = np.abs(a - b).max()
+    assert np.allclose(a, b, atol=atol, rtol=rtol), f"{name}: max abs err {err}"
+
+
+def test_short_eval_b1(golden, short_sd):
+    g = golden("short_eval_b1.npz")
+    im1, im2 = synthetic_pair(1, seed=1234)
+    cap = {}
+    with torch.no_grad():
+        mask, fw, bw = O.short_forward(im1, im2, short_sd, capture=cap)
+    _close(cap["pvt1"][0][:, :, ::2, ::2], g["pvt1_s2"], 2e-4, name="pvt s2")
+    _close(cap["pvt1"][1], g["pvt1_s3"], 2e-4, name="pvt s3")
+    _close(cap["pvt1"][2], g["pvt1_s4"], 2e-4, name="pvt s4")
+    _close(cap["gm1"][:, :, ::2, ::2], g["gm1"], 2e-4, name="gm cnn")
+    _close(cap["inj_a"][:, :, ::2, ::2], g["inj_a"], 2e-4, name="injector a")
+    _close(cap["f0"][:, :, ::2, ::2], g["f0"], 1e-3, name="gm transformer")
+    corr = cap["corr"]
+    _close(corr[:, :64].reshape(1, 64, -1)[:, :, :64], g["corr_block"], 2e-3, name="corr")
+    _close(cap["flow_lr"], g["flow_lr"], 5e-2, name="flow_lr")  # ill-conditioned: softmax over 1936
+    _close(cap["flow_prop"], g["flow_prop"], 5e-2, name="flow_prop")
+    _close(cap["conv_corr"][:, :, ::2, ::2], g["conv_corr"], 5e-3, name="conv_corr")
+    _close(cap["inj1"][:, :, ::2, ::2], g["inj1"], 5e-4, name="injector1")
+    _close(cap["dr2"], g["dr2"], 2e-4, name="dr2")
+    _close(cap["dr3"], g["dr3"], 2e-4, name="dr3")
+    _close(cap["pc"], g["pc"], 1e-3, name="pc")
+    _close(mask, g["mask"], 1e-3, name="mask")
+    _close(fw[0][:, :, ::4, ::4], g["flow_fw"], 0.5, name="flow_fw")
+
+
+def test_short_eval_b2_mask(golden, short_sd):
+    g = golden("short_eval_b2.npz")
+    im1, im2 = synthetic_pair(2, seed=1234)
+    with torch.no_grad():
+        mask, fw, bw = O.short_forward(im1, im2, short_sd)
+    _close(mask, g["mask"], 1e-3, name="mask b2")
+    assert mask.shape == (2, 1, 352, 352) and fw[0].shape == (2, 2, 352, 352) and len(fw) == 1
+
+
+def test_short_train_losses(golden, short_sd):
+    g = golden("short_train_b2.npz")
+    im1, im2 = synthetic_pair(2, seed=77)
+    gt = synthetic_gt(2, seed=99)
+    with torch.no_grad():
+        mask, fw, bw = O.short_forward(im1, im2, short_sd, training=True)
+        lp = O.hybrid_e_loss(mask, gt)
+        lf = O.unflow_loss([torch.cat([fw[i], bw[i]], 1) for i in range(len(fw))], torch.cat((im1, im2), 1))
+    assert len(fw) == int(g["n_preds"]) == 2
+    _close(mask, g["mask"], 2e-3, name="train mask")
+    assert abs(lp.item() - float(g["loss_pred"])) < 1e-4
+    assert abs(lf.item() - float(g["loss_flow"])) < 2e-3
+
+
+def test_loss_micro(golden):
+    g = golden("loss_micro.npz")
+    x, y, flow = (torch.from_numpy(g[k]) for k in ("x", "y", "flow"))
+    _close(O.flow_warp(x, flow), g["warped"], 1e-6, name="warp")
+    _close(O.occu_mask_backward(flow), g["occ"], 0, name="occ")
+    B, _, H, W = flow.shape
+    idx, vals = O.corresponding_indices(O.mesh_grid(B, H, W).type_as(flow) + flow)
+    cmap = torch.zeros(B, H * W).scatter_add_(1, idx, vals).view(B, 1, H, W)
+    _close(cmap, g["cmap"], 1e-6, name="cmap")
+    _close(O.ssim_dist(x, y), g["ssim"], 1e-6, name="ssim")
+    assert abs(O.hybrid_e_loss(torch.from_numpy(g["pred"]), torch.from_numpy(g["gt"])).item() - float(g["hybrid"])) < 1e-6
+    flows4 = [torch.cat([flow, -flow * 0.5], 1), torch.cat([flow * 0.9, -flow * 0.4], 1)]
+    assert abs(O.unflow_loss(flows4, torch.cat((x, y), 1)).item() - float(g["unflow"])) < 1e-5
+
+
+def test_warp_indices_bit_exact(golden):
+    g = golden("warp_indices_352.npz")
+    fl = torch.from_numpy(np.random.RandomState(11).normal(0, 6.0, (1, 2, 352, 352)).astype(np.float32))
+    idx, _ = O.corresponding_indices(O.mesh_grid(1, 352, 352).type_as(fl) + fl)
+    assert np.array_equal(idx.numpy().astype(np.int32), g["indices"])
+    assert np.array_equal(O.occu_mask_backward(fl).numpy().astype(np.uint8), g["occ"])
+
+
+def test_long_stream(golden, long_sd):
+    g = golden("long_eval.npz")
+    seq = [synthetic_pair(1, seed=500, shift=(t - 4, 4 - t))[1][0] for t in range(8)]
+    mk = mv = None
+    with torch.no_grad():
+        for i in range(4):  # index 0 (short only), 1 (first memory), 2, 3
+            if i == 0:
+                m, _, _ = O.long_forward(seq[0], seq[1], 0, None, None, long_sd)
+            else:
+                m, mk, mv = O.long_forward(seq[i - 1], seq[i], i, mk, mv, long_sd)
+                assert mk.shape[3] == int(g[f"T_{i}"])
+                assert np.allclose(_stats(mk), g[f"k_{i}_stats"], rtol=1e-4, atol=1e-4)
+            _close(m[:, :, ::2, ::2], g[f"mask_{i}"], 2e-3, name=f"long mask {i}")
