@@ -1,0 +1,90 @@
+// Shared device/host helpers for libemip_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/emip_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define EMIP_WAVE 64
+
+// Launch-time argument checks: a kernel that faults can reset the whole host,
+// so every shape/alignment assumption is verified here and refused with a code.
+#define EMIP_REQUIRE(cond)                 \
+    do {                                   \
+        if (!(cond)) return EMIP_E_INVALID; \
+    } while (0)
+
+static inline int emip_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? EMIP_OK : EMIP_E_LAUNCH;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+template <typename T>
+__device__ __forceinline__ float to_f32(T v);
+template <>
+__device__ __forceinline__ float to_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ float to_f32<bf16_t>(bf16_t v) { return (float)v; }
+
+template <typename T>
+__device__ __forceinline__ T from_f32(float v);
+template <>
+__device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <>
+__device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// 4 consecutive elements as a vector (16 B for f32, 8 B for bf16)
+template <typename T>
+struct Vec4;
+template <>
+struct Vec4<float> {
+    typedef float4 type;
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <>
+struct Vec4<bf16_t> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+        bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+        bf16x4 t;
+        t[0] = (bf16_t)v[0]; t[1] = (bf16_t)v[1]; t[2] = (bf16_t)v[2]; t[3] = (bf16_t)v[3];
+        *reinterpret_cast<bf16x4*>(p) = t;
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Bijective XCD-aware remap of a linear workgroup id: blocks are dealt round-robin
+// over the 8 XCDs, so give each XCD a contiguous chunk of the tile space (speed only).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

@@ -1,0 +1,132 @@
+// Channel ("transposed") attention pieces of the MDTA injector block
+// (/root/reference/model/EMIP_short/motion/PromptInteract.py:407-432):
+//   gram:    G[b,h,c1,c2] = sum_p q[b,p,h*64+c1] * k[b,p,h*64+c2]   (contraction over 1936 pixels)
+//            nq[b,c] = sum_p q^2,  nk[b,c] = sum_p k^2              (for F.normalize over pixels)
+//   softmax: attn = softmax_c2( G / (max(|q_c1|,eps) max(|k_c2|,eps)) * temperature[h] )
+// attn @ v and project_out are plain GEMMs (emip_gemm).  The Gram matrix is tiny
+// (64x64 per head); the work is the HBM pass over q and k, so pixels are split over
+// many workgroups and combined with f32 atomics (256-B contiguous rows per wave).
+#include "common.h"
+
+namespace {
+
+constexpr int PC = 64;  // pixels per workgroup
+
+template <typename T>
+__global__ __launch_bounds__(256) void mdta_gram_kernel(const T* __restrict__ Q, long ldq, long q_bs,
+                                                        const T* __restrict__ K, long ldk, long k_bs,
+                                                        float* __restrict__ G, float* __restrict__ nq,
+                                                        float* __restrict__ nk, int P, int heads) {
+    __shared__ __attribute__((aligned(16))) float sq[PC][64];
+    __shared__ __attribute__((aligned(16))) float sk[PC][64];
+    const int p0 = blockIdx.x * PC, head = blockIdx.y;
+    const long b = blockIdx.z;
+    const T* q = Q + b * q_bs + head * 64;
+    const T* k = K + b * k_bs + head * 64;
+    for (int i = threadIdx.x; i < PC * 16; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        float a[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
+        if (p0 + r < P) {
+            Vec4<T>::load(q + (long)(p0 + r) * ldq + c, a);
+            Vec4<T>::load(k + (long)(p0 + r) * ldk + c, d);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sq[r][c + j] = a[j];
+            sk[r][c + j] = d[j];
+        }
+    }
+    __syncthreads();
+    const int ty = threadIdx.x >> 4, tx = threadIdx.x & 15;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int r = 0; r < PC; ++r) {
+        const float4 a = *reinterpret_cast<const float4*>(&sq[r][ty * 4]);
+        const float4 d = *reinterpret_cast<const float4*>(&sk[r][tx * 4]);
+        const float av[4] = {a.x, a.y, a.z, a.w}, dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], dv[j], acc[i][j]);
+    }
+    float* g = G + ((b * heads + head) * 64) * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(g + (ty * 4 + i) * 64 + tx * 4 + j, acc[i][j]);
+    if (threadIdx.x < 128) {
+        const int c = threadIdx.x & 63;
+        const bool isq = threadIdx.x < 64;
+        float s = 0.f;
+        for (int r = 0; r < PC; ++r) {
+            const float v = isq ? sq[r][c] : sk[r][c];
+            s = fmaf(v, v, s);
+        }
+        atomicAdd((isq ? nq : nk) + (b * heads + head) * 64 + c, s);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void mdta_softmax_kernel(const float* __restrict__ G, const float* __restrict__ nq,
+                                                          const float* __restrict__ nk,
+                                                          const float* __restrict__ temperature,
+                                                          T* __restrict__ attn, int heads) {
+    const long bh = blockIdx.x;
+    const int head = (int)(bh % heads);
+    const int c1 = threadIdx.x;
+    const float* g = G + (bh * 64 + c1) * 64;
+    const float qn = fmaxf(sqrtf(nq[bh * 64 + c1]), 1e-12f);
+    const float temp = temperature[head];
+    float v[64];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c2 = 0; c2 < 64; ++c2) {
+        const float kn = fmaxf(sqrtf(nk[bh * 64 + c2]), 1e-12f);
+        v[c2] = g[c2] / (qn * kn) * temp;
+        mx = fmaxf(mx, v[c2]);
+    }
+    float den = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 64; ++c2) {
+        v[c2] = expf(v[c2] - mx);
+        den += v[c2];
+    }
+    const float inv = 1.f / den;
+    T* o = attn + (bh * 64 + c1) * 64;
+#pragma unroll
+    for (int c2 = 0; c2 < 64; ++c2) o[c2] = from_f32<T>(v[c2] * inv);
+}
+
+}  // namespace
+
+// ws: f32 workspace of B*heads*(64*64 + 128) floats: [G | nq | nk]; attn: T [B][heads][64][64]
+extern "C" int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K, long ldk, long k_bs,
+                              const float* temperature, float* ws, void* attn, int B, int heads, int P, int dtype,
+                              void* stream) {
+    EMIP_REQUIRE(Q && K && temperature && ws && attn && B > 0 && B < 65536 && heads > 0 && heads < 65536 && P > 0);
+    EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
+    EMIP_REQUIRE((ldq & 3) == 0 && (ldk & 3) == 0 && ldq >= heads * 64 && ldk >= heads * 64 && (q_bs & 3) == 0 &&
+                 (k_bs & 3) == 0);
+    hipStream_t s = (hipStream_t)stream;
+    const long nbh = (long)B * heads;
+    float* G = ws;
+    float* nq = ws + nbh * 4096;
+    float* nk = nq + nbh * 64;
+    if (hipMemsetAsync(ws, 0, sizeof(float) * nbh * (4096 + 128), s) != hipSuccess) return EMIP_E_LAUNCH;
+    dim3 grid((P + PC - 1) / PC, heads, B);
+    if (dtype == EMIP_F32) {
+        hipLaunchKernelGGL(mdta_gram_kernel<float>, grid, dim3(256), 0, s, (const float*)Q, ldq, q_bs,
+                           (const float*)K, ldk, k_bs, G, nq, nk, P, heads);
+        hipLaunchKernelGGL(mdta_softmax_kernel<float>, dim3((unsigned)nbh), dim3(64), 0, s, G, nq, nk, temperature,
+                           (float*)attn, heads);
+    } else {
+        hipLaunchKernelGGL(mdta_gram_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)Q, ldq, q_bs,
+                           (const bf16_t*)K, ldk, k_bs, G, nq, nk, P, heads);
+        hipLaunchKernelGGL(mdta_softmax_kernel<bf16_t>, dim3((unsigned)nbh), dim3(64), 0, s, G, nq, nk, temperature,
+                           (bf16_t*)attn, heads);
+    }
+    return emip_launch_status();
+}

@@ -1,0 +1,633 @@
+// HBM-bound kernels of the EMIP path: normalisations, depthwise 3x3 convs,
+// bilinear resampling, elementwise products/adds, layout conversion, convex
+// flow upsampling.  All of them move 8-16 bytes per lane per access over
+// channels-last tensors (channels are the fastest dimension, so a wavefront
+// touches whole contiguous rows).
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxBlocks = 256 * 16;  // memory-bound grids: cap and grid-stride
+
+inline int grid_for(long work_items, int threads) {
+    long b = (work_items + threads - 1) / threads;
+    if (b > kMaxBlocks) b = kMaxBlocks;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// ----------------------------------------------------------------------------
+// LayerNorm over the channel dimension (rows of C <= 1024, C % 4 == 0).
+// A row is spread over LPR lanes (power of two <= 64), 64/LPR rows per wave.
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, long M, int C, float eps,
+                                                        int lpr_log2) {
+    const int LPR = 1 << lpr_log2;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1);
+    const int rows_per_wave = 64 >> lpr_log2;
+    const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    const int nv = C >> 2;
+    for (long row0 = wave_global * rows_per_wave; row0 < M; row0 += nwaves * rows_per_wave) {
+        const long row = row0 + (lane >> lpr_log2);
+        const bool ok = row < M;
+        float v[4][4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vi = sub + i * LPR;
+            if (ok && vi < nv) {
+                Vec4<T>::load(X + row * ldx + vi * 4, v[i]);
+                s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
+            } else {
+                v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+            }
+        }
+        for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vi = sub + i * LPR;
+            if (vi < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = v[i][j] - mean;
+                    q += d * d;
+                }
+            }
+        }
+        for (int o = LPR >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vi = sub + i * LPR;
+            if (ok && vi < nv) {
+                float o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o4[j] = (v[i][j] - mean) * rstd * gamma[vi * 4 + j] + beta[vi * 4 + j];
+                Vec4<T>::store(Y + row * ldy + vi * 4, o4);
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Depthwise 3x3, stride 1, zero pad 1, channels-last.  Weights [9][C] f32.
+// GATED: X has 2*Ch channels, Y[c] = gelu(dw(X)[c]) * dw(X)[Ch + c] for c < Ch and 0 for
+// Ch <= c < ldy-padding (so that a following GEMM can read a 8-aligned K).
+template <typename T, bool GATED>
+__global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
+                                                        const float* __restrict__ Wt, const float* __restrict__ bias,
+                                                        int B, int H, int Wd, int C, int Cout_pad, int act) {
+    const int nvo = (GATED ? Cout_pad : C) >> 2;
+    const long total = (long)B * H * Wd * nvo;
+    const int Ch = GATED ? (C >> 1) : C;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nvo);
+        const long pix = idx / nvo;
+        const int x = (int)(pix % Wd);
+        const int y = (int)((pix / Wd) % H);
+        const long b = pix / ((long)Wd * H);
+        const int c = vi * 4;
+        float o[4];
+        if (GATED && c >= Ch) {
+            o[0] = o[1] = o[2] = o[3] = 0.f;
+            Vec4<T>::store(Y + pix * ldy + c, o);
+            continue;
+        }
+        float a[4], g[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = bias ? bias[c + j] : 0.f;
+            g[j] = (GATED && bias) ? bias[Ch + c + j] : 0.f;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int ix = x + kx - 1;
+                if ((unsigned)ix >= (unsigned)Wd) continue;
+                const T* px = X + ((b * H + iy) * Wd + ix) * ldx;
+                const float* w = Wt + (ky * 3 + kx) * C;
+                float v[4];
+                Vec4<T>::load(px + c, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = fmaf(v[j], w[c + j], a[j]);
+                if (GATED) {
+                    Vec4<T>::load(px + Ch + c, v);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) g[j] = fmaf(v[j], w[Ch + c + j], g[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (GATED) o[j] = gelu_erf(a[j]) * g[j];
+            else o[j] = act == EMIP_ACT_GELU ? gelu_erf(a[j]) : (act == EMIP_ACT_RELU ? fmaxf(a[j], 0.f) : a[j]);
+        }
+        Vec4<T>::store(Y + pix * ldy + c, o);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Per-(group, channel) sum and sum of squares over `rows` rows: InstanceNorm2d statistics
+// (group = image) and train-mode BatchNorm statistics (one group).  f64 atomics combine the
+// block partials so that E[x^2]-E[x]^2 is evaluated without cancellation trouble.
+template <typename T>
+__global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ X, long ldx, double* __restrict__ sums,
+                                                         long rows, int C, int rows_per_block) {
+    __shared__ float red[256 * 8];
+    const int nv = C >> 2;
+    const int plan = 256 / nv;  // row lanes
+    const int vi = threadIdx.x % nv, rl = threadIdx.x / nv;
+    const long g = blockIdx.y;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    float s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    if (rl < plan) {
+        for (long r = r0 + rl; r < r1; r += plan) {
+            float v[4];
+            Vec4<T>::load(X + (g * rows + r) * ldx + vi * 4, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s[j] += v[j];
+                q[j] = fmaf(v[j], v[j], q[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[threadIdx.x * 8 + j] = s[j];
+        red[threadIdx.x * 8 + 4 + j] = q[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < nv) {
+        float ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int l = 0; l < plan; ++l) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ts[j] += red[(l * nv + threadIdx.x) * 8 + j];
+        }
+        double* dst = sums + (g * C + threadIdx.x * 4) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(dst + j * 2, (double)ts[j]);
+            atomicAdd(dst + j * 2 + 1, (double)ts[4 + j]);
+        }
+    }
+}
+
+// y = [relu]( R + [relu]( (x - mean) * rstd * gamma + beta ) ), statistics from chan_stats_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void chan_norm_apply_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y,
+                                                              long ldy, const T* __restrict__ R, long ldr,
+                                                              const double* __restrict__ sums,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, long groups, long rows,
+                                                              int C, float eps, int relu_inner, int relu_outer) {
+    const int nv = C >> 2;
+    const long total = groups * rows * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nv);
+        const long row = idx / nv;
+        const long g = row / rows;
+        float v[4], o[4];
+        Vec4<T>::load(X + row * ldx + vi * 4, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = vi * 4 + j;
+            const double m = sums[(g * C + c) * 2] / (double)rows;
+            const double var = fmax(sums[(g * C + c) * 2 + 1] / (double)rows - m * m, 0.0);
+            float t = (v[j] - (float)m) * (float)(1.0 / sqrt(var + (double)eps));
+            if (gamma) t = t * gamma[c] + beta[c];
+            if (relu_inner) t = fmaxf(t, 0.f);
+            o[j] = t;
+        }
+        if (R) {
+            float r[4];
+            Vec4<T>::load(R + row * ldr + vi * 4, r);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] += r[j];
+        }
+        if (relu_outer) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = fmaxf(o[j], 0.f);
+        }
+        Vec4<T>::store(Y + row * ldy + vi * 4, o);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Bilinear resize of a channels-last tensor.  align_corners=1: src = dst*(in-1)/(out-1);
+// align_corners=0: src = max((dst+0.5)*in/out-0.5, 0).  Index/weight arithmetic in f32
+// exactly as ATen's upsample_bilinear2d evaluates it.
+__device__ __forceinline__ void bilin_src(int dst, int in, int out, int align, int& i0, int& i1, float& l1) {
+    float src;
+    if (align) {
+        const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+        src = scale * (float)dst;
+    } else {
+        const float scale = (float)in / (float)out;
+        src = scale * ((float)dst + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+    }
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
+                                                       int B, int H, int Wd, int C, int Ho, int Wo, int align,
+                                                       float mul) {
+    const int nv = C >> 2;
+    const long total = (long)B * Ho * Wo * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nv);
+        const long pix = idx / nv;
+        const int ox = (int)(pix % Wo);
+        const int oy = (int)((pix / Wo) % Ho);
+        const long b = pix / ((long)Wo * Ho);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilin_src(oy, H, Ho, align, y0, y1, ly);
+        bilin_src(ox, Wd, Wo, align, x0, x1, lx);
+        const T* base = X + b * H * Wd * ldx + vi * 4;
+        float a[4], bq[4], c[4], d[4], o[4];
+        Vec4<T>::load(base + ((long)y0 * Wd + x0) * ldx, a);
+        Vec4<T>::load(base + ((long)y0 * Wd + x1) * ldx, bq);
+        Vec4<T>::load(base + ((long)y1 * Wd + x0) * ldx, c);
+        Vec4<T>::load(base + ((long)y1 * Wd + x1) * ldx, d);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = mul * (hy * (hx * a[j] + lx * bq[j]) + ly * (hx * c[j] + lx * d[j]));
+        Vec4<T>::store(Y + pix * ldy + vi * 4, o);
+    }
+}
+
+// single channel, T in -> f32 out (the x8 mask logits and the x8 train-mode flow)
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_plane_kernel(const T* __restrict__ X, long ldx, int xc,
+                                                             float* __restrict__ Y, int B, int H, int Wd, int Cout,
+                                                             int Ho, int Wo, int align, float mul) {
+    // X: [B][H][W][ldx] channels-last, reads channels xc..xc+Cout-1; Y: [B][Cout][Ho][Wo] planar f32
+    const long total = (long)B * Cout * Ho * Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wo);
+        const int oy = (int)((idx / Wo) % Ho);
+        const int c = (int)((idx / ((long)Wo * Ho)) % Cout);
+        const long b = idx / ((long)Wo * Ho * Cout);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilin_src(oy, H, Ho, align, y0, y1, ly);
+        bilin_src(ox, Wd, Wo, align, x0, x1, lx);
+        const T* base = X + b * H * Wd * ldx + xc + c;
+        const float a = to_f32<T>(base[((long)y0 * Wd + x0) * ldx]);
+        const float bq = to_f32<T>(base[((long)y0 * Wd + x1) * ldx]);
+        const float cc = to_f32<T>(base[((long)y1 * Wd + x0) * ldx]);
+        const float d = to_f32<T>(base[((long)y1 * Wd + x1) * ldx]);
+        Y[idx] = mul * ((1.f - ly) * ((1.f - lx) * a + lx * bq) + ly * ((1.f - lx) * cc + lx * d));
+    }
+}
+
+// ----------------------------------------------------------------------------
+// Y = A op B (op C): elementwise over [M][C] with independent row strides.
+// mode 0: A*B   1: A*B*C3   2: A+B   3: A + bcast(B[row % period])
+template <typename T>
+__global__ __launch_bounds__(256) void eltwise_kernel(const T* __restrict__ A, long lda, const T* __restrict__ Bp,
+                                                      long ldb, const T* __restrict__ C3, long ldc3,
+                                                      T* __restrict__ Y, long ldy, long M, int C, int mode,
+                                                      long period) {
+    const int nv = C >> 2;
+    const long total = M * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nv);
+        const long row = idx / nv;
+        float a[4], b[4], o[4];
+        Vec4<T>::load(A + row * lda + vi * 4, a);
+        const long brow = mode == 3 ? row % period : row;
+        Vec4<T>::load(Bp + brow * ldb + vi * 4, b);
+        if (mode == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = a[j] * b[j];
+        } else if (mode == 1) {
+            float c[4];
+            Vec4<T>::load(C3 + row * ldc3 + vi * 4, c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = a[j] * b[j] * c[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = a[j] + b[j];
+        }
+        Vec4<T>::store(Y + row * ldy + vi * 4, o);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// planar f32 [B][C][P]  ->  channels-last T [B][P][ldy], zero-filling channels C..Cpad-1
+template <typename T>
+__global__ __launch_bounds__(256) void planar_to_cl_kernel(const float* __restrict__ X, T* __restrict__ Y, long ldy,
+                                                           int B, int C, long P, int Cpad) {
+    __shared__ float tile[32][33];
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const long b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i;
+        const long p = p0 + tx;
+        tile[i][tx] = (c < C && p < P) ? X[(b * C + c) * P + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const long p = p0 + i;
+        const int c = c0 + tx;
+        if (p < P && c < Cpad) Y[(b * P + p) * ldy + c] = from_f32<T>(tile[tx][i]);
+    }
+}
+
+// channels-last T [B][P][ldx] (channels xc..xc+C-1)  ->  planar f32 [B][C][P]
+template <typename T>
+__global__ __launch_bounds__(256) void cl_to_planar_kernel(const T* __restrict__ X, long ldx, int xc,
+                                                           float* __restrict__ Y, int B, int C, long P) {
+    __shared__ float tile[32][33];
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const long b = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const long p = p0 + i;
+        const int c = c0 + tx;
+        tile[i][tx] = (p < P && c < C) ? to_f32<T>(X[(b * P + p) * ldx + xc + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i;
+        const long p = p0 + tx;
+        if (c < C && p < P) Y[(b * C + c) * P + p] = tile[tx][i];
+    }
+}
+
+// strided 2-D copy with dtype conversion and zero padding: Y[m][yc + c] = c < C ? X[m][xc + c] : 0, c < Cpad
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void copy_cols_kernel(const TI* __restrict__ X, long ldx, int xc, TO* __restrict__ Y,
+                                                        long ldy, int yc, long M, int C, int Cpad) {
+    const long total = M * Cpad;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % Cpad);
+        const long m = idx / Cpad;
+        const float v = c < C ? to_f32<TI>(X[m * ldx + xc + c]) : 0.f;
+        Y[m * ldy + yc + c] = from_f32<TO>(v);
+    }
+}
+
+// ----------------------------------------------------------------------------
+// GMFlow convex upsampling (gmflow.py:64-77): logits [N][h][w][576] with channel = (k*8+i)*8+j,
+// flow f32 [N][h][w][2]; out f32 planar [N][2][8h][8w].
+template <typename T>
+__global__ __launch_bounds__(256) void convex_up_kernel(const T* __restrict__ L, long ldl,
+                                                        const float* __restrict__ F, float* __restrict__ Y, int N,
+                                                        int H, int Wd) {
+    const long total = (long)N * H * Wd * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ij = (int)(idx & 63);
+        const long pix = idx >> 6;
+        const int x = (int)(pix % Wd);
+        const int y = (int)((pix / Wd) % H);
+        const long n = pix / ((long)Wd * H);
+        float lg[9];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            lg[k] = to_f32<T>(L[pix * ldl + k * 64 + ij]);
+            mx = fmaxf(mx, lg[k]);
+        }
+        float den = 0.f, ax = 0.f, ay = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float e = expf(lg[k] - mx);
+            den += e;
+            const int iy = y + k / 3 - 1, ix = x + k % 3 - 1;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd) {
+                const float* f = F + ((n * H + iy) * Wd + ix) * 2;
+                ax = fmaf(e, 8.f * f[0], ax);
+                ay = fmaf(e, 8.f * f[1], ay);
+            }
+        }
+        const int i = ij >> 3, j = ij & 7;
+        const long Ho = 8L * H, Wo = 8L * Wd;
+        const long o = (n * 2 * Ho + (8L * y + i)) * Wo + 8L * x + j;
+        Y[o] = ax / den;
+        Y[o + Ho * Wo] = ay / den;
+    }
+}
+
+// correspondence (first two columns of O, f32) minus pixel grid -> flow f32 [N][hw][2]
+__global__ __launch_bounds__(256) void corresp_to_flow_kernel(const float* __restrict__ O, long ldo,
+                                                              float* __restrict__ F, long N, int hw, int Wd,
+                                                              int sub_grid) {
+    const long total = N * hw;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int p = (int)(idx % hw);
+        const float gx = sub_grid ? (float)(p % Wd) : 0.f, gy = sub_grid ? (float)(p / Wd) : 0.f;
+        F[idx * 2] = O[idx * ldo] - gx;
+        F[idx * 2 + 1] = O[idx * ldo + 1] - gy;
+    }
+}
+
+template <typename T>
+struct TypeOf { typedef T type; };
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                          \
+    do {                                                \
+        if ((dtype) == EMIP_F32) {                      \
+            typedef float T;                            \
+            __VA_ARGS__;                                \
+        } else {                                        \
+            typedef bf16_t T;                           \
+            __VA_ARGS__;                                \
+        }                                               \
+    } while (0)
+
+#define REQ_DT(dtype) EMIP_REQUIRE((dtype) == EMIP_F32 || (dtype) == EMIP_BF16)
+
+extern "C" int emip_version(void) { return 100; }
+
+extern "C" int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
+                              long M, int C, float eps, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && gamma && beta && M > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
+    EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
+    const int nv = C >> 2;
+    int lg = 0;
+    while ((1 << lg) < nv && lg < 6) ++lg;
+    const int rows_per_wave = 64 >> lg;
+    const long waves = (M + rows_per_wave - 1) / rows_per_wave;
+    const int grid = grid_for(waves, 4);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)X, ldx, (T*)Y, ldy, gamma, beta, M, C, eps, lg));
+    return emip_launch_status();
+}
+
+extern "C" int emip_dwconv3x3(const void* X, long ldx, void* Y, long ldy, const float* Wt, const float* bias, int B,
+                              int H, int Wd, int C, int act, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && Wt && B > 0 && H > 0 && Wd > 0 && C >= 4 && (C & 3) == 0);
+    EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
+    const long total = (long)B * H * Wd * (C >> 2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, Wt, bias, B, H, Wd, C, C,
+                                         act));
+    return emip_launch_status();
+}
+
+extern "C" int emip_dwconv3x3_gated(const void* X, long ldx, void* Y, long ldy, const float* Wt, const float* bias,
+                                    int B, int H, int Wd, int C2, int Cout_pad, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && Wt && B > 0 && H > 0 && Wd > 0 && C2 >= 8 && (C2 & 7) == 0);
+    EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C2 && (Cout_pad & 3) == 0 && Cout_pad >= C2 / 2 &&
+                 ldy >= Cout_pad);
+    const long total = (long)B * H * Wd * (Cout_pad >> 2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, Wt, bias, B, H, Wd, C2,
+                                         Cout_pad, 0));
+    return emip_launch_status();
+}
+
+extern "C" int emip_chan_stats(const void* X, long ldx, double* sums, long groups, long rows, int C, int dtype,
+                               void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && sums && groups > 0 && groups < 65536 && rows > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
+    EMIP_REQUIRE((ldx & 3) == 0 && ldx >= C);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * groups * C, s) != hipSuccess) return EMIP_E_LAUNCH;
+    const int rpb = 512;
+    dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)groups);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(chan_stats_kernel<T>, grid, dim3(256), 0, s, (const T*)X, ldx, sums, rows, C,
+                                         rpb));
+    return emip_launch_status();
+}
+
+extern "C" int emip_chan_norm_apply(const void* X, long ldx, void* Y, long ldy, const void* R, long ldr,
+                                    const double* sums, const float* gamma, const float* beta, long groups, long rows,
+                                    int C, float eps, int relu_inner, int relu_outer, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && sums && groups > 0 && rows > 0 && C >= 4 && (C & 3) == 0);
+    EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
+    EMIP_REQUIRE((gamma == nullptr) == (beta == nullptr));
+    if (R) EMIP_REQUIRE((ldr & 3) == 0 && ldr >= C);
+    const long total = groups * rows * (C >> 2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(chan_norm_apply_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, (const T*)R, ldr, sums,
+                                         gamma, beta, groups, rows, C, eps, relu_inner, relu_outer));
+    return emip_launch_status();
+}
+
+extern "C" int emip_bilinear(const void* X, long ldx, void* Y, long ldy, int B, int H, int Wd, int C, int Ho, int Wo,
+                             int align_corners, float mul, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && B > 0 && H > 0 && Wd > 0 && Ho > 0 && Wo > 0 && C >= 4 && (C & 3) == 0);
+    EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
+    const long total = (long)B * Ho * Wo * (C >> 2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, B, H, Wd, C, Ho, Wo,
+                                         align_corners, mul));
+    return emip_launch_status();
+}
+
+extern "C" int emip_bilinear_planar(const void* X, long ldx, int xc, float* Y, int B, int H, int Wd, int C, int Ho,
+                                    int Wo, int align_corners, float mul, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && B > 0 && H > 0 && Wd > 0 && Ho > 0 && Wo > 0 && C >= 1 && xc >= 0 && ldx >= xc + C);
+    const long total = (long)B * C * Ho * Wo;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_plane_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)X, ldx, xc, Y, B, H, Wd, C, Ho, Wo,
+                                         align_corners, mul));
+    return emip_launch_status();
+}
+
+extern "C" int emip_eltwise(const void* A, long lda, const void* Bp, long ldb, const void* C3, long ldc3, void* Y,
+                            long ldy, long M, int C, int mode, long period, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(A && Bp && Y && M > 0 && C >= 4 && (C & 3) == 0 && mode >= 0 && mode <= 3);
+    EMIP_REQUIRE((lda & 3) == 0 && (ldb & 3) == 0 && (ldy & 3) == 0 && lda >= C && ldb >= C && ldy >= C);
+    if (mode == 1) EMIP_REQUIRE(C3 && (ldc3 & 3) == 0 && ldc3 >= C);
+    if (mode == 3) EMIP_REQUIRE(period > 0);
+    const long total = M * (C >> 2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(eltwise_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)A, lda, (const T*)Bp, ldb, (const T*)C3, ldc3,
+                                         (T*)Y, ldy, M, C, mode, period));
+    return emip_launch_status();
+}
+
+extern "C" int emip_planar_to_cl(const float* X, void* Y, long ldy, int B, int C, long P, int Cpad, int dtype,
+                                 void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && B > 0 && B < 65536 && C > 0 && P > 0 && Cpad >= C && ldy >= Cpad);
+    dim3 grid((unsigned)((P + 31) / 32), (unsigned)((Cpad + 31) / 32), (unsigned)B);
+    EMIP_REQUIRE(grid.y < 65536);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(planar_to_cl_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, X, (T*)Y,
+                                         ldy, B, C, P, Cpad));
+    return emip_launch_status();
+}
+
+extern "C" int emip_cl_to_planar(const void* X, long ldx, int xc, float* Y, int B, int C, long P, int dtype,
+                                 void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && B > 0 && B < 65536 && C > 0 && P > 0 && xc >= 0 && ldx >= xc + C);
+    dim3 grid((unsigned)((P + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
+    EMIP_REQUIRE(grid.y < 65536);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(cl_to_planar_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)X,
+                                         ldx, xc, Y, B, C, P));
+    return emip_launch_status();
+}
+
+extern "C" int emip_copy_cols(const void* X, long ldx, int xc, int x_dtype, void* Y, long ldy, int yc, int y_dtype,
+                              long M, int C, int Cpad, void* stream) {
+    REQ_DT(x_dtype);
+    REQ_DT(y_dtype);
+    EMIP_REQUIRE(X && Y && M > 0 && C > 0 && Cpad >= C && xc >= 0 && yc >= 0 && ldx >= xc + C && ldy >= yc + Cpad);
+    const long total = M * Cpad;
+    const dim3 g(grid_for(total, 256)), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == EMIP_F32 && y_dtype == EMIP_F32)
+        hipLaunchKernelGGL((copy_cols_kernel<float, float>), g, b, 0, s, (const float*)X, ldx, xc, (float*)Y, ldy, yc,
+                           M, C, Cpad);
+    else if (x_dtype == EMIP_F32)
+        hipLaunchKernelGGL((copy_cols_kernel<float, bf16_t>), g, b, 0, s, (const float*)X, ldx, xc, (bf16_t*)Y, ldy,
+                           yc, M, C, Cpad);
+    else if (y_dtype == EMIP_F32)
+        hipLaunchKernelGGL((copy_cols_kernel<bf16_t, float>), g, b, 0, s, (const bf16_t*)X, ldx, xc, (float*)Y, ldy,
+                           yc, M, C, Cpad);
+    else
+        hipLaunchKernelGGL((copy_cols_kernel<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)X, ldx, xc, (bf16_t*)Y, ldy,
+                           yc, M, C, Cpad);
+    return emip_launch_status();
+}
+
+extern "C" int emip_convex_upsample(const void* logits, long ldl, const float* flow, float* out, int N, int H, int Wd,
+                                    int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(logits && flow && out && N > 0 && H > 0 && Wd > 0 && ldl >= 576);
+    const long total = (long)N * H * Wd * 64;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(convex_up_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)logits, ldl, flow, out, N, H, Wd));
+    return emip_launch_status();
+}
+
+extern "C" int emip_corresp_to_flow(const float* O, long ldo, float* flow, long N, int H, int Wd, int sub_grid,
+                                    void* stream) {
+    EMIP_REQUIRE(O && flow && N > 0 && H > 0 && Wd > 0 && ldo >= 2);
+    const long total = N * H * Wd;
+    hipLaunchKernelGGL(corresp_to_flow_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, O, ldo,
+                       flow, N, H * Wd, Wd, sub_grid);
+    return emip_launch_status();
+}

@@ -1,0 +1,277 @@
+"""Tensor-level wrappers over the C ABI (include/emip_hip.h).
+
+PyTorch is used for device memory and streams only: every function here checks
+layouts on the host, allocates the output with torch.empty and hands raw device
+pointers to libemip_hip.so on the current stream.  Activations are channels-last
+([..., C] with unit channel stride; a channel slice of a wider buffer is fine)."""
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_RELU, EMIP_BF16, EMIP_F32  # noqa: F401
+
+
+def dt_code(dtype):
+    if dtype == torch.float32:
+        return EMIP_F32
+    if dtype == torch.bfloat16:
+        return EMIP_BF16
+    raise TypeError(f"emip_amd supports float32 and bfloat16 activations, got {dtype}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _dev(t):
+    if not t.is_cuda:
+        raise _lib.EmipLibraryError("emip_amd ops need device tensors (there is no CPU path)")
+
+
+def rows(t):
+    """(M, C, ld) of a channels-last tensor whose leading dims collapse to rows of stride ld."""
+    _dev(t)
+    assert t.dim() >= 2 and t.stride(-1) == 1, (t.shape, t.stride())
+    ld = t.stride(-2)
+    m = t.shape[-2]
+    for i in range(t.dim() - 3, -1, -1):
+        assert t.shape[i] == 1 or t.stride(i) == t.stride(i + 1) * t.shape[i + 1], (t.shape, t.stride())
+        m *= t.shape[i]
+    return m, t.shape[-1], ld
+
+
+def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None):
+    """out[m, n] = act(a[m, :] . w[n, :] (+ a2 . w[n, K1:]) + bias[n]) + res[m, n]"""
+    M, K1, lda = rows(a)
+    N, K = w.shape
+    lda2 = 0
+    if a2 is not None:
+        M2, K2, lda2 = rows(a2)
+        assert M2 == M and K1 + K2 == K
+    else:
+        assert K1 == K, (K1, K)
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
+    Mo, No, ldc = rows(out)
+    assert Mo == M and No == N and w.dtype == a.dtype and out.dtype == a.dtype and w.is_contiguous()
+    ldr = 0
+    if res is not None:
+        Mr, Nr, ldr = rows(res)
+        assert Mr == M and Nr == N and res.dtype == a.dtype
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == N
+    _lib.call("emip_gemm", _p(a), _p(a2), _p(w), _p(out), _p(bias), _p(res), M, N, K, K1, lda, lda2, K, ldc, ldr, act,
+              1, 0, 0, 0, 0, dt_code(a.dtype), _stream())
+    return out
+
+
+def gemm_batched(a, w, out, batch, M, N, K, lda, ldw, ldc, bsA, bsW, bsC):
+    """Strided-batched gemm on raw views (a, w, out are tensors whose data_ptr is the first operand)."""
+    _dev(a)
+    _lib.call("emip_gemm", _p(a), None, _p(w), _p(out), None, None, M, N, K, K, lda, 0, ldw, ldc, 0, ACT_NONE, batch,
+              bsA, bsW, bsC, 0, dt_code(a.dtype), _stream())
+    return out
+
+
+def conv2d(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None):
+    """x [B,H,W,Cin] channels-last, w packed [Cout, kh*kw*Cin] -> [B,Ho,Wo,Cout]."""
+    _dev(x)
+    B, H, W, Cin = x.shape
+    assert x.stride(-1) == 1 and x.stride(1) == W * x.stride(2) and (B == 1 or x.stride(0) == H * x.stride(1))
+    ldx = x.stride(2)
+    Cout = w.shape[0]
+    assert w.shape[1] == kh * kw * Cin and w.is_contiguous() and w.dtype == x.dtype
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    Mo, No, ldy = rows(out)
+    assert Mo == B * Ho * Wo and No == Cout
+    ldr = 0
+    if res is not None:
+        Mr, Nr, ldr = rows(res)
+        assert Mr == Mo and Nr == Cout
+    _lib.call("emip_conv2d", _p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, ldx, Cout, kh, kw, stride, pad,
+              ldy, ldr, act, dt_code(x.dtype), _stream())
+    return out
+
+
+def layernorm(x, gamma, beta, eps, out=None):
+    M, C, ldx = rows(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    Mo, Co, ldy = rows(out)
+    assert Mo == M and Co == C
+    _lib.call("emip_layernorm", _p(x), ldx, _p(out), ldy, _p(gamma), _p(beta), M, C, float(eps), dt_code(x.dtype),
+              _stream())
+    return out
+
+
+def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo,
+              q_hs=0, k_hs=0, v_hs=0, o_hs=0, q_rows=None, k_rows=None, q_gid=None, k_gid=None, scale=1.0,
+              scores=None, s_bs=0, lds=0):
+    _dev(q)
+    o_f32 = 1 if (out.dtype == torch.float32 and q.dtype != torch.float32) else 0
+    _lib.call("emip_attention", _p(q), _p(k), _p(v), _p(out), _p(scores), batch, heads, nwin, Lq, Lk, D, DV, q_bs,
+              k_bs, v_bs, o_bs, s_bs, ldq, ldk, ldv, ldo, lds, q_hs, k_hs, v_hs, o_hs, _p(q_rows), _p(k_rows),
+              _p(q_gid), _p(k_gid), float(scale), o_f32, dt_code(q.dtype), _stream())
+    return out
+
+
+def mdta_attn(q, kv_k, temperature, B, heads, P):
+    """q [B,P,ldq] view, kv_k [B,P,ldk] view (the k half) -> attn [B,heads,64,64]."""
+    _dev(q)
+    ws = torch.empty(B * heads * (4096 + 128), dtype=torch.float32, device=q.device)
+    attn = torch.empty((B, heads, 64, 64), dtype=q.dtype, device=q.device)
+    _lib.call("emip_mdta_attn", _p(q), q.stride(-2), q.stride(0), _p(kv_k), kv_k.stride(-2), kv_k.stride(0),
+              _p(temperature), _p(ws), _p(attn), B, heads, P, dt_code(q.dtype), _stream())
+    return attn
+
+
+def dwconv3x3(x, wt, bias=None, act=ACT_NONE, out=None):
+    B, H, W, C = x.shape
+    M, _, ldx = rows(x)
+    if out is None:
+        out = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    _, _, ldy = rows(out)
+    _lib.call("emip_dwconv3x3", _p(x), ldx, _p(out), ldy, _p(wt), _p(bias), B, H, W, C, act, dt_code(x.dtype),
+              _stream())
+    return out
+
+
+def dwconv3x3_gated(x, wt, cout_pad, bias=None):
+    B, H, W, C2 = x.shape
+    _, _, ldx = rows(x)
+    out = torch.empty((B, H, W, cout_pad), dtype=x.dtype, device=x.device)
+    _lib.call("emip_dwconv3x3_gated", _p(x), ldx, _p(out), cout_pad, _p(wt), _p(bias), B, H, W, C2, cout_pad,
+              dt_code(x.dtype), _stream())
+    return out
+
+
+def chan_stats(x, groups):
+    M, C, ldx = rows(x)
+    assert M % groups == 0
+    sums = torch.empty((groups, C, 2), dtype=torch.float64, device=x.device)
+    _lib.call("emip_chan_stats", _p(x), ldx, _p(sums), groups, M // groups, C, dt_code(x.dtype), _stream())
+    return sums
+
+
+def chan_norm_apply(x, sums, groups, eps, relu_inner, relu_outer=False, res=None, gamma=None, beta=None, out=None):
+    M, C, ldx = rows(x)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _, _, ldy = rows(out)
+    ldr = rows(res)[2] if res is not None else 0
+    _lib.call("emip_chan_norm_apply", _p(x), ldx, _p(out), ldy, _p(res), ldr, _p(sums), _p(gamma), _p(beta), groups,
+              M // groups, C, float(eps), int(relu_inner), int(relu_outer), dt_code(x.dtype), _stream())
+    return out
+
+
+def bilinear(x, Ho, Wo, align_corners, mul=1.0, out=None):
+    B, H, W, C = x.shape
+    _, _, ldx = rows(x)
+    if out is None:
+        out = torch.empty((B, Ho, Wo, C), dtype=x.dtype, device=x.device)
+    _, _, ldy = rows(out)
+    _lib.call("emip_bilinear", _p(x), ldx, _p(out), ldy, B, H, W, C, Ho, Wo, int(align_corners), float(mul),
+              dt_code(x.dtype), _stream())
+    return out
+
+
+def bilinear_planar(x, xc, C, Ho, Wo, align_corners, mul=1.0):
+    B, H, W, _ = x.shape
+    _, _, ldx = rows(x)
+    out = torch.empty((B, C, Ho, Wo), dtype=torch.float32, device=x.device)
+    _lib.call("emip_bilinear_planar", _p(x), ldx, xc, _p(out), B, H, W, C, Ho, Wo, int(align_corners), float(mul),
+              dt_code(x.dtype), _stream())
+    return out
+
+
+def eltwise(a, b, mode, c3=None, period=0, out=None):
+    M, C, lda = rows(a)
+    _, _, ldb = rows(b)
+    ldc3 = rows(c3)[2] if c3 is not None else 0
+    if out is None:
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    _, _, ldy = rows(out)
+    _lib.call("emip_eltwise", _p(a), lda, _p(b), ldb, _p(c3), ldc3, _p(out), ldy, M, C, mode, period,
+              dt_code(a.dtype), _stream())
+    return out
+
+
+def planar_to_cl(x, dtype, cpad=None):
+    """planar f32 [B,C,H,W] -> channels-last [B,H,W,cpad]"""
+    _dev(x)
+    B, C, H, W = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    cpad = cpad or C
+    out = torch.empty((B, H, W, cpad), dtype=dtype, device=x.device)
+    _lib.call("emip_planar_to_cl", _p(x), _p(out), cpad, B, C, H * W, cpad, dt_code(dtype), _stream())
+    return out
+
+
+def cl_to_planar(x, xc=0, C=None):
+    """channels-last [B,H,W,*] (channels xc..xc+C) -> planar f32 [B,C,H,W]"""
+    B, H, W, Ct = x.shape
+    C = C or Ct
+    _, _, ldx = rows(x)
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    _lib.call("emip_cl_to_planar", _p(x), ldx, xc, _p(out), B, C, H * W, dt_code(x.dtype), _stream())
+    return out
+
+
+def copy_cols(x, xc, C, out, yc, cpad=None):
+    M, _, ldx = rows(x)
+    Mo, _, ldy = rows(out)
+    assert M == Mo
+    _lib.call("emip_copy_cols", _p(x), ldx, xc, dt_code(x.dtype), _p(out), ldy, yc, dt_code(out.dtype), M, C,
+              cpad or C, _stream())
+    return out
+
+
+def convex_upsample(logits, flow):
+    N, H, W, _ = logits.shape
+    assert flow.dtype == torch.float32 and flow.is_contiguous() and flow.shape == (N, H, W, 2)
+    out = torch.empty((N, 2, 8 * H, 8 * W), dtype=torch.float32, device=logits.device)
+    _lib.call("emip_convex_upsample", _p(logits), rows(logits)[2], _p(flow), _p(out), N, H, W, dt_code(logits.dtype),
+              _stream())
+    return out
+
+
+def corresp_to_flow(o, N, H, W, sub_grid):
+    assert o.dtype == torch.float32
+    flow = torch.empty((N, H, W, 2), dtype=torch.float32, device=o.device)
+    _lib.call("emip_corresp_to_flow", _p(o), o.stride(-2), _p(flow), N, H, W, int(sub_grid), _stream())
+    return flow
+
+
+def flow_warp(x, flow):
+    _dev(x)
+    B, C, H, W = x.shape
+    assert x.dtype == torch.float32 and flow.dtype == torch.float32 and x.is_contiguous() and flow.is_contiguous()
+    out = torch.empty_like(x)
+    _lib.call("emip_flow_warp", _p(x), _p(flow), _p(out), B, C, H, W, _stream())
+    return out
+
+
+def occ_corners(flow):
+    _dev(flow)
+    B, _, H, W = flow.shape
+    assert flow.dtype == torch.float32 and flow.is_contiguous()
+    idx = torch.empty((B, 4 * H * W), dtype=torch.int64, device=flow.device)
+    wts = torch.empty((B, 4 * H * W), dtype=torch.float32, device=flow.device)
+    _lib.call("emip_occ_corners", _p(flow), _p(idx), _p(wts), B, H, W, _stream())
+    return idx, wts
+
+
+def occ_mask_backward(flow, th=0.2):
+    _dev(flow)
+    B, _, H, W = flow.shape
+    assert flow.dtype == torch.float32 and flow.is_contiguous()
+    ws = torch.empty((B, H * W), dtype=torch.float32, device=flow.device)
+    occ = torch.empty((B, 1, H, W), dtype=torch.float32, device=flow.device)
+    _lib.call("emip_occ_mask_backward", _p(flow), _p(ws), _p(occ), B, H, W, float(th), _stream())
+    return occ

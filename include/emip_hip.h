@@ -1,0 +1,160 @@
+/* libemip_hip.so -- C ABI of the MI355X (gfx950) kernels behind the EMIP two-stream path.
+ *
+ * The reference (zhangxin06/EMIP) has no native code and no FFI of its own: its hot path is
+ * PyTorch ops dispatched to cuDNN/cuBLAS.  Each entry point below
+ * therefore names the reference call site(s) (paths under /root/reference) whose arithmetic it
+ * replaces.  INTEGRATION.md shows the ctypes binding the host side uses.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller; nothing is allocated or freed here;
+ *  - `stream` is a hipStream_t passed as void* (0 = default stream); calls are asynchronous,
+ *    capture-safe (no allocation, no synchronisation) and re-entrant;
+ *  - activations are channels-last: an image tensor is [B][H][W][C] with an explicit channel
+ *    stride (`ld*`, elements) so that callers can read/write channel slices of wider buffers;
+ *  - `dtype` selects the storage type of activations and packed weights: EMIP_F32 (parity
+ *    mode, exact-f32 MFMA) or EMIP_BF16 (performance mode, f32 accumulation).  Biases,
+ *    normalisation parameters and statistics are always f32;
+ *  - return value: EMIP_OK, or a negative code.  Arguments are validated before any launch
+ *    (a faulting kernel can reset the whole GPU host), no exception crosses the ABI.
+ */
+#ifndef EMIP_HIP_H
+#define EMIP_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMIP_OK 0
+#define EMIP_E_INVALID (-1) /* shape / alignment / enum check failed; nothing was launched */
+#define EMIP_E_LAUNCH (-2)  /* the HIP runtime rejected the launch */
+
+#define EMIP_F32 0
+#define EMIP_BF16 1
+
+#define EMIP_ACT_NONE 0
+#define EMIP_ACT_RELU 1
+#define EMIP_ACT_GELU 2 /* exact erf GELU (nn.GELU default) */
+
+int emip_version(void);
+
+/* ---- dense contractions ------------------------------------------------------------------- */
+
+/* C[z][m][n] = act(sum_k A[z][m][k] * W[z][n][k] + bias[n]) + R[z][m][n]
+ * nn.Linear / 1x1 conv with fused bias, GELU/ReLU and residual add:
+ *   lib/pvt_v2.py:45-54 (fc1, fc2), :103 (q), :110 (kv), :126 (proj), :165-167 (residual adds);
+ *   model/EMIP_short/motion/gmflow/transformer.py:167-196 (q/k/v/merge/mlp; A2 = the second half
+ *   of torch.cat([source, message], -1), columns K1..K-1);
+ *   model/EMIP_short/motion/PromptInteract.py:380-385,413-431 (1x1 convs of the MDTA block).
+ * A2 may be NULL (then K1 is ignored).  bias, R may be NULL.  batch>=1 with element strides bs*. */
+int emip_gemm(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M, int N,
+              int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, int batch, long bsA, long bsW,
+              long bsC, long bsR, int dtype, void* stream);
+
+/* NHWC convolution as implicit GEMM, weights packed [Cout][KH][KW][Cin], same epilogue.
+ * nn.Conv2d call sites: lib/pvt_v2.py:187-188,208 (patch embed), :75,107 (SR conv);
+ *   gmflow/backbone.py:44-47,83,97 (CNN encoder); gmflow/gmflow.py:47-49 (upsampler);
+ *   model/EMIP_short/model.py:59-62 (conv_corr; X is the raw correlation [B][src][tgt], which IS the
+ *   NHWC view of matching.py:18-20's permuted tensor); create_backbone.py:22-36 (ConvBR, BN folded
+ *   into W/bias by the host in eval mode); model/EMIP_long/LTM.py:30-41,74-79. */
+int emip_conv2d(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd, int Cin,
+                long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act, int dtype,
+                void* stream);
+
+/* Fused attention  O = softmax(Q K^T * scale + mask) V  (online softmax, scores never stored unless S!=NULL).
+ * Replaces: lib/pvt_v2.py:121-125 (SRA, D=DV=64, Lk=121); gmflow/transformer.py:46-105 (split-window
+ *   attention; q_rows/k_rows [nwin][L] int32 tables fold torch.roll + split_feature + merge_splits into
+ *   addressing, q_gid/k_gid [nwin][L] region ids reproduce generate_shift_window_attn_mask :19-43 as an
+ *   additive -100); gmflow/matching.py:13-36 (S = raw correlation out, V = pixel grid -> correspondence);
+ *   gmflow/transformer.py:526-531 (flow propagation); model/EMIP_long/LTM.py:57-65 (memory read).
+ * (D,DV) in {(64,64),(128,128),(128,32)}.  Row r of batch b, head hd: X + b*x_bs + hd*x_hs + r*ldx.
+ * The batch index of the launch is b*nwin + win.  O is T, or f32 when o_f32!=0.  S (optional, heads==1,
+ * no q_rows): S[(b*nwin+win)*s_bs + q*lds + k] = scale * <Q_q, K_k> as T. */
+int emip_attention(const void* Q, const void* K, const void* V, void* O, void* S, int batch, int heads, int nwin,
+                   int Lq, int Lk, int D, int DV, long q_bs, long k_bs, long v_bs, long o_bs, long s_bs, long ldq,
+                   long ldk, long ldv, long ldo, long lds, long q_hs, long k_hs, long v_hs, long o_hs,
+                   const int* q_rows, const int* k_rows, const int* q_gid, const int* k_gid, float scale, int o_f32,
+                   int dtype, void* stream);
+
+/* MDTA channel attention matrix: L2-normalise q,k over pixels, 64x64 Gram per head, * temperature, softmax.
+ * PromptInteract.py:423-428.  ws: f32 [B*heads*(4096+128)] scratch; attn out: T [B][heads][64][64]. */
+int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K, long ldk, long k_bs, const float* temperature,
+                   float* ws, void* attn, int B, int heads, int P, int dtype, void* stream);
+
+/* ---- normalisations ------------------------------------------------------------------------ */
+
+/* Row LayerNorm over C channels (biased variance).  nn.LayerNorm call sites lib/pvt_v2.py:137,144,189,78,302
+ * (eps 1e-6 / 1e-5), gmflow/transformer.py:134,145, PromptInteract.py:346-349 (WithBias_LayerNorm). */
+int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta, long M, int C,
+                   float eps, int dtype, void* stream);
+
+/* Per-(group, channel) sum / sum-of-squares over `rows` rows -> sums f64 [groups][C][2] (zeroed inside).
+ * groups = images for nn.InstanceNorm2d (gmflow/backbone.py:40,50-53), 1 for train-mode BatchNorm2d
+ * (create_backbone.py:28, model.py:60). */
+int emip_chan_stats(const void* X, long ldx, double* sums, long groups, long rows, int C, int dtype, void* stream);
+
+/* y = [relu]( R + [relu]( (x-mean)*rstd [*gamma+beta] ) ) using emip_chan_stats output.
+ * gmflow/backbone.py:61-69 (ResidualBlock tail) and train-mode ConvBR. */
+int emip_chan_norm_apply(const void* X, long ldx, void* Y, long ldy, const void* R, long ldr, const double* sums,
+                         const float* gamma, const float* beta, long groups, long rows, int C, float eps,
+                         int relu_inner, int relu_outer, int dtype, void* stream);
+
+/* ---- depthwise / resampling / elementwise ---------------------------------------------------- */
+
+/* Depthwise 3x3 (stride 1, pad 1), weights f32 [9][C].  lib/pvt_v2.py:316-327 (+GELU of :50 fused via act);
+ * PromptInteract.py:402-404 (q_dwconv, kv_dwconv). */
+int emip_dwconv3x3(const void* X, long ldx, void* Y, long ldy, const float* Wt, const float* bias, int B, int H,
+                   int Wd, int C, int act, int dtype, void* stream);
+
+/* Gated depthwise: X has C2 = 2*Ch channels, Y[c] = gelu(dw(X)[c]) * dw(X)[Ch+c], zero for Ch <= c < Cout_pad.
+ * PromptInteract.py:380-384 (GDFN). */
+int emip_dwconv3x3_gated(const void* X, long ldx, void* Y, long ldy, const float* Wt, const float* bias, int B, int H,
+                         int Wd, int C2, int Cout_pad, int dtype, void* stream);
+
+/* Bilinear resize, channels-last in/out, result scaled by mul.  nn.Upsample(x2, align_corners=True)
+ * create_backbone.py:49. */
+int emip_bilinear(const void* X, long ldx, void* Y, long ldy, int B, int H, int Wd, int C, int Ho, int Wo,
+                  int align_corners, float mul, int dtype, void* stream);
+
+/* Bilinear resize of channels xc..xc+C-1 of a channels-last tensor into a planar f32 [B][C][Ho][Wo]:
+ * F.interpolate(pc, scale_factor=8) create_backbone.py:75 (align_corners=0); gmflow.py:58-60 (x8, align 1, mul 8). */
+int emip_bilinear_planar(const void* X, long ldx, int xc, float* Y, int B, int H, int Wd, int C, int Ho, int Wo,
+                         int align_corners, float mul, int dtype, void* stream);
+
+/* Y = A*B (mode 0), A*B*C3 (1), A+B (2), A + B[row % period] (3) over [M][C].
+ * create_backbone.py:63-64 (NCD products); gmflow/utils.py:74-75 (position add); LTM.py:39 (fea + corr). */
+int emip_eltwise(const void* A, long lda, const void* Bp, long ldb, const void* C3, long ldc3, void* Y, long ldy,
+                 long M, int C, int mode, long period, int dtype, void* stream);
+
+/* planar f32 [B][C][P] -> channels-last T [B][P][ldy] (channels C..Cpad-1 zero) and back. */
+int emip_planar_to_cl(const float* X, void* Y, long ldy, int B, int C, long P, int Cpad, int dtype, void* stream);
+int emip_cl_to_planar(const void* X, long ldx, int xc, float* Y, int B, int C, long P, int dtype, void* stream);
+
+/* Y[m][yc+c] = c < C ? X[m][xc+c] : 0 for c < Cpad, converting x_dtype -> y_dtype (torch.cat pieces). */
+int emip_copy_cols(const void* X, long ldx, int xc, int x_dtype, void* Y, long ldy, int yc, int y_dtype, long M,
+                   int C, int Cpad, void* stream);
+
+/* Convex x8 flow upsampling: softmax over 9 logits, weighted 3x3 neighbourhood of 8*flow.  gmflow.py:64-77.
+ * logits T [N][H][W][>=576], flow f32 [N][H][W][2], out f32 planar [N][2][8H][8W]. */
+int emip_convex_upsample(const void* logits, long ldl, const float* flow, float* out, int N, int H, int Wd, int dtype,
+                         void* stream);
+
+/* flow[n][p][0:2] = O[n][p][0:2] - (sub_grid ? pixel (x,y) of p : 0).  gmflow/matching.py:36-39. */
+int emip_corresp_to_flow(const float* O, long ldo, float* flow, long N, int H, int Wd, int sub_grid, void* stream);
+
+/* ---- flow-side loss (planar f32) --------------------------------------------------------------- */
+
+/* Bilinear warp, border padding, align_corners=True.  loss/warp_utils.py:83-93. */
+int emip_flow_warp(const float* X, const float* flow, float* Y, int B, int C, int H, int W, void* stream);
+
+/* Corner indices int64 [B][4][H*W] and weights f32 [B][4][H*W] of get_corresponding_map, reference corner order.
+ * loss/warp_utils.py:43-70.  Indices are bit-exact with the reference. */
+int emip_occ_corners(const float* flow, long long* indices, float* weights, int B, int H, int W, void* stream);
+
+/* get_occu_mask_backward: occ = clamp(scatter_add(weights), 0, 1) < th.  loss/warp_utils.py:72-80,106-112. */
+int emip_occ_mask_backward(const float* flow, float* cmap_ws, float* occ, int B, int H, int W, float th,
+                           void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
