@@ -1,0 +1,177 @@
+"""PVTv2-b5 segmentation backbone on MI355X kernels.
+
+Same module tree / state_dict keys as /root/reference/lib/pvt_v2.py (patch_embed{i}, block{i}.{j}.
+{norm1,attn.{q,kv,sr,norm,proj},norm2,mlp.{fc1,dwconv.dwconv,fc2}}, norm{i}), so reference checkpoints
+load unchanged.  The forward is re-designed for CDNA4: tokens stay channels-last [B,H,W,C] from the patch
+embed to the stage output (no permutes), every Linear is the MFMA GEMM with bias/GELU/residual fused in
+its epilogue, the spatial-reduction conv is an implicit GEMM over non-overlapping patches, and
+softmax(q k^T) v runs in one fused attention kernel whose 121-key K/V tile lives in LDS.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..nn_base import EmipModule, f32, pack_conv, pack_dw, pack_linear, to_cl, to_planar
+
+
+class DWConv(EmipModule):
+    """Parameter holder for the Mlp's depthwise 3x3 (pvt_v2.py:316-327)."""
+
+    def __init__(self, dim=768):
+        super().__init__()
+        self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
+
+
+class Mlp(EmipModule):
+    """fc1 -> depthwise 3x3 -> GELU -> fc2 (pvt_v2.py:45-54); GELU is fused into the depthwise kernel."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.dwconv = DWConv(hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features)
+
+    def run(self, h, residual):
+        dt = self.cdtype
+        w1, b1, wd, bd, w2, b2 = self.packed(
+            "mlp", (self.fc1.weight, self.fc1.bias, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias,
+                    self.fc2.weight, self.fc2.bias),
+            lambda a, b, c, d, e, f: (pack_linear(a, dt), f32(b), pack_dw(c), f32(d), pack_linear(e, dt), f32(f)))
+        t = ops.gemm(h, w1, bias=b1)
+        t = ops.dwconv3x3(t, wd, bd, act=ops.ACT_GELU)
+        return ops.gemm(t, w2, bias=b2, res=residual, out=residual)
+
+
+class Attention(EmipModule):
+    """Spatial-reduction attention (pvt_v2.py:57-129), head_dim 64, 121 keys in every stage."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, sr_ratio=1):
+        super().__init__()
+        assert dim % num_heads == 0, f"dim {dim} should be divided by num_heads {num_heads}."
+        self.dim, self.num_heads, self.sr_ratio = dim, num_heads, sr_ratio
+        self.scale = (dim // num_heads) ** -0.5
+        self.q = nn.Linear(dim, dim, bias=qkv_bias)
+        self.kv = nn.Linear(dim, dim * 2, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        if sr_ratio > 1:
+            self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.norm = nn.LayerNorm(dim)
+
+    def run(self, h, residual):
+        """h: normed tokens [B,H,W,C]; returns residual + proj(attn) written in place."""
+        dt, C, heads, sr = self.cdtype, self.dim, self.num_heads, self.sr_ratio
+        B, H, W, _ = h.shape
+        assert C // heads == 64, "the fused attention kernel is built for head_dim 64"
+        wq, bq, wkv, bkv, wp, bp = self.packed(
+            "lin", (self.q.weight, self.q.bias, self.kv.weight, self.kv.bias, self.proj.weight, self.proj.bias),
+            lambda a, b, c, d, e, f: (pack_linear(a, dt), f32(b), pack_linear(c, dt), f32(d), pack_linear(e, dt),
+                                      f32(f)))
+        q = ops.gemm(h, wq, bias=bq)
+        if sr > 1:
+            wsr, bsr, g, be = self.packed("sr", (self.sr.weight, self.sr.bias, self.norm.weight, self.norm.bias),
+                                          lambda a, b, c, d: (pack_conv(a, dt), f32(b), f32(c), f32(d)))
+            s = ops.conv2d(h, wsr, sr, sr, sr, 0, bias=bsr)
+            s = ops.layernorm(s, g, be, self.norm.eps)
+        else:
+            s = h
+        Lk = s.shape[1] * s.shape[2]
+        kv = ops.gemm(s, wkv, bias=bkv)                      # [B,h,w,2C]: k = [:C], v = [C:], head hd at hd*64
+        N = H * W
+        a = torch.empty((B, H, W, C), dtype=dt, device=h.device)
+        ops.attention(q, kv, kv[..., C:], a, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
+                      k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
+                      k_hs=64, v_hs=64, o_hs=64, scale=self.scale)
+        return ops.gemm(a, wp, bias=bp, res=residual, out=residual)
+
+
+class Block(EmipModule):
+    """Pre-LN residual block (pvt_v2.py:132-169).  DropPath acts in train mode only."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, drop_path=0., norm_layer=nn.LayerNorm,
+                 sr_ratio=1):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, sr_ratio=sr_ratio)
+        self.drop_path_rate = float(drop_path)
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
+
+    def run(self, x):
+        if self.training and self.drop_path_rate > 0:
+            raise NotImplementedError("stochastic depth (train mode) is not built yet; call .eval()")
+        g1, b1, g2, b2 = self.packed("ln", (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias),
+                                     lambda a, b, c, d: (f32(a), f32(b), f32(c), f32(d)))
+        x = self.attn.run(ops.layernorm(x, g1, b1, self.norm1.eps), x)
+        x = self.mlp.run(ops.layernorm(x, g2, b2, self.norm2.eps), x)
+        return x
+
+
+class OverlapPatchEmbed(EmipModule):
+    """Overlapping strided conv + LayerNorm (pvt_v2.py:172-214)."""
+
+    def __init__(self, img_size=224, patch_size=7, stride=4, in_chans=3, embed_dim=768):
+        super().__init__()
+        assert patch_size > stride, "Set larger patch_size than stride"
+        self.patch_size, self.stride = patch_size, stride
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
+        self.norm = nn.LayerNorm(embed_dim)
+
+    def run(self, x):
+        dt = self.cdtype
+        cin = x.shape[-1]  # the image arrives with its 3 channels zero-padded to 8
+        w, b, g, be = self.packed("pe", (self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias),
+                                  lambda a, bb, c, d: (pack_conv(a, dt, cin_pad=cin), f32(bb), f32(c), f32(d)))
+        y = ops.conv2d(x, w, self.patch_size, self.patch_size, self.stride, self.patch_size // 2, bias=b)
+        return ops.layernorm(y, g, be, self.norm.eps, out=y)
+
+
+class PyramidVisionTransformerV2(EmipModule):
+    def __init__(self, img_size=224, in_chans=3, embed_dims=(64, 128, 256, 512), num_heads=(1, 2, 4, 8),
+                 mlp_ratios=(4, 4, 4, 4), qkv_bias=False, drop_path_rate=0., norm_layer=nn.LayerNorm,
+                 depths=(3, 4, 6, 3), sr_ratios=(8, 4, 2, 1), num_stages=4, pretrained=None):
+        super().__init__()
+        self.depths, self.num_stages = depths, num_stages
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, sum(depths))]
+        cur = 0
+        for i in range(num_stages):
+            setattr(self, f"patch_embed{i + 1}", OverlapPatchEmbed(
+                img_size=img_size if i == 0 else img_size // (2 ** (i + 1)), patch_size=7 if i == 0 else 3,
+                stride=4 if i == 0 else 2, in_chans=in_chans if i == 0 else embed_dims[i - 1],
+                embed_dim=embed_dims[i]))
+            setattr(self, f"block{i + 1}", nn.ModuleList([
+                Block(dim=embed_dims[i], num_heads=num_heads[i], mlp_ratio=mlp_ratios[i], qkv_bias=qkv_bias,
+                      drop_path=dpr[cur + j], norm_layer=norm_layer, sr_ratio=sr_ratios[i])
+                for j in range(depths[i])]))
+            setattr(self, f"norm{i + 1}", norm_layer(embed_dims[i]))
+            cur += depths[i]
+
+    def run(self, x):
+        """x: channels-last image [B,H,W,8] -> list of the 4 stage outputs, channels-last."""
+        outs = []
+        for i in range(self.num_stages):
+            x = getattr(self, f"patch_embed{i + 1}").run(x)
+            for blk in getattr(self, f"block{i + 1}"):
+                x = blk.run(x)
+            norm = getattr(self, f"norm{i + 1}")
+            g, b = self.packed(f"n{i}", (norm.weight, norm.bias), lambda a, c: (f32(a), f32(c)))
+            x = ops.layernorm(x, g, b, norm.eps)
+            outs.append(x)
+        return outs
+
+    def forward_features(self, x):
+        return [to_planar(o) for o in self.run(to_cl(x, self.cdtype, 8))]
+
+    def forward(self, x):
+        return self.forward_features(x)
+
+
+class pvt_v2_b5(PyramidVisionTransformerV2):
+    """embed 64/128/320/512, heads 1/2/5/8, depths 3/6/40/3, sr 8/4/2/1, LN eps 1e-6 (pvt_v2.py:395-401)."""
+
+    def __init__(self, **kwargs):
+        from functools import partial
+        super().__init__(embed_dims=[64, 128, 320, 512], num_heads=[1, 2, 5, 8], mlp_ratios=[4, 4, 4, 4],
+                         qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), depths=[3, 6, 40, 3],
+                         sr_ratios=[8, 4, 2, 1], drop_path_rate=0.1, pretrained=kwargs.get("pretrained"))

@@ -1,0 +1,160 @@
+"""Backbone wrapper, ConvBR, DimensionalReduction and the neighbour-connection decoder.
+
+Module names follow /root/reference/model/EMIP_short/create_backbone.py so that state_dict keys match
+(backbone.feat_net.pvtv2_en.*, backbone.decoder.NCD.*, decoder.*, dr{1,2,3}.reduce.{0,1}.{conv,bn}.*).
+Forward passes run on channels-last tensors: a ConvBR is ONE implicit-GEMM launch (BatchNorm folded
+into the packed weights in eval mode, ReLU in the epilogue); torch.cat is replaced by writing each
+producer straight into its channel slice of the concat buffer.
+"""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...nn_base import EmipModule, f32, fold_bn, pack_conv, to_cl, to_planar
+
+
+class ConvBR(EmipModule):
+    """conv3x3 (no bias) + BatchNorm2d + ReLU (create_backbone.py:22-42)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, dilation=1):
+        super().__init__()
+        assert dilation == 1
+        self.k, self.s, self.p = kernel_size, stride, padding
+        self.conv = nn.Conv2d(in_channel, out_channel, kernel_size, stride=stride, padding=padding, bias=False)
+        self.bn = nn.BatchNorm2d(out_channel)
+        nn.init.kaiming_normal_(self.conv.weight, a=1)
+
+    def run(self, x, out=None):
+        dt = self.cdtype
+        if self.training:
+            return conv_bn_train(self, self.conv, self.bn, x, self.k, self.s, self.p, out=out)
+        w, b = self.packed("w", (self.conv.weight, self.bn.weight, self.bn.bias, self.bn.running_mean,
+                                 self.bn.running_var),
+                           lambda cw, *_: (lambda wb: (pack_conv(wb[0], dt), wb[1]))(fold_bn(cw, None, self.bn)))
+        return ops.conv2d(x, w, self.k, self.k, self.s, self.p, bias=b, act=ops.ACT_RELU, out=out)
+
+    def forward(self, x):
+        return to_planar(self.run(to_cl(x, self.cdtype)))
+
+
+def conv_bn_train(owner, conv, bn, x, k, s, p, out=None, relu=True):
+    """Train-mode conv + BatchNorm with per-replica batch statistics (the reference keeps plain
+    BatchNorm2d under DDP, train.py:279) + ReLU.  Running buffers are updated like nn.BatchNorm2d."""
+    dt = owner.cdtype
+    w, b = owner.packed("wt", (conv.weight,) + ((conv.bias,) if conv.bias is not None else ()),
+                        lambda cw, *cb: (pack_conv(cw, dt), f32(cb[0]) if cb else None))
+    g, be = owner.packed("bn", (bn.weight, bn.bias), lambda a, c: (f32(a), f32(c)))
+    y = ops.conv2d(x, w, k, k, s, p, bias=b)
+    sums = ops.chan_stats(y, 1)
+    with torch.no_grad():
+        n = y.shape[0] * y.shape[1] * y.shape[2]
+        mean = (sums[0, :, 0] / n)
+        var = (sums[0, :, 1] / n - mean * mean).clamp_min(0)
+        m = bn.momentum
+        bn.running_mean.mul_(1 - m).add_(mean.float() * m)
+        bn.running_var.mul_(1 - m).add_((var * n / max(n - 1, 1)).float() * m)
+        bn.num_batches_tracked.add_(1)
+    return ops.chan_norm_apply(y, sums, 1, bn.eps, relu_inner=relu, gamma=g, beta=be, out=out if out is not None else y)
+
+
+class DimensionalReduction(EmipModule):
+    """Two ConvBR (create_backbone.py:199-208)."""
+
+    def __init__(self, in_channel, out_channel):
+        super().__init__()
+        self.reduce = nn.Sequential(ConvBR(in_channel, out_channel, 3, padding=1),
+                                    ConvBR(out_channel, out_channel, 3, padding=1))
+
+    def run(self, x):
+        return self.reduce[1].run(self.reduce[0].run(x))
+
+    def forward(self, x):
+        return to_planar(self.run(to_cl(x, self.cdtype)))
+
+
+class NeighborConnectionDecoder(EmipModule):
+    """NCD (create_backbone.py:46-76): x2 bilinear upsampling (align_corners=True), ConvBR, elementwise
+    products, two concats, 1x1 head, x8 bilinear (align_corners=False) to the mask logits."""
+
+    def __init__(self, channel):
+        super().__init__()
+        c = self.channel = channel
+        self.conv_upsample1 = ConvBR(c, c, 3, padding=1)
+        self.conv_upsample2 = ConvBR(c, c, 3, padding=1)
+        self.conv_upsample3 = ConvBR(c, c, 3, padding=1)
+        self.conv_upsample4 = ConvBR(c, c, 3, padding=1)
+        self.conv_upsample5 = ConvBR(2 * c, 2 * c, 3, padding=1)
+        self.conv_concat2 = ConvBR(2 * c, 2 * c, 3, padding=1)
+        self.conv_concat3 = ConvBR(3 * c, 3 * c, 3, padding=1)
+        self.conv4 = ConvBR(3 * c, 3 * c, 3, padding=1)
+        self.conv5 = nn.Conv2d(3 * c, 1, 1)
+
+    @staticmethod
+    def _up2(x):
+        return ops.bilinear(x, 2 * x.shape[1], 2 * x.shape[2], True)
+
+    def run(self, zt5, zt4, zt3):
+        """channels-last inputs [B,11,11,c], [B,22,22,c], [B,44,44,c] -> planar f32 logits [B,1,352,352]"""
+        dt, c = self.cdtype, self.channel
+        B = zt5.shape[0]
+        up5, up4 = self._up2(zt5), self._up2(zt4)
+        cat2 = torch.empty((B,) + tuple(zt4.shape[1:3]) + (2 * c,), dtype=dt, device=zt5.device)
+        cat3 = torch.empty((B,) + tuple(zt3.shape[1:3]) + (3 * c,), dtype=dt, device=zt5.device)
+        zt4_1 = ops.eltwise(self.conv_upsample1.run(up5), zt4, 0, out=cat2[..., :c])
+        self.conv_upsample4.run(up5, out=cat2[..., c:])
+        ops.eltwise(self.conv_upsample2.run(self._up2(zt4_1)), self.conv_upsample3.run(up4), 1, c3=zt3,
+                    out=cat3[..., :c])
+        zt4_2 = self.conv_concat2.run(cat2)
+        self.conv_upsample5.run(self._up2(zt4_2), out=cat3[..., c:])
+        x = self.conv4.run(self.conv_concat3.run(cat3))
+        w5, b5 = self.packed("c5", (self.conv5.weight, self.conv5.bias),
+                             lambda a, b: (a.detach().reshape(1, -1).to(dt).contiguous(), f32(b)))
+        pc = ops.gemm(x, w5, bias=b5)                       # [B,44,44,1]
+        self.last_pc = pc
+        return ops.bilinear_planar(pc, 0, 1, 8 * pc.shape[1], 8 * pc.shape[2], False)
+
+    def forward(self, zt5, zt4, zt3):
+        dt = self.cdtype
+        return self.run(to_cl(zt5, dt), to_cl(zt4, dt), to_cl(zt3, dt))
+
+
+class FeatureExtraction(EmipModule):
+    """Backbone selector (create_backbone.py:78-163).  Only the shipped configuration, pvt_v2_b5, is built
+    (configs/configs.yaml:33); the reference's other branches are unused and partly unimportable."""
+
+    def __init__(self, channel=32, pretrained=None, backbone_name='pvt_v2_b5', input_shape=None):
+        super().__init__()
+        self.backbone_name = backbone_name
+        if backbone_name != 'pvt_v2_b5':
+            raise Exception("Invalid Architecture Symbol: {}".format(backbone_name))
+        from ...lib.pvt_v2 import pvt_v2_b5
+        self.pvtv2_en = pvt_v2_b5(pretrained=None, in_channel_list=input_shape)
+
+    def run(self, img_cl):
+        return self.pvtv2_en.run(img_cl)[1:]
+
+    def forward(self, x):
+        return tuple(to_planar(o) for o in self.run(to_cl(x, self.cdtype, 8)))
+
+
+class Decoder(EmipModule):
+    def __init__(self, channel=32):
+        super().__init__()
+        self.NCD = NeighborConnectionDecoder(channel)
+
+    def forward(self, x):
+        return self.NCD(x[2], x[1], x[0])
+
+
+class Network(EmipModule):
+    """feat_net + (unused by EMIP) decoder, create_backbone.py:182-196."""
+
+    def __init__(self, channel=32, pretrained=None, backbone_name='pvt_v2_b5', input_shape=None):
+        super().__init__()
+        self.channel = channel
+        self.feat_net = FeatureExtraction(channel=channel, pretrained=pretrained, backbone_name=backbone_name,
+                                          input_shape=input_shape)
+        self.decoder = Decoder(self.channel)
+
+    def forward(self, x):
+        return self.decoder(self.feat_net(x))

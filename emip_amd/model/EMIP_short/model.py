@@ -1,0 +1,106 @@
+"""EMIP-short surface: CoUpdater(args).forward(image1, image2) -> (mask, flow_fw, flow_bw).
+
+Drop-in for /root/reference/model/EMIP_short/model.py: same constructor dictionary, same forward signature and
+return structure, same state_dict keys (including the reference's never-called modules dr2_new, dr3_new,
+downscaling1, upscaling3/4 and backbone.decoder, which exist as parameters only).  The forward is a fixed
+sequence of libemip_hip.so launches on the current stream: both frames go through the PVTv2 and GMFlow-CNN
+streams as ONE batch of 2B images, activations stay channels-last in HBM between kernels, and only the two
+boundary conversions (planar images in, planar mask/flows out) touch the reference's NCHW layout.
+"""
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from ...nn_base import EmipModule, f32, fold_bn, pack_conv, to_cl
+from .create_backbone import DimensionalReduction, NeighborConnectionDecoder, Network, conv_bn_train
+from .motion.common import LayerNorm2d
+from .motion.gmflow.gmflow import GMFlow
+from .motion.PromptInteract import Injector
+
+
+class CoUpdater(EmipModule):
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args
+        self.channel = args['channel']
+        self.test_mode = args['test_mode']
+        self.corr_levels, self.corr_radius = args['corr_levels'], args['corr_radius']
+        self.hidden_dim, self.context_dim = args['hidden_dim'], args['context_dim']
+        self.iters, self.inp_size = args['iters'], args['inp_size']
+
+        self.backbone = Network(channel=self.channel, pretrained=None, backbone_name=args['backbone_name'],
+                                input_shape=args['in_channel_list'])
+        self.decoder = NeighborConnectionDecoder(self.channel)
+        self.GMFlow = GMFlow(feature_channels=args['GMFlow']['feature_channels'], args=args)
+        self.dr1 = DimensionalReduction(128, self.channel)
+        self.dr2 = DimensionalReduction(320, self.channel)
+        self.dr3 = DimensionalReduction(512, self.channel)
+        self.conv_corr = nn.Sequential(nn.Conv2d(44 * 44, 968, 3, 1, 1), nn.BatchNorm2d(968), nn.ReLU(inplace=True),
+                                       nn.Conv2d(968, 128, 3, 1, 1))
+        self.injector = Injector()
+        self.injector1 = Injector()
+        # ---- parameters the reference registers but never uses in forward (model.py:53-58,66-84)
+        self.dr2_new = nn.Conv2d(128, 32, kernel_size=3, stride=2, padding=1)
+        self.dr3_new = nn.Sequential(nn.Conv2d(128, 64, 3, 2, 1), nn.BatchNorm2d(64), nn.ReLU(inplace=True),
+                                     nn.Conv2d(64, 32, 3, 2, 1), nn.BatchNorm2d(32), nn.ReLU(inplace=True))
+        self.downscaling1 = nn.Sequential(nn.Conv2d(64, 128, kernel_size=2, stride=2), LayerNorm2d(128), nn.GELU())
+        self.upscaling4 = nn.Sequential(nn.ConvTranspose2d(512, 256, kernel_size=2, stride=2), LayerNorm2d(256),
+                                        nn.GELU(), nn.ConvTranspose2d(256, 128, kernel_size=2, stride=2), nn.GELU())
+        self.upscaling3 = nn.Sequential(nn.ConvTranspose2d(320, 128, kernel_size=2, stride=2), LayerNorm2d(128),
+                                        nn.GELU())
+
+    # ------------------------------------------------------------------------------------------
+    def run_conv_corr(self, corr):
+        """corr: [B, src, tgt] = channels-last [B,44,44,1936] (the reference's permuted view, matching.py:18-20)."""
+        dt = self.cdtype
+        B, n, _ = corr.shape
+        h = w = int(round(n ** 0.5))
+        x = corr.view(B, h, w, n)
+        c0, bn, c3 = self.conv_corr[0], self.conv_corr[1], self.conv_corr[3]
+        w3, b3 = self.packed("cc3", (c3.weight, c3.bias), lambda a, b: (pack_conv(a, dt), f32(b)))
+        if self.training:
+            y = conv_bn_train(self, c0, bn, x, 3, 1, 1)
+        else:
+            w0, b0 = self.packed("cc0", (c0.weight, c0.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var),
+                                 lambda cw, cb, *_: (lambda wb: (pack_conv(wb[0], dt), wb[1]))(fold_bn(cw, cb, bn)))
+            y = ops.conv2d(x, w0, 3, 3, 1, 1, bias=b0, act=ops.ACT_RELU)
+        return ops.conv2d(y, w3, 3, 3, 1, 1, bias=b3)
+
+    def run(self, image1, image2):
+        """Planar images [B,3,H,W] -> (mask planar f32, flow predictions [2B,2,H,W] list, intermediates)."""
+        dt = self.cdtype
+        B = image1.shape[0]
+        imgs = to_cl(torch.cat((image1, image2), 0), dt, 8)            # [2B,H,W,8]
+        fea = self.backbone.feat_net.run(imgs)                         # stages 2..4 of both frames
+        gm = self.GMFlow.backbone.run(imgs)                            # [2B,44,44,128]
+        ab = self.injector.run(gm, fea[0])                             # camouflage feeder (shared weights)
+        preds, corr = self.GMFlow.run(ab[:B], ab[B:])
+        cc = self.run_conv_corr(corr)                                  # motion collector, part 1
+        fea_new = self.injector1.run(fea[0][:B], cc)
+        f1 = self.dr1.run(fea_new)
+        f2 = self.dr2.run(fea[1][:B])
+        f3 = self.dr3.run(fea[2][:B])
+        mask = self.decoder.run(f3, f2, f1)
+        self.last = dict(fea=fea, gm=gm, ab=ab, corr=corr, conv_corr=cc, inj1=fea_new, dr=(f1, f2, f3))
+        return mask, preds
+
+    def forward(self, image1, image2):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # The backward kernels are not part of this build yet: refuse rather than return tensors that
+            # silently carry no gradient.
+            raise NotImplementedError("emip_amd CoUpdater: run forward under torch.no_grad() (inference build)")
+        B = image1.shape[0]
+        mask, preds = self.run(image1, image2)
+        flow_fw = [p[:B] for p in preds]
+        flow_bw = [p[B:] for p in preds]
+        return mask, flow_fw, flow_bw
+
+    def postprocess_masks(self, masks: torch.Tensor, input_size: Tuple[int, ...],
+                          original_size: Tuple[int, ...]) -> torch.Tensor:
+        """model.py:105-134 (unused by the drivers): resize to input_size, crop, resize to original_size."""
+        import torch.nn.functional as F
+        masks = F.interpolate(masks, (input_size, input_size), mode="bilinear", align_corners=False)
+        masks = masks[..., :input_size, :input_size]
+        return F.interpolate(masks, original_size, mode="bilinear", align_corners=False)

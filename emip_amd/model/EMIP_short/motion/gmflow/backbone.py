@@ -1,0 +1,86 @@
+"""GMFlow CNN encoder (1/8 resolution features) on MI355X kernels.
+
+Keys match /root/reference/model/EMIP_short/motion/gmflow/backbone.py (conv1, layer{1,2,3}.{0,1}.{conv1,conv2,
+downsample.0}, conv2, plus the never-called adaptor parameters dwconv64/96/128, dwconv_pre, dwconv, dwconv_post
+which exist only as state_dict entries).  Each 3x3 conv is an implicit GEMM; InstanceNorm2d (affine=False, no
+running statistics) is a per-(image, channel) statistics pass plus one fused normalise/ReLU/residual pass.
+"""
+import torch.nn as nn
+
+from ..... import ops
+from .....nn_base import EmipModule, f32, pack_conv, pack_linear, to_cl, to_planar
+
+
+def _inorm(y, relu, res=None, relu_outer=False):
+    B = y.shape[0]
+    sums = ops.chan_stats(y, B)
+    return ops.chan_norm_apply(y, sums, B, 1e-5, relu_inner=relu, relu_outer=relu_outer, res=res, out=y)
+
+
+class ResidualBlock(EmipModule):
+    """backbone.py:39-69"""
+
+    def __init__(self, in_planes, planes, norm_layer=nn.InstanceNorm2d, stride=1, dilation=1):
+        super().__init__()
+        assert dilation == 1
+        self.stride = stride
+        self.conv1 = nn.Conv2d(in_planes, planes, kernel_size=3, padding=1, stride=stride, bias=False)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, padding=1, bias=False)
+        if stride == 1 and in_planes == planes:
+            self.downsample = None
+        else:
+            self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride),
+                                            norm_layer(planes))
+
+    def run(self, x):
+        dt = self.cdtype
+        w1, w2 = self.packed("w", (self.conv1.weight, self.conv2.weight),
+                             lambda a, b: (pack_conv(a, dt), pack_conv(b, dt)))
+        y = _inorm(ops.conv2d(x, w1, 3, 3, self.stride, 1), relu=True)
+        y = ops.conv2d(y, w2, 3, 3, 1, 1)
+        if self.downsample is not None:
+            wd, bd = self.packed("d", (self.downsample[0].weight, self.downsample[0].bias),
+                                 lambda a, b: (pack_conv(a, dt), f32(b)))
+            x = _inorm(ops.conv2d(x, wd, 1, 1, self.stride, 0, bias=bd), relu=False)
+        return _inorm(y, relu=True, res=x, relu_outer=True)
+
+
+class CNNEncoder(EmipModule):
+    """backbone.py:72-192 with num_output_scales == 1 (strides 2, 1, 2, 2 -> 1/8)."""
+
+    def __init__(self, output_dim=128, norm_layer=nn.InstanceNorm2d, num_output_scales=1, **kwargs):
+        super().__init__()
+        assert num_output_scales == 1, "EMIP uses a single 1/8 scale (gmflow.py:13-21)"
+        dims = [64, 96, 128]
+        self.conv1 = nn.Conv2d(3, dims[0], kernel_size=7, stride=2, padding=3, bias=False)
+        self.in_planes = dims[0]
+        self.layer1 = self._make_layer(dims[0], 1, norm_layer)
+        self.layer2 = self._make_layer(dims[1], 2, norm_layer)
+        self.layer3 = self._make_layer(dims[2], 2, norm_layer)
+        self.conv2 = nn.Conv2d(dims[2], output_dim, 1, 1, 0)
+        # adaptor parameters of the reference (backbone.py:99-111): registered, never used in forward
+        self.dwconv64 = nn.Conv2d(64, 64, 3, 1, 1, bias=True, groups=64)
+        self.dwconv96 = nn.Conv2d(96, 96, 3, 1, 1, bias=True, groups=96)
+        self.dwconv128 = nn.Conv2d(128, 128, 3, 1, 1, bias=True, groups=128)
+        self.dwconv_pre = nn.Conv2d(64, 16, kernel_size=3, stride=1, padding=1, bias=False)
+        self.dwconv = nn.Conv2d(16, 16, 3, 1, 1, bias=True, groups=16)
+        self.dwconv_post = nn.Conv2d(16, 64, kernel_size=3, stride=1, padding=1, bias=False)
+
+    def _make_layer(self, dim, stride, norm_layer):
+        layers = (ResidualBlock(self.in_planes, dim, norm_layer, stride=stride), ResidualBlock(dim, dim, norm_layer))
+        self.in_planes = dim
+        return nn.Sequential(*layers)
+
+    def run(self, img_cl):
+        dt = self.cdtype
+        cin = img_cl.shape[-1]
+        w1, w2, b2 = self.packed("w", (self.conv1.weight, self.conv2.weight, self.conv2.bias),
+                                 lambda a, b, c: (pack_conv(a, dt, cin_pad=cin), pack_linear(b.reshape(b.shape[0], -1), dt),
+                                                  f32(c)))
+        x = _inorm(ops.conv2d(img_cl, w1, 7, 7, 2, 3), relu=True)
+        for layer in (self.layer1, self.layer2, self.layer3):
+            x = layer[1].run(layer[0].run(x))
+        return ops.gemm(x, w2, bias=b2)
+
+    def forward(self, x):
+        return [to_planar(self.run(to_cl(x, self.cdtype, 8)))]

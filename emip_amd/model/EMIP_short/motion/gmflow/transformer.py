@@ -1,0 +1,154 @@
+"""GMFlow feature transformer and flow-propagation attention on MI355X kernels.
+
+State-dict layout follows /root/reference/model/EMIP_short/motion/gmflow/transformer.py:
+layers.{i}.{self_attn,cross_attn_ffn}.{q_proj,k_proj,v_proj,merge,norm1[,mlp.0,mlp.2,norm2],adaptor_fc1,adaptor_fc2}
+and feature_flow_attn.{q_proj,k_proj}.  Design differences from the reference's op stream:
+  * both frames run as one [2B, 1936, 128] token batch; q/k/v of the self-attention are ONE GEMM (N = 384);
+  * the cross-attention target is "the other half of the batch at block start": its k/v projection is written
+    with the halves swapped, so no concatenated/rolled copies of the features are ever made;
+  * window split, cyclic shift and the -100 shift mask are index tables of the fused attention kernel;
+  * torch.cat([source, message]) feeding the FFN is a two-source K loop inside the GEMM.
+"""
+import torch
+import torch.nn as nn
+
+from ..... import ops
+from .....nn_base import EmipModule, f32, pack_linear
+from .tables import window_tables
+
+
+class TransformerLayer(EmipModule):
+    """Parameter holder + packing for one attention layer (transformer.py:108-211)."""
+
+    def __init__(self, d_model=256, nhead=1, attention_type='swin', no_ffn=False, ffn_dim_expansion=4,
+                 with_shift=False, **kwargs):
+        super().__init__()
+        self.dim, self.nhead, self.no_ffn, self.with_shift = d_model, nhead, no_ffn, with_shift
+        self.attention_type = attention_type
+        self.q_proj = nn.Linear(d_model, d_model, bias=False)
+        self.k_proj = nn.Linear(d_model, d_model, bias=False)
+        self.v_proj = nn.Linear(d_model, d_model, bias=False)
+        self.merge = nn.Linear(d_model, d_model, bias=False)
+        self.norm1 = nn.LayerNorm(d_model)
+        if not no_ffn:
+            c = d_model * 2
+            self.mlp = nn.Sequential(nn.Linear(c, c * ffn_dim_expansion, bias=False), nn.GELU(),
+                                     nn.Linear(c * ffn_dim_expansion, d_model, bias=False))
+            self.norm2 = nn.LayerNorm(d_model)
+        # the reference's unused adaptor (transformer.py:148-151): state_dict entries only
+        self.adaptor_fc1 = nn.Linear(128, 32)
+        self.adaptor_fc2 = nn.Linear(32, 128)
+
+    def weights(self):
+        dt = self.cdtype
+
+        def build(q, k, v, m, g, b):
+            return dict(qkv=torch.cat([q, k, v], 0).detach().to(dt).contiguous(), q=pack_linear(q, dt),
+                        kv=torch.cat([k, v], 0).detach().to(dt).contiguous(), merge=pack_linear(m, dt),
+                        n1=(f32(g), f32(b)))
+        w = self.packed("attn", (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.merge.weight,
+                                 self.norm1.weight, self.norm1.bias), build)
+        if not self.no_ffn:
+            f = self.packed("ffn", (self.mlp[0].weight, self.mlp[2].weight, self.norm2.weight, self.norm2.bias),
+                            lambda a, b, g, be: dict(m0=pack_linear(a, dt), m2=pack_linear(b, dt),
+                                                     n2=(f32(g), f32(be))))
+            w = dict(w, **f)
+        return w
+
+
+class TransformerBlock(EmipModule):
+    """self attention, then cross attention + FFN (transformer.py:348-401)."""
+
+    def __init__(self, d_model=256, nhead=1, attention_type='swin', ffn_dim_expansion=4, with_shift=False, **kw):
+        super().__init__()
+        self.self_attn = TransformerLayer(d_model, nhead, attention_type, no_ffn=True,
+                                          ffn_dim_expansion=ffn_dim_expansion, with_shift=with_shift)
+        self.cross_attn_ffn = TransformerLayer(d_model, nhead, attention_type, ffn_dim_expansion=ffn_dim_expansion,
+                                               with_shift=with_shift)
+
+
+def _window_attention(q, k, v, B2, h, w, C, ldq, ldk, ldv, shift, splits):
+    """q/k/v: views with row strides ld*; returns message [B2, h*w, C]"""
+    rows, gid = window_tables(h, w, splits, shift, q.device)
+    L = (h // splits) * (w // splits)
+    out = torch.empty((B2, h * w, C), dtype=q.dtype, device=q.device)
+    n = h * w
+    ops.attention(q, k, v, out, batch=B2, heads=1, nwin=splits * splits, Lq=L, Lk=L, D=C, DV=C, q_bs=n * ldq,
+                  k_bs=n * ldk, v_bs=n * ldv, o_bs=n * C, ldq=ldq, ldk=ldk, ldv=ldv, ldo=C, q_rows=rows, k_rows=rows,
+                  q_gid=gid if shift else None, k_gid=gid if shift else None, scale=C ** -0.5)
+    return out
+
+
+class FeatureTransformer(EmipModule):
+    """transformer.py:404-482"""
+
+    def __init__(self, num_layers=6, d_model=128, nhead=1, attention_type='swin', ffn_dim_expansion=4, **kwargs):
+        super().__init__()
+        assert attention_type == 'swin' and nhead == 1 and d_model == 128
+        self.attention_type, self.d_model, self.nhead = attention_type, d_model, nhead
+        self.layers = nn.ModuleList([
+            TransformerBlock(d_model=d_model, nhead=nhead, attention_type=attention_type,
+                             ffn_dim_expansion=ffn_dim_expansion, with_shift=(i % 2 == 1))
+            for i in range(num_layers)])
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def run(self, c0, h, w, attn_num_splits=2):
+        """c0: [2B, h*w, C] tokens, frame-0 features in the first half, frame-1 in the second.  In place."""
+        B2, n, C = c0.shape
+        B = B2 // 2
+        assert n == h * w and C == self.d_model
+        dt = c0.dtype
+        for blk in self.layers:
+            ws, wc = blk.self_attn.weights(), blk.cross_attn_ffn.weights()
+            shift = blk.self_attn.with_shift
+            # k/v of the cross attention come from the OTHER frame as it is at block start
+            kvx = torch.empty((B2, n, 2 * C), dtype=dt, device=c0.device)
+            ops.gemm(c0[:B], wc["kv"], out=kvx[B:])
+            ops.gemm(c0[B:], wc["kv"], out=kvx[:B])
+            # ---- self attention (no FFN): c0 += LN(merge(attn))
+            qkv = ops.gemm(c0, ws["qkv"])
+            msg = _window_attention(qkv, qkv[..., C:], qkv[..., 2 * C:], B2, h, w, C, 3 * C, 3 * C, 3 * C, shift,
+                                    attn_num_splits)
+            msg = ops.gemm(msg, ws["merge"])
+            msg = ops.layernorm(msg, ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, out=msg)
+            ops.eltwise(c0, msg, 2, out=c0)
+            # ---- cross attention + FFN
+            q = ops.gemm(c0, wc["q"])
+            msg = _window_attention(q, kvx, kvx[..., C:], B2, h, w, C, C, 2 * C, 2 * C, shift, attn_num_splits)
+            msg = ops.gemm(msg, wc["merge"])
+            msg = ops.layernorm(msg, wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps, out=msg)
+            hid = ops.gemm(c0, wc["m0"], a2=msg, act=ops.ACT_GELU)
+            msg = ops.gemm(hid, wc["m2"])
+            msg = ops.layernorm(msg, wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps, out=msg)
+            ops.eltwise(c0, msg, 2, out=c0)
+        return c0
+
+
+class FeatureFlowAttention(EmipModule):
+    """Flow propagation (transformer.py:485-533); note key = k_proj(q_proj(feature)) as in the reference."""
+
+    def __init__(self, in_channels, **kwargs):
+        super().__init__()
+        self.q_proj = nn.Linear(in_channels, in_channels)
+        self.k_proj = nn.Linear(in_channels, in_channels)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def run(self, feat, flow, h, w):
+        """feat [N, h*w, C] tokens, flow f32 [N, h, w, 2] -> propagated flow f32 [N, h, w, 2]"""
+        dt = feat.dtype
+        N, n, C = feat.shape
+        wq, bq, wk, bk = self.packed("w", (self.q_proj.weight, self.q_proj.bias, self.k_proj.weight,
+                                           self.k_proj.bias),
+                                     lambda a, b, c, d: (pack_linear(a, dt), f32(b), pack_linear(c, dt), f32(d)))
+        q = ops.gemm(feat, wq, bias=bq)
+        k = ops.gemm(q, wk, bias=bk)
+        v = torch.empty((N, n, 32), dtype=dt, device=feat.device)
+        ops.copy_cols(flow.view(N * n, 2), 0, 2, v.view(N * n, 32), 0, 32)
+        o = torch.empty((N, n, 32), dtype=torch.float32, device=feat.device)
+        ops.attention(q, k, v, o, batch=N, heads=1, nwin=1, Lq=n, Lk=n, D=C, DV=32, q_bs=n * C, k_bs=n * C,
+                      v_bs=n * 32, o_bs=n * 32, ldq=C, ldk=C, ldv=32, ldo=32, scale=C ** -0.5)
+        return ops.corresp_to_flow(o, N, h, w, False)

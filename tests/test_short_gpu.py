@@ -1,0 +1,116 @@
+"""End-to-end parity of the HIP EMIP-short forward: against the CPU oracle on the same seeded inputs, and
+against the fixtures the reference itself produced (tests/golden).  f32 mode carries the 1e-3 mask bound of
+BASELINE.json; bf16 (performance mode) carries per-stage relative bounds."""
+import numpy as np
+import pytest
+import torch
+
+from emip_amd.filler import synthetic_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(model_args, sd):
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    net = CoUpdater(model_args)
+    net.load_state_dict(sd)
+    return net.to("cuda:0").eval()
+
+
+def _rel(a, b):
+    a, b = a.float().cpu(), torch.as_tensor(b).float()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-6)).item()
+
+
+def _planar(t):
+    from emip_amd import ops
+    return ops.cl_to_planar(t).cpu()
+
+
+@pytest.fixture(scope="module")
+def short_f32(model_args, short_sd):
+    from emip_amd import nn_base
+    nn_base.set_default_dtype(torch.float32)
+    return _net(model_args, short_sd)
+
+
+def test_f32_stages_and_mask_vs_reference_golden(short_f32, golden):
+    from emip_amd import nn_base
+    nn_base.set_default_dtype(torch.float32)
+    g = golden("short_eval_b1.npz")
+    im1, im2 = synthetic_pair(1, seed=1234)
+    with torch.no_grad():
+        mask, fw, bw = short_f32(im1.cuda(), im2.cuda())
+    L = short_f32.last
+    assert _rel(_planar(L["fea"][0][:1])[:, :, ::2, ::2], g["pvt1_s2"]) < 1e-3
+    assert _rel(_planar(L["fea"][1][:1]), g["pvt1_s3"]) < 1e-3
+    assert _rel(_planar(L["fea"][2][:1]), g["pvt1_s4"]) < 1e-3
+    assert _rel(_planar(L["gm"][:1])[:, :, ::2, ::2], g["gm1"]) < 1e-3
+    assert _rel(_planar(L["ab"][:1])[:, :, ::2, ::2], g["inj_a"]) < 1e-3
+    corr = L["corr"].float().cpu()          # [B, src, tgt]; golden block is [tgt<64, src<64]
+    assert _rel(corr[:, :64, :64].transpose(1, 2), g["corr_block"]) < 1e-3
+    assert _rel(_planar(L["conv_corr"])[:, :, ::2, ::2], g["conv_corr"]) < 1e-3
+    assert _rel(_planar(L["inj1"])[:, :, ::2, ::2], g["inj1"]) < 1e-3
+    assert _rel(_planar(L["dr"][1]), g["dr2"]) < 1e-3 and _rel(_planar(L["dr"][2]), g["dr3"]) < 1e-3
+    err = (mask.cpu() - torch.from_numpy(g["mask"])).abs().max().item()
+    assert mask.shape == (1, 1, 352, 352) and mask.dtype == torch.float32
+    assert err < 1e-3, f"mask logits max abs err vs reference {err}"      # BASELINE.json north_star bound
+    assert len(fw) == 1 and fw[0].shape == (1, 2, 352, 352)
+    # flow is ill-conditioned under random weights: softmax over 1936 near-ties
+    assert (fw[0].cpu()[:, :, ::4, ::4] - torch.from_numpy(g["flow_fw"])).abs().max().item() < 0.5
+
+
+def test_f32_batch2_vs_oracle_and_iou(short_f32, short_sd, golden):
+    from emip_amd import nn_base
+    from oracle import emip_oracle as O
+    nn_base.set_default_dtype(torch.float32)
+    im1, im2 = synthetic_pair(2, seed=1234)
+    with torch.no_grad():
+        mask, fw, bw = short_f32(im1.cuda(), im2.cuda())
+        ref, rfw, rbw = O.short_forward(im1, im2, short_sd)
+    m = mask.cpu()
+    assert (m - ref).abs().max().item() < 1e-3
+    assert (m - torch.from_numpy(golden("short_eval_b2.npz")["mask"])).abs().max().item() < 1e-3
+    a, b = m >= 0, ref >= 0                                   # sigmoid(logit) >= 0.5, eval/metrics.py:488-492
+    iou = (a & b).sum().item() / max((a | b).sum().item(), 1)
+    assert iou > 0.999
+    assert (bw[0].cpu() - rbw[0]).abs().max().item() < 0.5
+
+
+def test_bf16_mode_stage_bounds(model_args, short_sd, golden):
+    from emip_amd import nn_base
+    nn_base.set_default_dtype(torch.bfloat16)
+    try:
+        net = _net(model_args, short_sd)
+        g = golden("short_eval_b1.npz")
+        im1, im2 = synthetic_pair(1, seed=1234)
+        with torch.no_grad():
+            mask, fw, bw = net(im1.cuda(), im2.cuda())
+        L = net.last
+        assert _rel(_planar(L["fea"][1][:1]), g["pvt1_s3"]) < 0.08
+        assert _rel(_planar(L["gm"][:1])[:, :, ::2, ::2], g["gm1"]) < 0.05
+        assert _rel(_planar(L["inj1"])[:, :, ::2, ::2], g["inj1"]) < 0.08
+        ref = torch.from_numpy(g["mask"])
+        assert _rel(mask, ref) < 0.08
+        a, b = mask.cpu() >= 0, ref >= 0
+        assert (a & b).sum().item() / max((a | b).sum().item(), 1) > 0.97
+    finally:
+        nn_base.set_default_dtype(torch.float32)
+
+
+def test_train_mode_forward_shapes(model_args, short_sd, golden):
+    """train-mode semantics that do not need backward: BatchNorm batch statistics, two flow predictions."""
+    from emip_amd import nn_base
+    nn_base.set_default_dtype(torch.float32)
+    net = _net(model_args, short_sd)
+    net.train()
+    for m in net.modules():
+        if hasattr(m, "drop_path_rate"):
+            m.drop_path_rate = 0.0
+    g = golden("short_train_b2.npz")
+    im1, im2 = synthetic_pair(2, seed=77)
+    with torch.no_grad():
+        mask, fw, bw = net(im1.cuda(), im2.cuda())
+    assert len(fw) == 2 and len(bw) == 2
+    assert (mask.cpu() - torch.from_numpy(g["mask"])).abs().max().item() < 5e-3
+    assert (fw[0].cpu()[:, :, ::4, ::4] - torch.from_numpy(g["flow0_fw"])).abs().max().item() < 0.5
