@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""Benchmark of the EMIP two-stream hot path on MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
+
+A step = one EMIP-short inference forward (CoUpdater.forward) over a batch of 16 synthetic 352x352 frame
+pairs per GPU in bf16 (BASELINE.json configs[1]), inputs resident in HBM, replayed as a hipGraph.
+Prints ONE JSON line: frame-pairs/s over all ranks, the roofline of the dominant kernel measured live
+with HIP events, and the CPU oracle timed on this box's host cores (baseline, not the target)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PAIRS_PER_GPU = 16
+PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+F_ALG_PAIR_GFLOP = 270.63      # algorithmic forward FLOPs per frame pair
+
+
+def _algo_flops(name, a):
+    """algorithmic FLOPs of one emip_gemm / emip_conv2d launch (zero-padded channels not counted)"""
+    if name == "emip_gemm":
+        M, N, K, batch = a[6], a[7], a[8], a[16]
+        K = {344: 340}.get(K, K)
+        return 2.0 * M * N * K * batch, (M, N, batch, False)
+    if name == "emip_conv2d":
+        B, H, W, Cin, Cout, KH, KW, s, p = a[5], a[6], a[7], a[8], a[10], a[11], a[12], a[13], a[14]
+        Ho, Wo = (H + 2 * p - KH) // s + 1, (W + 2 * p - KW) // s + 1
+        cin = {8: 3, 136: 130}.get(Cin, Cin)
+        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin, (B * Ho * Wo, Cout, 1, True)
+    return 0.0, None
+
+
+def kernel_breakdown(net, im1, im2):
+    """One eager forward with a HIP-event pair around every C-ABI call (on the launch stream)."""
+    from emip_amd import _lib
+    lib = _lib.load()
+    rec = []
+    _lib.profile(rec)
+    with torch.no_grad():
+        net.run(im1, im2)
+    _lib.profile(None)
+    torch.cuda.synchronize()
+    agg = {}
+    for name, a, s, e in rec:
+        ms = s.elapsed_time(e)
+        fl, tile = _algo_flops(name, a)
+        key = name
+        if tile is not None:
+            t = lib.emip_gemm_tile(tile[0], tile[1], tile[2])
+            key = "gemm_kernel<bf16,%d,%d,%s>" % (t // 1000, t % 1000, "conv" if tile[3] else "dense")
+        d = agg.setdefault(key, [0.0, 0.0, 0])
+        d[0] += ms
+        d[1] += fl
+        d[2] += 1
+    return agg
+
+
+def cpu_baseline(sd):
+    from emip_amd.filler import synthetic_pair
+    from oracle import emip_oracle as O
+    im1, im2 = synthetic_pair(1, seed=1234)
+    with torch.no_grad():
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))   # the GPU box gives one GPU a 16-CPU share
+        O.short_forward(im1, im2, sd)                        # warm-up
+        t0 = time.time()
+        n = 0
+        while n < 3 or (time.time() - t0 < 12.0 and n < 12):
+            O.short_forward(im1, im2, sd)
+            n += 1
+        dt = time.time() - t0
+    return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d fp32 batch-1 EMIP-short forwards of the CPU oracle (oracle/emip_oracle.py, PyTorch-CPU, "
+                      "%d threads, host has %d logical CPUs)" % (n, torch.get_num_threads(), os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from emip_amd import _lib, nn_base
+    from emip_amd.filler import state_dict_from_manifest, synthetic_pair
+    from emip_amd.graph import GraphedShort
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    _lib.load()
+    g = os.path.join(ROOT, "tests", "golden")
+    margs = json.load(open(os.path.join(g, "model_args.json")))
+    sd = state_dict_from_manifest(json.load(open(os.path.join(g, "short_state_manifest.json"))), 0)
+    nn_base.set_default_dtype(torch.bfloat16)
+    net = CoUpdater(margs)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+
+    B = PAIRS_PER_GPU
+    im1, im2 = synthetic_pair(B, seed=1234 + rank)
+    im1, im2 = im1.to(dev), im2.to(dev)
+
+    if args.no_graph:
+        def step():
+            with torch.no_grad():
+                net.run(im1, im2)
+    else:
+        runner = GraphedShort(net, B, device=dev)
+        runner.im1.copy_(im1)
+        runner.im2.copy_(im2)
+        step = runner.replay
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+
+    out = None
+    if rank == 0:
+        pairs = world * B * args.steps
+        value = pairs / dt
+        agg = kernel_breakdown(net, im1, im2)
+        kernels = {k: v for k, v in agg.items() if v[1] > 0}
+        dom = max(kernels, key=lambda k: kernels[k][0])
+        ms, fl, cnt = kernels[dom]
+        achieved = fl / (ms * 1e-3) / 1e12
+        total_ms = sum(v[0] for v in agg.values())
+        out = {
+            "metric": "frame_pairs_per_sec_352x352_emip_short_fwd", "value": round(value, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "EMIP-short inference forward (CoUpdater.forward), batch=16 352x352 frame pairs "
+                                   "per GPU, bf16 storage / f32 accumulate, random-filled weights",
+                       "pairs_per_gpu": B, "parallelism": "dp%d (independent replicas, no collective)" % world,
+                       "hipgraph": not args.no_graph},
+            "end_to_end": {"achieved_TFLOPs": round(value / world * F_ALG_PAIR_GFLOP / 1e3, 2),
+                           "frac_of_bf16_mfma_peak": round(value / world * F_ALG_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4)},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                         "launches": cnt, "kernel_ms_per_step": round(ms, 3),
+                         "share_of_step_kernel_time": round(ms / total_ms, 3)},
+            "kernel_breakdown_ms": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sd)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

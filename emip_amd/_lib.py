@@ -73,9 +73,26 @@ def load():
     return lib
 
 
+_profile = None  # when a list: (name, args, start_event, end_event) of every launch is appended
+
+
+def profile(records):
+    """Enable (list) / disable (None) per-call HIP-event timing on the current stream."""
+    global _profile
+    _profile = records
+
+
 def call(name, *args):
     lib = load()
-    rc = getattr(lib, name)(*args)
+    if _profile is not None:
+        import torch
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = getattr(lib, name)(*args)
+        e.record()
+        _profile.append((name, args, s, e))
+    else:
+        rc = getattr(lib, name)(*args)
     if rc != 0:
         raise EmipLibraryError(f"{name} failed: {ERRORS.get(rc, rc)}")
     return rc

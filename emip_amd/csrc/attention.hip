@@ -54,11 +54,12 @@ __device__ __forceinline__ int v_off(int row, int c) {
     return row * RBV + c * 16;
 }
 
-template <typename T, int D, int DV>
+// BKV = keys per K/V tile: 64 (bf16 streaming), 32 (f32), or 128 (bf16, whole K/V of the 121-key SRA
+// attention resident in one tile: a single pass, no online rescale, one barrier).
+template <typename T, int D, int DV, int BKV>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     constexpr int ES = sizeof(T);
     constexpr bool BF = ES == 2;
-    constexpr int BKV = BF ? 64 : 32;
     constexpr int NKT = BKV / 32;
     constexpr int RBK = D * ES, RBV = DV * ES;
     constexpr int NQ = RBK / 32;   // 16-B fragments per lane per Q/K row
@@ -91,9 +92,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     const int q_g = (p.q_gid && q_ok) ? p.q_gid[(long)win * p.Lq + q] : 0;
     uint4 qf[NQ];
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-        qf[i] = make_uint4(0, 0, 0, 0);
-        if (q_ok) qf[i] = *reinterpret_cast<const uint4*>(Qp + q_row * p.ldq + (2 * i + h) * (16 / ES));
+    for (int i = 0; i < NQ; ++i) {   // unconditional load (q_row is 0 for out-of-range queries), masked afterwards
+        const uint4 v = *reinterpret_cast<const uint4*>(Qp + q_row * p.ldq + (2 * i + h) * (16 / ES));
+        qf[i] = mask4(v, q_ok);
     }
 
     // ---- staging bookkeeping
@@ -105,23 +106,23 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
         for (int i = 0; i < NSK; ++i) {
             const int id = tid + 256 * i;
             const int r = id / CPRK, c = id - r * CPRK;
-            rk[i] = make_uint4(0, 0, 0, 0);
-            if (r < BKV && k0 + r < p.Lk) {
-                const long gr = krows ? krows[k0 + r] : (k0 + r);
-                rk[i] = *reinterpret_cast<const uint4*>(Kp + gr * p.ldk + c * (16 / ES));
-            }
+            const bool ok = r < BKV && k0 + r < p.Lk;
+            const int kr = min(k0 + r, p.Lk - 1);          // clamped: loads stay unconditional (no per-load branch+wait)
+            const long gr = krows ? krows[kr] : kr;
+            const uint4 v = *reinterpret_cast<const uint4*>(Kp + gr * p.ldk + c * (16 / ES));
+            rk[i] = mask4(v, ok);
         }
 #pragma unroll
         for (int i = 0; i < NSV; ++i) {
             const int id = tid + 256 * i;
             const int r = id / CPRV, c = id - r * CPRV;
-            rv[i] = make_uint4(0, 0, 0, 0);
-            if (r < BKV && k0 + r < p.Lk) {
-                const long gr = krows ? krows[k0 + r] : (k0 + r);
-                rv[i] = *reinterpret_cast<const uint4*>(Vp + gr * p.ldv + c * (16 / ES));
-            }
+            const bool ok = r < BKV && k0 + r < p.Lk;
+            const int kr = min(k0 + r, p.Lk - 1);
+            const long gr = krows ? krows[kr] : kr;
+            const uint4 v = *reinterpret_cast<const uint4*>(Vp + gr * p.ldv + c * (16 / ES));
+            rv[i] = mask4(v, ok);
         }
-        if (kgid && tid < BKV) gid_reg = (k0 + tid < p.Lk) ? kgid[k0 + tid] : 0;
+        if (kgid) gid_reg = kgid[min(k0 + (tid & (BKV - 1)), p.Lk - 1)];
     };
     auto store_tile = [&](int buf) {
         char* kt_ = smem + buf * STAGE_BYTES;
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
         // ---- raw scores out (the correlation volume), masks, online softmax
         float tmax = -INFINITY;
+        const bool last_partial = (t == ntile - 1) && (p.Lk % BKV != 0);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -209,26 +211,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = s[kt][4 * g + j] * sc2;
-                    if (kgid) {
+                    if (kgid) {        // shifted-window mask only where a table was passed
                         const int kg = gl[32 * kt + 8 * g + 4 * h + j];
-                        if (kg != q_g) v += mask2;
+                        v += (kg != q_g) ? mask2 : 0.f;
                     }
-                    if (kbase + j >= p.Lk) v = -INFINITY;
                     s[kt][4 * g + j] = v;
-                    tmax = fmaxf(tmax, v);
                 }
+                if (last_partial) {    // wave-uniform: only the last K/V tile can hold keys >= Lk
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (kbase + j >= p.Lk) s[kt][4 * g + j] = -INFINITY;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) tmax = fmaxf(tmax, s[kt][4 * g + j]);
             }
         }
         tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
         const float m_new = fmaxf(m_run, tmax);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[kt][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
                 s[kt][r] = e;
                 psum += e;
             }
@@ -316,13 +323,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     }
 }
 
-template <typename T, int D, int DV>
-int launch(const AttnArgs& a, int batch, hipStream_t s) {
+template <typename T, int D, int DV, int BKV>
+int launch_bkv(const AttnArgs& a, int batch, hipStream_t s) {
     constexpr int ES = sizeof(T);
-    constexpr int BKV = ES == 2 ? 64 : 32;
-    const size_t lds = 2 * (size_t)(BKV * D * ES + BKV * DV * ES + BKV * 4);
-    auto kfn = attn_kernel<T, D, DV>;
-    if (lds > 64 * 1024) {
+    const int ntile = (a.Lk + BKV - 1) / BKV;
+    const size_t lds = (ntile > 1 ? 2 : 1) * (size_t)(BKV * D * ES + BKV * DV * ES + BKV * 4);
+    auto kfn = attn_kernel<T, D, DV, BKV>;
+    static bool attr_done = false;  // per instantiation; set on the first (warm-up) launch, before any capture
+    if (lds > 64 * 1024 && !attr_done) {
+        attr_done = true;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return EMIP_E_LAUNCH;
@@ -330,6 +339,18 @@ int launch(const AttnArgs& a, int batch, hipStream_t s) {
     dim3 grid((a.Lq + 127) / 128, a.heads, batch * a.nwin);
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
     return emip_launch_status();
+}
+
+template <typename T, int D, int DV>
+int launch(const AttnArgs& a, int batch, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+        return launch_bkv<T, D, DV, 32>(a, batch, s);
+    } else {
+        if constexpr (D == 64 && DV == 64) {
+            if (a.Lk <= 128) return launch_bkv<T, D, DV, 128>(a, batch, s);
+        }
+        return launch_bkv<T, D, DV, 64>(a, batch, s);
+    }
 }
 
 }  // namespace

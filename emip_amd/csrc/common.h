@@ -44,6 +44,29 @@ __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; 
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7): one rcp, one exp and a degree-5 Horner chain instead of
+// libm's branchy erff (~60 VALU ops), which made the GELU-carrying kernels VALU-bound.  Used where the
+// activation is stored as bf16 (its rounding step is 4e-3 relative); f32 parity mode keeps erff.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));   // raw v_rcp_f32 (1 ulp)
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);   // raw v_exp_f32
+    const float r = fmaf(-p * t, e, 1.0f);
+    return copysignf(r, x);
+}
+template <typename T>
+__device__ __forceinline__ float gelu_t(float x);
+template <>
+__device__ __forceinline__ float gelu_t<float>(float x) { return gelu_erf(x); }
+template <>
+__device__ __forceinline__ float gelu_t<bf16_t>(float x) {
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
+
 // 4 consecutive elements as a vector (16 B for f32, 8 B for bf16)
 template <typename T>
 struct Vec4;
@@ -70,6 +93,14 @@ struct Vec4<bf16_t> {
         *reinterpret_cast<bf16x4*>(p) = t;
     }
 };
+
+// v if ok else 0, component-wise AND with a lane mask (a ternary on the 16-byte struct makes hipcc build an
+// indexed select through scratch memory).
+__device__ __forceinline__ uint4 mask4(uint4 v, bool ok) {
+    const unsigned m = ok ? 0xFFFFFFFFu : 0u;
+    v.x &= m; v.y &= m; v.z &= m; v.w &= m;
+    return v;
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

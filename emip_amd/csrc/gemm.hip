@@ -60,7 +60,11 @@ struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN, bool CONV>
+// NBUF = 2: two LDS buffers, one barrier per K tile (64 KB at 128x128 -> 2 workgroups per CU).
+// NBUF = 1: one LDS buffer, two barriers per K tile (32 KB -> 4-5 workgroups per CU): more tiles
+//           in flight per CU, which is what the short-K GEMMs of this network need (K = 64..1280,
+//           each workgroup has only 1..20 K tiles to hide HBM/L2 latency behind).
+template <typename T, int BM, int BN, bool CONV, int NBUF>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int VEC = 16 / sizeof(T);   // elements per 16-B chunk
     constexpr int BK = 128 / sizeof(T);   // K elements per tile
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             a_iy[i] = oy * p.stride - p.pad;
             a_ix[i] = ox * p.stride - p.pad;
         } else {
-            a_off[i] = (long)m;
+            a_off[i] = (long)(a_ok[i] ? m : p.M - 1);
             a_iy[i] = a_ix[i] = 0;
         }
     }
@@ -115,39 +119,43 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     for (int i = 0; i < CW; ++i) {
         const int n = n0 + srow + 32 * i;
         w_ok[i] = n < p.N;
-        w_off[i] = (long)n * p.ldw;
+        w_off[i] = (long)(w_ok[i] ? n : p.N - 1) * p.ldw;
     }
 
+    // Loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a load inside an
+    // `if` makes hipcc branch around it and wait for it on the spot, which serialises the tile's loads.
     uint4 ra[CA], rw[CW];
     auto load_tile = [&](int k0) {
         const int kk = k0 + sc * VEC;
         const bool kok = kk < p.K;
+        const int kkc = kok ? kk : 0;
         if (CONV) {
-            const int tap = kk / p.Cin;
-            const int ci = kk - tap * p.Cin;
+            const int tap = kkc / p.Cin;
+            const int ci = kkc - tap * p.Cin;
             const int ky = tap / p.KW, kx = tap - ky * p.KW;
 #pragma unroll
             for (int i = 0; i < CA; ++i) {
                 const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
                 const bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
-                ra[i] = make_uint4(0, 0, 0, 0);
-                if (ok) ra[i] = *reinterpret_cast<const uint4*>(A + (a_off[i] + (long)iy * p.Wd + ix) * p.lda + ci);
+                const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.Wd - 1);
+                const uint4 v = *reinterpret_cast<const uint4*>(A + (a_off[i] + (long)iyc * p.Wd + ixc) * p.lda + ci);
+                ra[i] = mask4(v, ok);
             }
         } else {
-            const bool second = kk >= p.K1;
+            const bool second = kkc >= p.K1;
             const T* base = second ? A2 : A;
             const long ld = second ? p.lda2 : p.lda;
-            const int kc = second ? kk - p.K1 : kk;
+            const int kc = second ? kkc - p.K1 : kkc;
 #pragma unroll
             for (int i = 0; i < CA; ++i) {
-                ra[i] = make_uint4(0, 0, 0, 0);
-                if (kok && a_ok[i]) ra[i] = *reinterpret_cast<const uint4*>(base + a_off[i] * ld + kc);
+                const uint4 v = *reinterpret_cast<const uint4*>(base + a_off[i] * ld + kc);
+                ra[i] = mask4(v, kok && a_ok[i]);
             }
         }
 #pragma unroll
         for (int i = 0; i < CW; ++i) {
-            rw[i] = make_uint4(0, 0, 0, 0);
-            if (kok && w_ok[i]) rw[i] = *reinterpret_cast<const uint4*>(Wp + w_off[i] + kk);
+            const uint4 v = *reinterpret_cast<const uint4*>(Wp + w_off[i] + kkc);
+            rw[i] = mask4(v, kok && w_ok[i]);
         }
     };
     auto store_tile = [&](int buf) {
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     store_tile(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+        const int cur = NBUF == 2 ? (kt & 1) : 0;
         if (kt + 1 < nk) load_tile((kt + 1) * BK);
         const char* ta = smem + cur * TILE_BYTES;
         const char* tw = ta + BM * 128;
@@ -192,81 +200,136 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int b = 0; b < TM; ++b) acc[a][b] = Mma<T>::run(fw[a], fa[b], acc[a][b]);
         }
-        if (kt + 1 < nk) store_tile(cur ^ 1);
+        if (NBUF == 1) __syncthreads();   // everyone is done reading the single buffer
+        if (kt + 1 < nk) store_tile(NBUF == 2 ? (cur ^ 1) : 0);
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds rows m = .. + fr, channels n = .. + 4*fq + {0..3}
-    T* __restrict__ C = reinterpret_cast<T*>(p.C) + z * p.bsC;
-    const T* __restrict__ R = p.R ? reinterpret_cast<const T*>(p.R) + z * p.bsR : nullptr;
-    const bool vec_ok = ((p.ldc & 3) == 0) && (R == nullptr || (p.ldr & 3) == 0);
+    // ---- epilogue.  Each lane holds, per 16x16 sub-tile, 4 consecutive channels of one row.  Storing
+    // that directly touches 16 rows x 32 B per wave instruction; instead every wave bounces 16-row slabs
+    // of its (BM/2 x BN/2) block through its own LDS slice (bias + activation applied on the way in) and
+    // reads them back row-major, so global stores and residual loads are 16 B per lane and cover whole
+    // 128/256-B row segments.  LDS ops of one wave execute in order: no workgroup barrier is needed.
+    T* C = reinterpret_cast<T*>(p.C) + z * p.bsC;   // may alias R (in-place residual update)
+    const T* R = p.R ? reinterpret_cast<const T*>(p.R) + z * p.bsR : nullptr;
+    constexpr int WM = BM / 2, WN = BN / 2, EP_LD = WN + 4;
+    constexpr int CG = WN / VEC;        // 16-B column groups per row of the wave block
+    constexpr int RPI = 64 / CG;        // rows covered by one wave instruction
+    float* ep = reinterpret_cast<float*>(smem) + wave * 16 * EP_LD;
+    const int cg = lane % CG, er0 = lane / CG;
+    const bool fast = ((p.ldc % VEC) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15) == 0) &&
+                      (R == nullptr || (((p.ldr % VEC) == 0) && ((reinterpret_cast<uintptr_t>(R) & 15) == 0)));
+    const int nb = n0 + wn * WN;
+    const bool act_gelu = p.act == EMIP_ACT_GELU, act_relu = p.act == EMIP_ACT_RELU;
+    float4 bias_v[TN];      // this lane's 4 output channels of each sub-tile column, loaded once
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        bias_v[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) {
+            const int n = nb + 16 * a + 4 * fq;
+            const int nc = min(n, max(p.N - 4, 0));     // clamped 4-wide window, masked per element below
+            const float b0 = p.bias[min(n + 0, p.N - 1)], b1 = p.bias[min(n + 1, p.N - 1)];
+            const float b2 = p.bias[min(n + 2, p.N - 1)], b3 = p.bias[min(n + 3, p.N - 1)];
+            (void)nc;
+            bias_v[a] = make_float4(b0, b1, b2, b3);    // columns >= N are never stored
+        }
+    }
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
-        const int m = m0 + wm * (BM / 2) + 16 * b + fr;
-        if (m >= p.M) continue;
+        uint4 rres[16 / RPI];   // residual rows of this slab: issued first, consumed after the LDS bounce
+#pragma unroll
+        for (int i = 0; i < 16 / RPI; ++i) {
+            const int m = m0 + wm * WM + 16 * b + er0 + RPI * i;
+            const int n = nb + cg * VEC;
+            rres[i] = make_uint4(0, 0, 0, 0);
+            if (R && fast) {   // wave-uniform condition; the address is clamped instead of branching per lane
+                const int mc = min(m, p.M - 1), nc = (n + VEC <= p.N) ? n : 0;
+                rres[i] = *reinterpret_cast<const uint4*>(R + (long)mc * p.ldr + nc);
+            }
+        }
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
-            const int n = n0 + wn * (BN / 2) + 16 * a + 4 * fq;
-            if (n >= p.N) continue;
-            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
-            const bool full = (n + 3 < p.N) && vec_ok;
-            if (p.bias) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (n + j < p.N) v[j] += p.bias[n + j];
+            float4 v = make_float4(acc[a][b][0] + bias_v[a].x, acc[a][b][1] + bias_v[a].y, acc[a][b][2] + bias_v[a].z,
+                                   acc[a][b][3] + bias_v[a].w);
+            if (act_gelu) {          // wave-uniform flags, tested once per sub-tile (not per element)
+                v.x = gelu_t<T>(v.x); v.y = gelu_t<T>(v.y); v.z = gelu_t<T>(v.z); v.w = gelu_t<T>(v.w);
+            } else if (act_relu) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
             }
-            if (p.act == EMIP_ACT_RELU) {
+            *reinterpret_cast<float4*>(ep + fr * EP_LD + 16 * a + 4 * fq) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-            } else if (p.act == EMIP_ACT_GELU) {
+        for (int i = 0; i < 16 / RPI; ++i) {
+            const int row = er0 + RPI * i;
+            const int m = m0 + wm * WM + 16 * b + row;
+            const int n = nb + cg * VEC;
+            if (m < p.M && n < p.N) {
+                float v[VEC];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = gelu_erf(v[j]);
-            }
-            if (full) {
-                if (R) {
-                    float r[4];
-                    Vec4<T>::load(R + (long)m * p.ldr + n, r);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += r[j];
+                for (int j = 0; j < VEC; j += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(ep + row * EP_LD + cg * VEC + j);
+                    v[j] = t.x; v[j + 1] = t.y; v[j + 2] = t.z; v[j + 3] = t.w;
                 }
-                Vec4<T>::store(C + (long)m * p.ldc + n, v);
-            } else {
+                if (fast && n + VEC <= p.N) {
+                    if (R) {
+                        const T* rv = reinterpret_cast<const T*>(&rres[i]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (n + j < p.N) {
-                        float o = v[j];
-                        if (R) o += to_f32<T>(R[(long)m * p.ldr + n + j]);
-                        C[(long)m * p.ldc + n + j] = from_f32<T>(o);
+                        for (int j = 0; j < VEC; ++j) v[j] += to_f32<T>(rv[j]);
+                    }
+                    uint4 ov;
+                    T* o = reinterpret_cast<T*>(&ov);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) o[j] = from_f32<T>(v[j]);
+                    *reinterpret_cast<uint4*>(C + (long)m * p.ldc + n) = ov;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        if (n + j < p.N) {
+                            float o = v[j];
+                            if (R) o += to_f32<T>(R[(long)m * p.ldr + n + j]);
+                            C[(long)m * p.ldc + n + j] = from_f32<T>(o);
+                        }
                     }
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
+
+int g_gemm_nbuf = 1;  // debug/tuning knob (emip_debug_set)
 
 template <typename T, int BM, int BN, bool CONV>
 int launch(GemmArgs& a, int batch, hipStream_t s) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
-    const size_t lds = 2 * (BM + BN) * 128;
     dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
-    hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV>), grid, dim3(256), lds, s, a);
+    if (g_gemm_nbuf == 2)
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 2>), grid, dim3(256), 2 * (BM + BN) * 128, s, a);
+    else
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 1>), grid, dim3(256), (BM + BN) * 128, s, a);
     return emip_launch_status();
+}
+
+// tile choice: least padded work, then the larger tile; small problems take the smaller tile so
+// that the grid still covers the 256 CUs.
+void pick_tile(long M, long N, long batch, int& bm, int& bn) {
+    auto waste = [&](int tm_, int tn_) {
+        const long tm = (M + tm_ - 1) / tm_, tn = (N + tn_ - 1) / tn_;
+        return tm * tm_ * tn * tn_;
+    };
+    auto blocks = [&](int tm_, int tn_) { return ((M + tm_ - 1) / tm_) * ((N + tn_ - 1) / tn_) * batch; };
+    bn = (waste(128, 64) < waste(128, 128)) ? 64 : 128;
+    bm = 128;
+    if (blocks(bm, bn) < 1024 || waste(64, bn) * 10 < waste(128, bn) * 9) bm = 64;
+    if (bn == 128 && blocks(bm, bn) < 256) bn = 64;
 }
 
 template <typename T, bool CONV>
 int dispatch(GemmArgs& a, int batch, hipStream_t s) {
-    // tile choice: least padded work, then the larger tile; small problems take the
-    // smaller tile so that the grid still covers the 256 CUs.
-    auto waste = [&](int bm, int bn) {
-        const long tm = (a.M + bm - 1) / bm, tn = (a.N + bn - 1) / bn;
-        return tm * bm * tn * bn;
-    };
-    auto blocks = [&](int bm, int bn) { return (long)((a.M + bm - 1) / bm) * ((a.N + bn - 1) / bn) * batch; };
-    int bn = (waste(128, 64) < waste(128, 128)) ? 64 : 128;
-    int bm = 128;
-    if (blocks(bm, bn) < 512 || waste(64, bn) * 10 < waste(128, bn) * 9) bm = 64;
-    if (bn == 128 && blocks(bm, bn) < 256) bn = 64;
+    int bm, bn;
+    pick_tile(a.M, a.N, batch, bm, bn);
     if (bm == 128 && bn == 128) return launch<T, 128, 128, CONV>(a, batch, s);
     if (bm == 128 && bn == 64) return launch<T, 128, 64, CONV>(a, batch, s);
     if (bm == 64 && bn == 128) return launch<T, 64, 128, CONV>(a, batch, s);
@@ -322,4 +385,20 @@ extern "C" int emip_conv2d(const void* X, const void* W, void* Y, const float* b
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == EMIP_F32 ? dispatch<float, true>(a, 1, s) : dispatch<bf16_t, true>(a, 1, s);
+}
+
+// the block tile the dispatcher picks for an (M, N, batch) problem, as BM*1000 + BN (introspection for bench.py)
+extern "C" int emip_gemm_tile(long M, long N, long batch) {
+    int bm, bn;
+    pick_tile(M, N, batch, bm, bn);
+    return bm * 1000 + bn;
+}
+
+// tuning knobs for experiments (not part of the product contract): key 0 = LDS buffers of the GEMM (1|2)
+extern "C" int emip_debug_set(int key, int value) {
+    if (key == 0 && (value == 1 || value == 2)) {
+        g_gemm_nbuf = value;
+        return EMIP_OK;
+    }
+    return EMIP_E_INVALID;
 }

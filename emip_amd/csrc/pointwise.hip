@@ -36,11 +36,13 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X,
         const bool ok = row < M;
         float v[4][4];
         float s = 0.f;
+        const long rowc = ok ? row : M - 1;   // clamped: loads stay unconditional, results are masked
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int vi = sub + i * LPR;
-            if (ok && vi < nv) {
-                Vec4<T>::load(X + row * ldx + vi * 4, v[i]);
+            if (i * LPR < nv) {               // wave-uniform
+                Vec4<T>::load(X + rowc * ldx + min(vi, nv - 1) * 4, v[i]);
+                if (!(ok && vi < nv)) v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
                 s += v[i][0] + v[i][1] + v[i][2] + v[i][3];
             } else {
                 v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
@@ -128,10 +130,110 @@ __global__ __launch_bounds__(256) void dwconv3x3_kernel(const T* __restrict__ X,
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (GATED) o[j] = gelu_erf(a[j]) * g[j];
-            else o[j] = act == EMIP_ACT_GELU ? gelu_erf(a[j]) : (act == EMIP_ACT_RELU ? fmaxf(a[j], 0.f) : a[j]);
+            if (GATED) o[j] = gelu_t<T>(a[j]) * g[j];
+            else o[j] = act == EMIP_ACT_GELU ? gelu_t<T>(a[j]) : (act == EMIP_ACT_RELU ? fmaxf(a[j], 0.f) : a[j]);
         }
         Vec4<T>::store(Y + pix * ldy + c, o);
+    }
+}
+
+// Depthwise 3x3 (+bias, +activation), 16 B of channels per thread and XT consecutive output pixels of
+// one row per thread: the 3 x (XT+2) input window is loaded once and reused from registers, so every
+// input element is fetched ~1.5x instead of 9x, with 16-B coalesced accesses along the channel axis.
+template <typename T, int XT>
+__global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y,
+                                                             long ldy, const float* __restrict__ Wt,
+                                                             const float* __restrict__ bias, int B, int H, int Wd,
+                                                             int C, int act) {
+    constexpr int NV = 16 / sizeof(T);
+    const int ncg = C / NV;
+    const int nxg = (Wd + XT - 1) / XT;
+    const long total = (long)B * H * nxg * ncg;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cgi = (int)(idx % ncg);
+        long r = idx / ncg;
+        const int xg = (int)(r % nxg);
+        r /= nxg;
+        const int y = (int)(r % H);
+        const long b = r / H;
+        const int c = cgi * NV, x0 = xg * XT;
+        float acc[XT][NV];
+        {
+            float bv[NV];
+#pragma unroll
+            for (int j = 0; j < NV; ++j) bv[j] = 0.f;
+            if (bias) {
+#pragma unroll
+                for (int j = 0; j < NV; j += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(bias + c + j);
+                    bv[j] = t.x; bv[j + 1] = t.y; bv[j + 2] = t.z; bv[j + 3] = t.w;
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < XT; ++o)
+#pragma unroll
+                for (int j = 0; j < NV; ++j) acc[o][j] = bv[j];
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int iy = y + ky - 1;
+            const float rmask = (unsigned)iy < (unsigned)H ? 1.f : 0.f;   // out-of-image rows: zero the weights,
+            const int iyc = min(max(iy, 0), H - 1);                        // keep the (clamped) loads unconditional
+            const T* rowp = X + ((b * H + iyc) * (long)Wd) * ldx + c;
+            float w[3][NV];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int j = 0; j < NV; j += 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(Wt + (ky * 3 + kx) * C + c + j);
+                    w[kx][j] = t.x * rmask; w[kx][j + 1] = t.y * rmask; w[kx][j + 2] = t.z * rmask;
+                    w[kx][j + 3] = t.w * rmask;
+                }
+            uint4 raw[XT + 2];
+#pragma unroll
+            for (int dx = 0; dx < XT + 2; ++dx) {
+                const int ix = x0 - 1 + dx;
+                const int ixc = min(max(ix, 0), Wd - 1);
+                raw[dx] = mask4(*reinterpret_cast<const uint4*>(rowp + (long)ixc * ldx), (unsigned)ix < (unsigned)Wd);
+            }
+#pragma unroll
+            for (int dx = 0; dx < XT + 2; ++dx) {
+                const T* tv = reinterpret_cast<const T*>(&raw[dx]);
+                float v[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) v[j] = to_f32<T>(tv[j]);
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int o = dx - kx;                    // output pixel this column feeds with tap kx
+                    if (o >= 0 && o < XT) {
+#pragma unroll
+                        for (int j = 0; j < NV; ++j) acc[o][j] = fmaf(v[j], w[kx][j], acc[o][j]);
+                    }
+                }
+            }
+        }
+        if (act == EMIP_ACT_GELU) {      // hoisted: a per-element test of the runtime `act` costs a branch per element
+#pragma unroll
+            for (int o = 0; o < XT; ++o)
+#pragma unroll
+                for (int j = 0; j < NV; ++j) acc[o][j] = gelu_t<T>(acc[o][j]);
+        } else if (act == EMIP_ACT_RELU) {
+#pragma unroll
+            for (int o = 0; o < XT; ++o)
+#pragma unroll
+                for (int j = 0; j < NV; ++j) acc[o][j] = fmaxf(acc[o][j], 0.f);
+        }
+#pragma unroll
+        for (int o = 0; o < XT; ++o) {
+            const int x = x0 + o;
+            if (x < Wd) {
+                uint4 ov;
+                T* op = reinterpret_cast<T*>(&ov);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) op[j] = from_f32<T>(acc[o][j]);
+                *reinterpret_cast<uint4*>(Y + ((b * H + y) * (long)Wd + x) * ldy + c) = ov;
+            }
+        }
     }
 }
 
@@ -482,6 +584,14 @@ extern "C" int emip_dwconv3x3(const void* X, long ldx, void* Y, long ldy, const 
     REQ_DT(dtype);
     EMIP_REQUIRE(X && Y && Wt && B > 0 && H > 0 && Wd > 0 && C >= 4 && (C & 3) == 0);
     EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
+    const int nv = dtype == EMIP_F32 ? 4 : 8;
+    if (C % nv == 0 && ldx % nv == 0 && ldy % nv == 0 && aligned16(X) && aligned16(Y)) {
+        const long total = (long)B * H * ((Wd + 3) / 4) * (C / nv);
+        DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_rows_kernel<T, 4>), dim3(grid_for(total, 256)), dim3(256), 0,
+                                             (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, Wt, bias, B, H, Wd, C,
+                                             act));
+        return emip_launch_status();
+    }
     const long total = (long)B * H * Wd * (C >> 2);
     DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, Wt, bias, B, H, Wd, C, C,

@@ -50,6 +50,12 @@ int emip_gemm(const void* A, const void* A2, const void* W, void* C, const float
               int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, int batch, long bsA, long bsW,
               long bsC, long bsR, int dtype, void* stream);
 
+/* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch) problem. */
+int emip_gemm_tile(long M, long N, long batch);
+
+/* Tuning knob for experiments (not part of the drop-in contract): key 0 = LDS buffers of the GEMM main loop. */
+int emip_debug_set(int key, int value);
+
 /* NHWC convolution as implicit GEMM, weights packed [Cout][KH][KW][Cin], same epilogue.
  * nn.Conv2d call sites: lib/pvt_v2.py:187-188,208 (patch embed), :75,107 (SR conv);
  *   gmflow/backbone.py:44-47,83,97 (CNN encoder); gmflow/gmflow.py:47-49 (upsampler);
