@@ -24,7 +24,12 @@ F_ALG_PAIR_GFLOP = 270.63      # algorithmic forward FLO
 
 
 def _algo_flops(name, a):
-    """algorithmic FLOPs of one emip_gemm / emip_conv2d launch (zero-padded channels not counted)"""
+    """algorithmic FLOPs of one emip_gemm / emip_conv2d / emip_attention launch (zero-padded channels not counted)"""
+    if name == "emip_attention":
+        batch, heads, nwin, Lq, Lk, D, DV = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
+        dv = 2 if DV == 32 else DV                          # DV=32 carries a 2-channel value (flow / pixel grid)
+        bkv = 128 if (D == 64 and Lk <= 128) else 64
+        return 2.0 * batch * heads * nwin * Lq * Lk * (D + dv), ("attn", D, DV, bkv)
     if name == "emip_gemm":
         M, N, K, batch = a[6], a[7], a[8], a[16]
         K = {344: 340}.get(K, K)
@@ -52,9 +57,11 @@ def kernel_breakdown(net, im1, im2):
         ms = s.elapsed_time(e)
         fl, tile = _algo_flops(name, a)
         key = name
-        if tile is not None:
+        if tile is not None and tile[0] == "attn":
+            key = "attn_kernel<bf16,%d,%d,%d>" % tile[1:]
+        elif tile is not None:
             t = lib.emip_gemm_tile(tile[0], tile[1], tile[2])
-            key = "gemm_kernel<bf16,%d,%d,%s>" % (t // 1000, t % 1000, "conv" if tile[3] else "dense")
+            key = "gemm_kernel<bf16,%d,%d,%s,1>" % (t // 1000, t % 1000, "conv" if tile[3] else "dense")
         d = agg.setdefault(key, [0.0, 0.0, 0])
         d[0] += ms
         d[1] += fl
@@ -89,15 +96,12 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    from emip_amd import dist as edist
+    world, rank, local = edist.env_world()
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")
     torch.cuda.set_device(local)
+    if world > 1:
+        dist = edist.init("nccl")          # "nccl" is RCCL on ROCm; only barriers / the timing max-reduce use it
     dev = torch.device("cuda", local)
 
     from emip_amd import _lib, nn_base
@@ -114,7 +118,7 @@ def main():
     net = net.to(dev).eval()
 
     B = PAIRS_PER_GPU
-    im1, im2 = synthetic_pair(B, seed=1234 + rank)
+    im1, im2 = synthetic_pair(B, seed=edist.pair_seed(1234, rank))
     im1, im2 = im1.to(dev), im2.to(dev)
 
     if args.no_graph:
@@ -141,10 +145,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+    dt = edist.max_over_ranks(dt, dev)
 
     out = None
     if rank == 0:
@@ -156,6 +157,10 @@ def main():
         ms, fl, cnt = kernels[dom]
         achieved = fl / (ms * 1e-3) / 1e12
         total_ms = sum(v[0] for v in agg.values())
+        traffic = None                      # HBM bytes per launch from the committed rocprofv3 PMC passes, if any
+        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tf):
+            traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "frame_pairs_per_sec_352x352_emip_short_fwd", "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -168,8 +173,9 @@ def main():
             "end_to_end": {"achieved_TFLOPs": round(value / world * F_ALG_PAIR_GFLOP / 1e3, 2),
                            "frac_of_bf16_mfma_peak": round(value / world * F_ALG_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
-                         "launches": cnt, "kernel_ms_per_step": round(ms, 3),
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                         "launches": cnt, "avg_launch_us": round(ms / cnt * 1e3, 2),
+                         "algorithmic_flops_per_launch": round(fl / cnt), "kernel_ms_per_step": round(ms, 3),
                          "share_of_step_kernel_time": round(ms / total_ms, 3)},
             "kernel_breakdown_ms": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]},
         }

@@ -1,0 +1,59 @@
+"""N>1 bookkeeping of bench.py on CPU: two gloo ranks (127.0.0.1 rendezvous)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    from emip_amd import dist as ed
+    d = ed.init("gloo")
+    w, r, _ = ed.env_world()
+    assert (w, r) == (world, rank)
+    lo, hi = ed.shard_range(37, world, rank)
+    d.barrier()
+    tmax = ed.max_over_ranks(0.010 * (rank + 1))          # the slowest rank defines the step time
+    total = ed.sum_over_ranks(hi - lo)
+    out.put((rank, lo, hi, tmax, total, ed.pair_seed(1234, rank)))
+    d.barrier()
+    d.destroy_process_group()
+
+
+def test_two_rank_gloo_timing_and_sharding():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, lo0, hi0, t0, tot0, s0), (r1, lo1, hi1, t1, tot1, s1) = res
+    assert (lo0, hi0, lo1, hi1) == (0, 19, 19, 37)        # disjoint, exhaustive, sizes differ by <= 1
+    assert abs(t0 - 0.020) < 1e-12 and abs(t1 - 0.020) < 1e-12
+    assert tot0 == tot1 == 37
+    assert s0 != s1
+
+
+def test_shard_range_properties():
+    from emip_amd.dist import shard_range
+    for n in (0, 1, 7, 16, 256):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
