@@ -109,6 +109,8 @@ def main():
     from emip_amd.graph import GraphedShort
     from emip_amd.model.EMIP_short.model import CoUpdater
     _lib.load()
+    if os.environ.get("EMIP_GEMM_NBUF"):
+        _lib.call("emip_debug_set", 0, int(os.environ["EMIP_GEMM_NBUF"]))
     g = os.path.join(ROOT, "tests", "golden")
     margs = json.load(open(os.path.join(g, "model_args.json")))
     sd = state_dict_from_manifest(json.load(open(os.path.join(g, "short_state_manifest.json"))), 0)

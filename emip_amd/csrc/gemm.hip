@@ -124,8 +124,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     // Loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a load inside an
     // `if` makes hipcc branch around it and wait for it on the spot, which serialises the tile's loads.
-    uint4 ra[CA], rw[CW];
-    auto load_tile = [&](int k0) {
+    auto load_tile = [&](int k0, uint4 (&ra)[CA], uint4 (&rw)[CW]) {
         const int kk = k0 + sc * VEC;
         const bool kok = kk < p.K;
         const int kkc = kok ? kk : 0;
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             rw[i] = mask4(v, kok && w_ok[i]);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const uint4 (&ra)[CA], const uint4 (&rw)[CW]) {
         char* ta = smem + buf * TILE_BYTES;
         char* tw = ta + BM * 128;
 #pragma unroll
@@ -176,14 +175,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int fr = lane & 15, fq = lane >> 4;
     const int fsw = (fr >> 1) & 7;  // sub-tile bases are multiples of 16 -> (row>>1)&7 == (fr>>1)&7
 
-    const int nk = (p.K + BK - 1) / BK;
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = NBUF == 2 ? (kt & 1) : 0;
-        if (kt + 1 < nk) load_tile((kt + 1) * BK);
-        const char* ta = smem + cur * TILE_BYTES;
+    auto compute_tile = [&](int buf) {
+        const char* ta = smem + buf * TILE_BYTES;
         const char* tw = ta + BM * 128;
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
@@ -200,9 +193,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int b = 0; b < TM; ++b) acc[a][b] = Mma<T>::run(fw[a], fa[b], acc[a][b]);
         }
-        if (NBUF == 1) __syncthreads();   // everyone is done reading the single buffer
-        if (kt + 1 < nk) store_tile(NBUF == 2 ? (cur ^ 1) : 0);
+    };
+
+    const int nk = (p.K + BK - 1) / BK;
+    if (NBUF == 2) {
+        uint4 ra[CA], rw[CW];
+        load_tile(0, ra, rw);
+        store_tile(0, ra, rw);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) load_tile((kt + 1) * BK, ra, rw);
+            compute_tile(cur);
+            if (kt + 1 < nk) store_tile(cur ^ 1, ra, rw);
+            __syncthreads();
+        }
+    } else {
+        // one LDS buffer, two barriers per K tile: half the LDS, more workgroups per CU
+        uint4 ra[CA], rw[CW];
+        load_tile(0, ra, rw);
+        store_tile(0, ra, rw);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) load_tile((kt + 1) * BK, ra, rw);
+            compute_tile(0);
+            __syncthreads();
+            if (kt + 1 < nk) store_tile(0, ra, rw);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue.  Each lane holds, per 16x16 sub-tile, 4 consecutive channels of one row.  Storing
