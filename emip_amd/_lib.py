@@ -17,7 +17,7 @@ _CTYPES = {
     "const double*": ctypes.c_void_p, "double*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p,
     "long long*": ctypes.c_void_p,
-    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float,
+    "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
 }
 
 EMIP_F32, EMIP_BF16 = 0, 1

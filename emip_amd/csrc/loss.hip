@@ -84,10 +84,11 @@ __global__ __launch_bounds__(256) void occ_corner_kernel(const float* __restrict
 }
 
 __global__ __launch_bounds__(256) void occ_threshold_kernel(const float* __restrict__ cmap, float* __restrict__ occ,
-                                                            long total, float th) {
+                                                            long total, float th, int complement) {
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const float v = fminf(fmaxf(cmap[idx], 0.f), 1.f);
-        occ[idx] = v < th ? 1.f : 0.f;
+        const float o = v < th ? 1.f : 0.f;
+        occ[idx] = complement ? 1.f - o : o;
     }
 }
 
@@ -110,13 +111,163 @@ extern "C" int emip_occ_corners(const float* flow, long long* indices, float* we
 
 // occ = (clamp(scatter_add(weights at indices), 0, 1) < th); cmap_ws: f32 [B][H*W] workspace
 extern "C" int emip_occ_mask_backward(const float* flow, float* cmap_ws, float* occ, int B, int H, int W, float th,
-                                      void* stream) {
+                                      int complement, void* stream) {
     EMIP_REQUIRE(flow && cmap_ws && occ && B > 0 && H > 1 && W > 1 && (long)H * W < (1L << 24));
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * H * W;
     if (hipMemsetAsync(cmap_ws, 0, sizeof(float) * total, s) != hipSuccess) return EMIP_E_LAUNCH;
     hipLaunchKernelGGL(occ_corner_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, flow, (long long*)nullptr,
                        (float*)nullptr, cmap_ws, B, H, W);
-    hipLaunchKernelGGL(occ_threshold_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, cmap_ws, occ, total, th);
+    hipLaunchKernelGGL(occ_threshold_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, cmap_ws, occ, total, th, complement);
+    return emip_launch_status();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loss reductions (forward).  Planar f32 inputs; partial sums are combined with f64 atomics.
+//   hybrid_e_loss   /root/reference/loss/loss_pred.py:4-22
+//   loss_photomatric + SSIM   /root/reference/loss/loss_flow.py:35-49, loss/loss_blocks.py:46-65
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+    // 256 threads -> one value in thread 0
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double r = 0;
+    if (threadIdx.x == 0) r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+// acc[b][0..3] += sum sigmoid(p), sum m, sum sigmoid(p)*m, sum bce(p, m)      (per image b)
+__global__ __launch_bounds__(256) void hybrid_pass1_kernel(const float* __restrict__ P, const float* __restrict__ M,
+                                                           double* __restrict__ acc, int HW) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        const float x = P[(long)b * HW + i], z = M[(long)b * HW + i];
+        const float sg = 1.f / (1.f + expf(-x));
+        s0 += sg; s1 += z; s2 += sg * z;
+        s3 += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));
+    }
+    const double r0 = block_sum(s0, sh), r1 = block_sum(s1, sh), r2 = block_sum(s2, sh), r3 = block_sum(s3, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(acc + b * 8 + 0, r0); atomicAdd(acc + b * 8 + 1, r1);
+        atomicAdd(acc + b * 8 + 2, r2); atomicAdd(acc + b * 8 + 3, r3);
+    }
+}
+
+// acc[b][4] += sum (1+EFM)^2/4 with the per-image means from pass 1
+__global__ __launch_bounds__(256) void hybrid_pass2_kernel(const float* __restrict__ P, const float* __restrict__ M,
+                                                           double* __restrict__ acc, int HW) {
+    __shared__ double sh[4];
+    const int b = blockIdx.y;
+    const float mp = (float)(acc[b * 8 + 0] / HW), mm = (float)(acc[b * 8 + 1] / HW);
+    double s = 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+        const float sg = 1.f / (1.f + expf(-P[(long)b * HW + i]));
+        const float f = sg - mp, g = M[(long)b * HW + i] - mm;
+        const float e = (2.0f * f * g + 1e-8f) / (f * f + g * g + 1e-8f);
+        s += (1.f + e) * (1.f + e) / 4.0f;
+    }
+    const double r = block_sum(s, sh);
+    if (threadIdx.x == 0) atomicAdd(acc + b * 8 + 4, r);
+}
+
+__global__ void hybrid_final_kernel(const double* __restrict__ acc, float* __restrict__ out, int B, int HW) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double bce = 0;
+    for (int b = 0; b < B; ++b) bce += acc[b * 8 + 3];
+    bce /= (double)B * HW;
+    double tot = 0;
+    for (int b = 0; b < B; ++b) {
+        const double eloss = 1.0 - acc[b * 8 + 4] / HW;
+        const double inter = acc[b * 8 + 2], uni = acc[b * 8 + 0] + acc[b * 8 + 1];
+        const double wiou = 1.0 - (inter + 1 + 1e-8) / (uni - inter + 1 + 1e-8);
+        tot += bce + eloss + wiou;
+    }
+    out[0] = (float)(tot / B);
+}
+
+// sums[0] += sum_{b,c,y,x} |im - rec| * m ; sums[1] += sum over the (H-2)x(W-2) interior of ssim_dist(rec*m, im*m);
+// sums[2] += sum m  (counted once per pixel)
+__global__ __launch_bounds__(256) void photometric_kernel(const float* __restrict__ IM, const float* __restrict__ REC,
+                                                          const float* __restrict__ MK, double* __restrict__ sums,
+                                                          int B, int C, int H, int W) {
+    __shared__ double sh[4];
+    const long hw = (long)H * W;
+    const long total = (long)B * C * hw;
+    double l1 = 0, ss = 0, ms = 0;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W), y = (int)((idx / W) % H);
+        const int c = (int)((idx / hw) % C);
+        const long b = idx / (hw * C);
+        const float* im = IM + (b * C + c) * hw;
+        const float* rc = REC + (b * C + c) * hw;
+        const float* mk = MK + b * hw;
+        const float m0 = mk[(long)y * W + x];
+        l1 += fabsf(im[(long)y * W + x] - rc[(long)y * W + x]) * m0;
+        if (c == 0) ms += m0;
+        if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
+            float sx = 0, sy = 0, sxx = 0, syy = 0, sxy = 0;
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const long o = (long)(y + dy) * W + x + dx;
+                    const float mm = mk[o];
+                    const float a = rc[o] * mm, bb = im[o] * mm;     // SSIM(x = rec*m, y = im*m)
+                    sx += a; sy += bb; sxx += a * a; syy += bb * bb; sxy += a * bb;
+                }
+            const float mux = sx / 9.f, muy = sy / 9.f;
+            const float sgx = sxx / 9.f - mux * mux, sgy = syy / 9.f - muy * muy, sgxy = sxy / 9.f - mux * muy;
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float n = (2 * mux * muy + C1) * (2 * sgxy + C2);
+            const float d = (mux * mux + muy * muy + C1) * (sgx + sgy + C2);
+            ss += fminf(fmaxf((1.f - n / d) / 2.f, 0.f), 1.f);
+        }
+    }
+    const double r0 = block_sum(l1, sh), r1 = block_sum(ss, sh), r2 = block_sum(ms, sh);
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + 0, r0); atomicAdd(sums + 1, r1); atomicAdd(sums + 2, r2);
+    }
+}
+
+// out[0] += weight * (0.15*L1mean + 0.85*SSIMmean) / maskmean  from the three sums
+__global__ void photometric_final_kernel(const double* __restrict__ sums, float* __restrict__ out, double n_l1,
+                                         double n_ssim, double n_mask, float weight, int accumulate) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double v = (0.15 * sums[0] / n_l1 + 0.85 * sums[1] / n_ssim) / (sums[2] / n_mask);
+    out[0] = (accumulate ? out[0] : 0.f) + weight * (float)v;
+}
+
+}  // namespace
+
+// loss = mean_b( bce_mean + eloss_b + wiou_b ).  ws: f64 [B][8] scratch.  pred/mask: [B][1][H][W] f32.
+extern "C" int emip_hybrid_e_loss(const float* pred, const float* mask, double* ws, float* out, int B, int H, int W,
+                                  void* stream) {
+    EMIP_REQUIRE(pred && mask && ws && out && B > 0 && B < 65536 && H > 0 && W > 0);
+    hipStream_t s = (hipStream_t)stream;
+    const int HW = H * W;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 8 * B, s) != hipSuccess) return EMIP_E_LAUNCH;
+    dim3 grid((HW + 256 * 8 - 1) / (256 * 8), B);
+    hipLaunchKernelGGL(hybrid_pass1_kernel, grid, dim3(256), 0, s, pred, mask, ws, HW);
+    hipLaunchKernelGGL(hybrid_pass2_kernel, grid, dim3(256), 0, s, pred, mask, ws, HW);
+    hipLaunchKernelGGL(hybrid_final_kernel, dim3(1), dim3(64), 0, s, ws, out, B, HW);
+    return emip_launch_status();
+}
+
+// out[0] (+)= weight * loss_photomatric(im, rec, mask).  ws: f64 [4] scratch.  im/rec [B][C][H][W], mask [B][1][H][W].
+extern "C" int emip_photometric_loss(const float* im, const float* rec, const float* mask, double* ws, float* out,
+                                     int B, int C, int H, int W, float weight, int accumulate, void* stream) {
+    EMIP_REQUIRE(im && rec && mask && ws && out && B > 0 && C > 0 && H > 2 && W > 2);
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(ws, 0, sizeof(double) * 4, s) != hipSuccess) return EMIP_E_LAUNCH;
+    const long total = (long)B * C * H * W;
+    hipLaunchKernelGGL(photometric_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, im, rec, mask, ws, B, C, H, W);
+    hipLaunchKernelGGL(photometric_final_kernel, dim3(1), dim3(64), 0, s, ws, out, (double)total,
+                       (double)B * C * (H - 2) * (W - 2), (double)B * H * W, weight, accumulate);
     return emip_launch_status();
 }

@@ -267,11 +267,33 @@ def occ_corners(flow):
     return idx, wts
 
 
-def occ_mask_backward(flow, th=0.2):
+def occ_mask_backward(flow, th=0.2, complement=False):
     _dev(flow)
     B, _, H, W = flow.shape
     assert flow.dtype == torch.float32 and flow.is_contiguous()
     ws = torch.empty((B, H * W), dtype=torch.float32, device=flow.device)
     occ = torch.empty((B, 1, H, W), dtype=torch.float32, device=flow.device)
-    _lib.call("emip_occ_mask_backward", _p(flow), _p(ws), _p(occ), B, H, W, float(th), _stream())
+    _lib.call("emip_occ_mask_backward", _p(flow), _p(ws), _p(occ), B, H, W, float(th), int(complement), _stream())
     return occ
+
+
+def hybrid_e_loss(pred, mask):
+    """pred (logits), mask: planar f32 [B,1,H,W] -> scalar tensor f32 [1]"""
+    _dev(pred)
+    B, _, H, W = pred.shape
+    assert pred.dtype == torch.float32 and mask.dtype == torch.float32 and pred.is_contiguous() and mask.is_contiguous()
+    ws = torch.empty((B, 8), dtype=torch.float64, device=pred.device)
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    _lib.call("emip_hybrid_e_loss", _p(pred), _p(mask), _p(ws), _p(out), B, H, W, _stream())
+    return out
+
+
+def photometric_loss(im, rec, mask, out, weight=1.0, accumulate=False):
+    _dev(im)
+    B, C, H, W = im.shape
+    for t in (im, rec, mask):
+        assert t.dtype == torch.float32 and t.is_contiguous()
+    ws = torch.empty(4, dtype=torch.float64, device=im.device)
+    _lib.call("emip_photometric_loss", _p(im), _p(rec), _p(mask), _p(ws), _p(out), B, C, H, W, float(weight),
+              int(accumulate), _stream())
+    return out

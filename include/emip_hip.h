@@ -156,9 +156,20 @@ int emip_flow_warp(const float* X, const float* flow, float* Y, int B, int C, in
  * loss/warp_utils.py:43-70.  Indices are bit-exact with the reference. */
 int emip_occ_corners(const float* flow, long long* indices, float* weights, int B, int H, int W, void* stream);
 
-/* get_occu_mask_backward: occ = clamp(scatter_add(weights), 0, 1) < th.  loss/warp_utils.py:72-80,106-112. */
+/* get_occu_mask_backward: occ = clamp(scatter_add(weights), 0, 1) < th (complement != 0: 1 - occ, the
+ * non-occluded mask loss_flow.py:95-96 uses).  loss/warp_utils.py:72-80,106-112. */
 int emip_occ_mask_backward(const float* flow, float* cmap_ws, float* occ, int B, int H, int W, float th,
-                           void* stream);
+                           int complement, void* stream);
+
+/* hybrid_e_loss = mean_b(BCE-with-logits mean + E-loss_b + soft-IoU_b).  loss/loss_pred.py:4-22.
+ * pred (logits), mask: f32 [B][1][H][W]; ws: f64 [B][8] scratch; out: f32 [1]. */
+int emip_hybrid_e_loss(const float* pred, const float* mask, double* ws, float* out, int B, int H, int W,
+                       void* stream);
+
+/* out[0] (+)= weight * (0.15*mean(|im-rec|*m) + 0.85*mean(SSIM3x3(rec*m, im*m))) / mean(m).
+ * loss/loss_flow.py:35-49 + loss/loss_blocks.py:46-65.  im, rec: f32 [B][C][H][W]; mask f32 [B][1][H][W]; ws f64 [4]. */
+int emip_photometric_loss(const float* im, const float* rec, const float* mask, double* ws, float* out, int B, int C,
+                          int H, int W, float weight, int accumulate, void* stream);
 
 #ifdef __cplusplus
 }
