@@ -28,7 +28,7 @@ def _algo_flops(name, a):
     if name == "emip_attention":
         batch, heads, nwin, Lq, Lk, D, DV = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
         dv = 2 if DV == 32 else DV                          # DV=32 carries a 2-channel value (flow / pixel grid)
-        bkv = 128 if (D == 64 and Lk <= 128) else 64
+        bkv = 64
         return 2.0 * batch * heads * nwin * Lq * Lk * (D + dv), ("attn", D, DV, bkv)
     if name == "emip_gemm":
         M, N, K, batch = a[6], a[7], a[8], a[16]

@@ -343,12 +343,11 @@ int launch_bkv(const AttnArgs& a, int batch, hipStream_t s) {
 
 template <typename T, int D, int DV>
 int launch(const AttnArgs& a, int batch, hipStream_t s) {
+    // BKV = 128 (whole 121-key SRA K/V in one tile) measured slower than two 64-key tiles on MI355X
+    // (240 vs 166 VGPRs -> one fewer wave per SIMD), so bf16 always streams 64-key tiles.
     if constexpr (sizeof(T) == 4) {
         return launch_bkv<T, D, DV, 32>(a, batch, s);
     } else {
-        if constexpr (D == 64 && DV == 64) {
-            if (a.Lk <= 128) return launch_bkv<T, D, DV, 128>(a, batch, s);
-        }
         return launch_bkv<T, D, DV, 64>(a, batch, s);
     }
 }
