@@ -1,0 +1,62 @@
+"""Fused clamp + AdamW for the EMIP training step (one HIP launch for all parameters).
+
+Mirrors the reference's optimizer usage: `clip_gradient(optimizer, 0.5)` (utils/utils.py:1-11, an ELEMENT-WISE
+clamp, not a norm clip) followed by `torch.optim.AdamW(lr=1e-5, weight_decay=1e-7).step()` (train.py:61-62,380).
+State layout follows torch.optim.AdamW (exp_avg, exp_avg_sq, step) so checkpoints stay interchangeable."""
+import struct
+
+import torch
+
+from . import _lib
+
+
+class FusedClampAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-7, clip=0.5):
+        defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, clip=clip)
+        super().__init__(params, defaults)
+        self._tables = {}
+
+    def _table(self, gi, plist):
+        """device tables for one param group; rebuilt if the tensors' storage moved"""
+        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+        hit = self._tables.get(gi)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2], hit[3]
+        chunk = _lib.load().emip_adamw_chunk()
+        recs, bmap = bytearray(), []
+        for i, p in enumerate(plist):
+            st = self.state[p]
+            recs += struct.pack("<QQQQq", p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                st["exp_avg_sq"].data_ptr(), p.numel())
+            bmap += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
+        dev = plist[0].device
+        recs_t = torch.frombuffer(bytes(recs), dtype=torch.uint8).clone().to(dev)
+        bmap_t = torch.tensor(bmap, dtype=torch.int32).to(dev)
+        self._tables[gi] = (key, recs_t, bmap_t, len(bmap))
+        return recs_t, bmap_t, len(bmap)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                assert p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and p.grad.is_contiguous()
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p)
+                    st["exp_avg_sq"] = torch.zeros_like(p)
+            steps = {self.state[p]["step"] for p in plist}
+            assert len(steps) == 1, "parameters of one group must share the step count"
+            step = steps.pop() + 1
+            recs, bmap, nb = self._table(gi, plist)
+            b1, b2 = group["betas"]
+            _lib.call("emip_clamp_adamw", recs.data_ptr(), bmap.data_ptr(), nb, float(group["lr"]), float(b1),
+                      float(b2), float(group["eps"]), float(group["weight_decay"]), float(group["clip"] or 0.0), step,
+                      torch.cuda.current_stream().cuda_stream)
+            for p in plist:
+                self.state[p]["step"] = step
+        return loss

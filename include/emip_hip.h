@@ -171,6 +171,16 @@ int emip_hybrid_e_loss(const float* pred, const float* mask, double* ws, float* 
 int emip_photometric_loss(const float* im, const float* rec, const float* mask, double* ws, float* out, int B, int C,
                           int H, int W, float weight, int accumulate, void* stream);
 
+/* ---- optimizer ----------------------------------------------------------------------------------- */
+
+/* Element-wise gradient clamp to +-clip (utils/utils.py:1-11; clip <= 0 disables) fused with one AdamW step
+ * (train.py:380) over every trainable tensor in a single launch.  recs: device array of records
+ * {float* p; const float* g; float* m; float* v; long n;}; blockmap: device int2[nblocks] = (record, chunk) with
+ * chunks of emip_adamw_chunk() elements. */
+int emip_clamp_adamw(const void* recs, const void* blockmap, int nblocks, float lr, float beta1, float beta2,
+                     float eps, float weight_decay, float clip, int step, void* stream);
+int emip_adamw_chunk(void);
+
 #ifdef __cplusplus
 }
 #endif

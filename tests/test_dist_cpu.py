@@ -57,3 +57,51 @@ def test_shard_range_properties():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _dp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from emip_amd.dp import GradReducer, broadcast_parameters
+    dist.init_process_group("gloo")
+    torch.manual_seed(rank)                      # different init per rank -> broadcast must equalise
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4), torch.nn.Linear(4, 2))
+    dead = torch.nn.Parameter(torch.ones(3))     # never receives a gradient (like the reference's dead modules)
+    broadcast_parameters(net)
+    w0 = net[0].weight.detach().clone()
+    params = list(net.parameters()) + [dead]
+    red = GradReducer(params, bucket_bytes=300)  # tiny buckets: several buckets, one of them incomplete
+    g = torch.Generator().manual_seed(100 + rank)
+    x = torch.randn(5, 8, generator=g)
+    net(x).pow(2).sum().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    red.finish()
+    out.put((rank, w0.numpy(), [t.numpy() for t in local], [p.grad.clone().numpy() for p in net.parameters()],
+             dead.grad is None, len(red.buckets)))   # numpy: tensors in a Queue are shared-memory handles
+    # a second step must work after the reset
+    for p in net.parameters():
+        p.grad = None
+    net(x * 0.5).pow(2).sum().backward()
+    red.finish()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_two_ranks_mean_and_unused_params():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w0a, la, ra, da, nb), (_, w0b, lb, rb, db, _) = res
+    import numpy as np
+    assert np.array_equal(w0a, w0b)                                # broadcast equalised the replicas
+    assert nb >= 3 and da and db                                   # dead parameter: skipped, no gradient invented
+    for a, b, x, y in zip(la, lb, ra, rb):
+        assert np.allclose(x, (a + b) / 2, atol=1e-6) and np.array_equal(x, y)
