@@ -1,0 +1,196 @@
+// Weight-gradient contraction for gfx950:   C[n][k] (+)= sum_m A[m][n] * B[m][k]      (f32 output)
+//
+// A = dY [M][N] and B = X [M][K] are both row-major with the CONTRACTION index m as the row (the layouts the
+// forward pass leaves in HBM), i.e. a "TN" GEMM: nn.Linear / 1x1-conv wgrad dW = dY^T X
+// (backward of /root/reference/lib/pvt_v2.py:45-54,103,110,126 and the other Linear call sites of emip_gemm).
+// M is huge (up to 247 808 tokens) and N x K small, so M is split over blockIdx.y and partial tiles are
+// combined with f32 atomics into a zero-initialised C.
+//
+// Tiles are staged row-major ([m][n], [m][k]: coalesced 16-B global loads) and the MFMA operands, which need 8
+// consecutive m for a fixed n / k, are produced by the LDS transpose read ds_read_b64_tr_b16 (bf16) or plain
+// ds_read_b32 (f32).  16-B chunks are XOR-swizzled by a function of the row so that the 8 rows a half-wave's
+// transposed read touches land in distinct bank groups.
+#include "common.h"
+
+namespace {
+
+struct TnArgs {
+    const void* A;
+    const void* B;
+    float* C;
+    long M;
+    int N, K;
+    long lda, ldb, ldc;
+    long m_per_split;
+    int tiles_n, tiles_k;
+};
+
+__device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
+    constexpr int ES = sizeof(T);
+    constexpr bool BF = ES == 2;
+    constexpr int BMS = BF ? 64 : 32;          // rows (m) per stage
+    constexpr int RB = 128 * ES;               // bytes per tile row (128 columns)
+    constexpr int CPR = RB / 16;               // 16-B chunks per row
+    constexpr int NS = BMS * CPR / 256;        // staged chunks per thread per operand
+    constexpr int TILE = BMS * RB;
+    __shared__ __attribute__((aligned(16))) char smem[2 * TILE];
+    char* ta = smem;
+    char* tb = smem + TILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wk = wave >> 1;
+    const int tile_n = blockIdx.x / p.tiles_k, tile_k = blockIdx.x - tile_n * p.tiles_k;
+    const int n0 = tile_n * 128, k0 = tile_k * 128;
+    const long m_lo = (long)blockIdx.y * p.m_per_split;
+    const long m_hi = min(p.M, m_lo + p.m_per_split);
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
+    const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B);
+
+    uint4 ra[NS], rb[NS];
+    auto load_stage = [&](long m0) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id / CPR, c = id - r * CPR;
+            const long m = m0 + r;
+            const long mc = min(m, p.M - 1);
+            const int na = n0 + c * (16 / ES), kb = k0 + c * (16 / ES);
+            const int nac = min(na, max(p.N - 16 / ES, 0)), kbc = min(kb, max(p.K - 16 / ES, 0));
+            ra[i] = mask4(*reinterpret_cast<const uint4*>(A + mc * p.lda + nac), m < m_hi && na < p.N);
+            rb[i] = mask4(*reinterpret_cast<const uint4*>(Bp + mc * p.ldb + kbc), m < m_hi && kb < p.K);
+        }
+    };
+    auto store_stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int id = tid + 256 * i;
+            const int r = id / CPR, c = id - r * CPR;
+            const int cs = BF ? (c ^ (tn_f(r) << 1)) : c;
+            *reinterpret_cast<uint4*>(ta + r * RB + cs * 16) = ra[i];
+            *reinterpret_cast<uint4*>(tb + r * RB + cs * 16) = rb[i];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int q = lane >> 4, i16 = lane & 15;
+    if (m_lo < m_hi) {
+        load_stage(m_lo);
+        store_stage();
+        __syncthreads();
+        for (long m0 = m_lo; m0 < m_hi; m0 += BMS) {
+            if (m0 + BMS < m_hi) load_stage(m0 + BMS);
+            if (BF) {
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const int r = i16 >> 2, pp = i16 & 3;
+#pragma unroll
+                for (int ks = 0; ks < BMS / 32; ++ks) {
+                    const int row0 = 32 * ks + 8 * q + r, row1 = row0 + 4;
+                    bf16x8 fa[4], fb[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int cola = wn * 64 + 16 * t + 4 * pp, colb = wk * 64 + 16 * t + 4 * pp;
+                        const int ca = cola >> 3, ha = (cola >> 2) & 1, cb = colb >> 3, hb = (colb >> 2) & 1;
+                        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds_s16x4*)(ta + row0 * RB + ((ca ^ (tn_f(row0) << 1)) * 16) + 8 * ha));
+                        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds_s16x4*)(ta + row1 * RB + ((ca ^ (tn_f(row1) << 1)) * 16) + 8 * ha));
+                        const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds_s16x4*)(tb + row0 * RB + ((cb ^ (tn_f(row0) << 1)) * 16) + 8 * hb));
+                        const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                            (lds_s16x4*)(tb + row1 * RB + ((cb ^ (tn_f(row1) << 1)) * 16) + 8 * hb));
+                        const bf16x4 xa0 = __builtin_bit_cast(bf16x4, a0), xa1 = __builtin_bit_cast(bf16x4, a1);
+                        const bf16x4 xb0 = __builtin_bit_cast(bf16x4, b0), xb1 = __builtin_bit_cast(bf16x4, b1);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            fa[t][j] = xa0[j]; fa[t][4 + j] = xa1[j];
+                            fb[t][j] = xb0[j]; fb[t][4 + j] = xb1[j];
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                }
+            } else {
+#pragma unroll 2
+                for (int ks = 0; ks < BMS / 4; ++ks) {
+                    const int row = 4 * ks + q;
+                    float fa[4], fb[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        fa[t] = *reinterpret_cast<const float*>(ta + row * RB + (wn * 64 + 16 * t + i16) * 4);
+                        fb[t] = *reinterpret_cast<const float*>(tb + row * RB + (wk * 64 + 16 * t + i16) * 4);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[a], fb[b], acc[a][b], 0, 0, 0);
+                }
+            }
+            __syncthreads();
+            if (m0 + BMS < m_hi) store_stage();
+            __syncthreads();
+        }
+    }
+
+    // lane holds C[n = .. + 4q + reg][k = .. + i16]
+    const bool atomic = gridDim.y > 1;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int k = k0 + wk * 64 + 16 * b + i16;
+            if (k >= p.K) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + 16 * a + 4 * q + j;
+                if (n >= p.N) continue;
+                float* dst = p.C + (long)n * p.ldc + k;
+                if (atomic) atomicAdd(dst, acc[a][b][j]);
+                else *dst = acc[a][b][j];
+            }
+        }
+}
+
+}  // namespace
+
+// C must be zero-filled by the caller when the launch splits M (it always may: the function zero-fills itself).
+extern "C" int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc,
+                            int dtype, void* stream) {
+    EMIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
+    EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= N && ldb >= K && ldc >= K);
+    EMIP_REQUIRE(aligned16(A) && aligned16(B));
+    TnArgs a{};
+    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.tiles_n = (N + 127) / 128;
+    a.tiles_k = (K + 127) / 128;
+    const int bms = dtype == EMIP_F32 ? 32 : 64;
+    const long tiles = (long)a.tiles_n * a.tiles_k;
+    long splits = (1024 + tiles - 1) / tiles;                       // aim at >= ~1024 workgroups
+    const long max_splits = (M + 4 * bms - 1) / (4 * bms);          // but >= 4 stages of work per workgroup
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits > 65535) splits = 65535;
+    a.m_per_split = ((M + splits - 1) / splits + bms - 1) / bms * bms;
+    splits = (M + a.m_per_split - 1) / a.m_per_split;
+    hipStream_t s = (hipStream_t)stream;
+    if (splits > 1) {
+        if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * K, N, s) != hipSuccess) return EMIP_E_LAUNCH;
+    }
+    dim3 grid((unsigned)tiles, (unsigned)splits);
+    if (dtype == EMIP_F32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+    return emip_launch_status();
+}

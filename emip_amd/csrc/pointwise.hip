@@ -78,6 +78,124 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X,
 }
 
 // ----------------------------------------------------------------------------
+// LayerNorm backward (rows of C channels).  mean / rstd are recomputed from x (cheaper than saving them):
+//   xh = (x - mean) * rstd,  g = dy * gamma,  dx = rstd * (g - mean_c(g) - xh * mean_c(g * xh))
+//   dgamma[c] += sum_rows dy * xh,  dbeta[c] += sum_rows dy      (f32 atomics, one add per channel per workgroup)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ X, long ldx,
+                                                            const T* __restrict__ DY, long lddy,
+                                                            T* __restrict__ DX, long lddx,
+                                                            const float* __restrict__ gamma,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            long M, int C, float eps, int lpr_log2) {
+    extern __shared__ float red[];   // [2][C]
+    const int LPR = 1 << lpr_log2;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1);
+    const int rows_per_wave = 64 >> lpr_log2;
+    const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    const int nv = C >> 2;
+    for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+    __syncthreads();
+    float ag[4][4], ab[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ag[i][j] = ab[i][j] = 0.f;
+    for (long row0 = wave_global * rows_per_wave; row0 < M; row0 += nwaves * rows_per_wave) {
+        const long row = row0 + (lane >> lpr_log2);
+        const bool ok = row < M;
+        const long rowc = ok ? row : M - 1;
+        float x[4][4], dy[4][4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vi = sub + i * LPR;
+            if (i * LPR < nv) {
+                const int vc = min(vi, nv - 1);
+                Vec4<T>::load(X + rowc * ldx + vc * 4, x[i]);
+                Vec4<T>::load(DY + rowc * lddy + vc * 4, dy[i]);
+                if (!(ok && vi < nv)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[i][j] = dy[i][j] = 0.f;
+                }
+                s += x[i][0] + x[i][1] + x[i][2] + x[i][3];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[i][j] = dy[i][j] = 0.f;
+            }
+        }
+        for (int o = LPR >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float qv = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vi = sub + i * LPR;
+            if (vi < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d = x[i][j] - mean;
+                    qv += d * d;
+                }
+            }
+        }
+        for (int o = LPR >> 1; o > 0; o >>= 1) qv += __shfl_xor(qv, o);
+        const float rstd = rsqrtf(qv / (float)C + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vi = sub + i * LPR;
+            if (vi < nv) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float xh = (x[i][j] - mean) * rstd;
+                    const float g = dy[i][j] * gamma[vi * 4 + j];
+                    x[i][j] = xh;          // keep xh
+                    sg += g;
+                    sgx += g * xh;
+                    ag[i][j] += dy[i][j] * xh;
+                    ab[i][j] += dy[i][j];
+                }
+            }
+        }
+        for (int o = LPR >> 1; o > 0; o >>= 1) {
+            sg += __shfl_xor(sg, o);
+            sgx += __shfl_xor(sgx, o);
+        }
+        const float mg = sg / (float)C, mgx = sgx / (float)C;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int vi = sub + i * LPR;
+            if (ok && vi < nv) {
+                float o4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    o4[j] = rstd * (dy[i][j] * gamma[vi * 4 + j] - mg - x[i][j] * mgx);
+                Vec4<T>::store(DX + row * lddx + vi * 4, o4);
+            }
+        }
+    }
+    // combine the workgroup's partial dgamma / dbeta in LDS, then one atomic per channel
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int vi = sub + i * LPR;
+        if (vi < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(&red[vi * 4 + j], ag[i][j]);
+                atomicAdd(&red[C + vi * 4 + j], ab[i][j]);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+        atomicAdd(dgamma + i, red[i]);
+        atomicAdd(dbeta + i, red[C + i]);
+    }
+}
+
+// ----------------------------------------------------------------------------
 // Depthwise 3x3, stride 1, zero pad 1, channels-last.  Weights [9][C] f32.
 // GATED: X has 2*Ch channels, Y[c] = gelu(dw(X)[c]) * dw(X)[Ch + c] for c < Ch and 0 for
 // Ch <= c < ldy-padding (so that a following GEMM can read a 8-aligned K).
@@ -576,6 +694,26 @@ extern "C" int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const 
     const int grid = grid_for(waves, 4);
     DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                          (const T*)X, ldx, (T*)Y, ldy, gamma, beta, M, C, eps, lg));
+    return emip_launch_status();
+}
+
+// dgamma / dbeta are ACCUMULATED into (the caller zero-fills them, or keeps accumulating across micro-batches)
+extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx,
+                                  const float* gamma, float* dgamma, float* dbeta, long M, int C, float eps,
+                                  int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && DY && DX && gamma && dgamma && dbeta && M > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
+    EMIP_REQUIRE((ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C && lddy >= C && lddx >= C);
+    const int nv = C >> 2;
+    int lg = 0;
+    while ((1 << lg) < nv && lg < 6) ++lg;
+    const int rows_per_wave = 64 >> lg;
+    const long waves = (M + rows_per_wave - 1) / rows_per_wave;
+    long blocks = (waves + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256),
+                                         2 * C * sizeof(float), (hipStream_t)stream, (const T*)X, ldx, (const T*)DY,
+                                         lddy, (T*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg));
     return emip_launch_status();
 }
 

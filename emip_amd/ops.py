@@ -297,3 +297,22 @@ def photometric_loss(im, rec, mask, out, weight=1.0, accumulate=False):
     _lib.call("emip_photometric_loss", _p(im), _p(rec), _p(mask), _p(ws), _p(out), B, C, H, W, float(weight),
               int(accumulate), _stream())
     return out
+
+
+def gemm_tn(a, b):
+    """c[n, k] = sum_m a[m, n] * b[m, k]  (weight gradient: a = dY, b = X) -> f32 [N, K]"""
+    M, N, lda = rows(a)
+    Mb, K, ldb = rows(b)
+    assert M == Mb and a.dtype == b.dtype
+    c = torch.empty((N, K), dtype=torch.float32, device=a.device)
+    _lib.call("emip_gemm_tn", _p(a), _p(b), _p(c), M, N, K, lda, ldb, K, dt_code(a.dtype), _stream())
+    return c
+
+
+def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta):
+    M, C, ldx = rows(x)
+    _, _, lddy = rows(dy)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _lib.call("emip_layernorm_bwd", _p(x), ldx, _p(dy), lddy, _p(dx), C, _p(gamma), _p(dgamma), _p(dbeta), M, C,
+              float(eps), dt_code(x.dtype), _stream())
+    return dx

@@ -30,7 +30,7 @@ class FusedClampAdamW(torch.optim.Optimizer):
                                 st["exp_avg_sq"].data_ptr(), p.numel())
             bmap += [(i, c) for c in range((p.numel() + chunk - 1) // chunk)]
         dev = plist[0].device
-        recs_t = torch.frombuffer(bytes(recs), dtype=torch.uint8).clone().to(dev)
+        recs_t = torch.frombuffer(recs, dtype=torch.uint8).clone().to(dev)
         bmap_t = torch.tensor(bmap, dtype=torch.int32).to(dev)
         self._tables[gi] = (key, recs_t, bmap_t, len(bmap))
         return recs_t, bmap_t, len(bmap)

@@ -171,6 +171,17 @@ int emip_hybrid_e_loss(const float* pred, const float* mask, double* ws, float* 
 int emip_photometric_loss(const float* im, const float* rec, const float* mask, double* ws, float* out, int B, int C,
                           int H, int W, float weight, int accumulate, void* stream);
 
+/* ---- backward building blocks (training step, train.py:43-62; more to come) ------------------------------- */
+
+/* Weight gradient of nn.Linear / 1x1 conv:  C[n][k] = sum_m A[m][n] * B[m][k]  (A = dY [M][N], B = X [M][K], both
+ * as the forward leaves them in HBM), f32 output; M is split over workgroups and combined with f32 atomics. */
+int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc, int dtype,
+                 void* stream);
+
+/* LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (f32 atomics).  mean/rstd are recomputed from x. */
+int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx, const float* gamma,
+                       float* dgamma, float* dbeta, long M, int C, float eps, int dtype, void* stream);
+
 /* ---- optimizer ----------------------------------------------------------------------------------- */
 
 /* Element-wise gradient clamp to +-clip (utils/utils.py:1-11; clip <= 0 disables) fused with one AdamW step
