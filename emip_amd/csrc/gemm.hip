@@ -37,6 +37,7 @@ struct GemmArgs {
     // batching over blockIdx.z
     long bsA, bsW, bsC, bsR;
     int tiles_m, tiles_n;
+    int dbg;   // experiment flags (emip_debug_set key 2): 1 = skip epilogue stores, 2 = skip global loads in the K loop
 };
 
 template <typename T>
@@ -64,6 +65,9 @@ struct Mma<float> {
 // NBUF = 1: one LDS buffer, two barriers per K tile (32 KB -> 4-5 workgroups per CU): more tiles
 //           in flight per CU, which is what the short-K GEMMs of this network need (K = 64..1280,
 //           each workgroup has only 1..20 K tiles to hide HBM/L2 latency behind).
+// NBUF = 3: LDS-DMA variant (dense GEMM with K a multiple of the K tile): global_load_lds_dwordx4 writes the
+//           tiles straight into two LDS buffers (no staging VGPRs, no ds_write traffic -- the register-staged
+//           loop is bound by the ds_write_b128 rate); the XOR swizzle moves to the per-lane SOURCE address.
 template <typename T, int BM, int BN, bool CONV, int NBUF>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int VEC = 16 / sizeof(T);   // elements per 16-B chunk
@@ -196,7 +200,55 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     };
 
     const int nk = (p.K + BK - 1) / BK;
-    if (NBUF == 2) {
+    if (NBUF == 3) {
+        // One wave instruction moves 64 x 16 B = 8 tile rows (LDS destination = wave-uniform base + lane*16).
+        // Wave w stages rows [w*BM/4, (w+1)*BM/4) of the A tile and [w*BN/4, ...) of the W tile.
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        const int lrow = lane >> 3, lslot = lane & 7;
+        const T* ga[BM / 32];
+        const T* gw[BN / 32];
+        const T* ga2[BM / 32];
+#pragma unroll
+        for (int i = 0; i < BM / 32; ++i) {
+            const int r = wave * (BM / 4) + 8 * i + lrow;                 // tile row
+            const int c = lslot ^ ((r >> 1) & 7);                          // source chunk that belongs in this slot
+            const long m = min((long)(m0 + r), (long)p.M - 1);             // clamped: rows >= M are never stored
+            ga[i] = A + m * p.lda + c * VEC;
+            ga2[i] = A2 ? A2 + m * p.lda2 + c * VEC : ga[i];
+        }
+#pragma unroll
+        for (int i = 0; i < BN / 32; ++i) {
+            const int r = wave * (BN / 4) + 8 * i + lrow;
+            const int c = lslot ^ ((r >> 1) & 7);
+            const long n = min((long)(n0 + r), (long)p.N - 1);
+            gw[i] = Wp + n * p.ldw + c * VEC;
+        }
+        auto issue = [&](int kt, int buf) {
+            char* ta = smem + buf * TILE_BYTES + wave * (BM / 4) * 128;
+            char* tw = smem + buf * TILE_BYTES + BM * 128 + wave * (BN / 4) * 128;
+            const int k0 = kt * BK;
+            const bool second = k0 >= p.K1;
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i) {
+                const T* src = second ? ga2[i] + (k0 - p.K1) : ga[i] + k0;
+                __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(ta + i * 1024), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i)
+                __builtin_amdgcn_global_load_lds((glb_void*)(gw[i] + k0), (lds_void*)(tw + i * 1024), 16, 0, 0);
+        };
+        issue(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+            compute_tile(cur);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else if (NBUF == 2) {
         uint4 ra[CA], rw[CW];
         load_tile(0, ra, rw);
         store_tile(0, ra, rw);
@@ -215,7 +267,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         store_tile(0, ra, rw);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) load_tile((kt + 1) * BK, ra, rw);
+            if (kt + 1 < nk && !(p.dbg & 2)) load_tile((kt + 1) * BK, ra, rw);
             compute_tile(0);
             __syncthreads();
             if (kt + 1 < nk) store_tile(0, ra, rw);
@@ -223,11 +275,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
     }
 
-    // ---- epilogue.  Each lane holds, per 16x16 sub-tile, 4 consecutive channels of one row.  Storing
-    // that directly touches 16 rows x 32 B per wave instruction; instead every wave bounces 16-row slabs
-    // of its (BM/2 x BN/2) block through its own LDS slice (bias + activation applied on the way in) and
-    // reads them back row-major, so global stores and residual loads are 16 B per lane and cover whole
-    // 128/256-B row segments.  LDS ops of one wave execute in order: no workgroup barrier is needed.
+    if ((p.dbg & 1) && acc[0][0][0] != 123456.f) return;   // experiment: no epilogue (the test keeps acc live)
     T* C = reinterpret_cast<T*>(p.C) + z * p.bsC;   // may alias R (in-place residual update)
     const T* R = p.R ? reinterpret_cast<const T*>(p.R) + z * p.bsR : nullptr;
     constexpr int WM = BM / 2, WN = BN / 2, EP_LD = WN + 4;
@@ -317,12 +365,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 }
 
 int g_gemm_nbuf = 1;  // debug/tuning knob (emip_debug_set)
+int g_gemm_tile = 0;  // 0 = heuristic, else BM*1000+BN
+int g_gemm_dbg = 0;
+int g_gemm_glds = 1;  // LDS-DMA main loop for dense GEMMs
 
 template <typename T, int BM, int BN, bool CONV>
 int launch(GemmArgs& a, int batch, hipStream_t s) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
+    a.dbg = g_gemm_dbg;
     dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
+    if constexpr (!CONV) {
+        constexpr int BKE = 128 / sizeof(T);
+        if (g_gemm_glds && a.K % BKE == 0 && a.K1 % BKE == 0) {
+            hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 3>), grid, dim3(256), 2 * (BM + BN) * 128, s, a);
+            return emip_launch_status();
+        }
+    }
     if (g_gemm_nbuf == 2)
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 2>), grid, dim3(256), 2 * (BM + BN) * 128, s, a);
     else
@@ -348,6 +407,7 @@ template <typename T, bool CONV>
 int dispatch(GemmArgs& a, int batch, hipStream_t s) {
     int bm, bn;
     pick_tile(a.M, a.N, batch, bm, bn);
+    if (g_gemm_tile) { bm = g_gemm_tile / 1000; bn = g_gemm_tile % 1000; }
     if (bm == 128 && bn == 128) return launch<T, 128, 128, CONV>(a, batch, s);
     if (bm == 128 && bn == 64) return launch<T, 128, 64, CONV>(a, batch, s);
     if (bm == 64 && bn == 128) return launch<T, 64, 128, CONV>(a, batch, s);
@@ -416,6 +476,18 @@ extern "C" int emip_gemm_tile(long M, long N, long batch) {
 extern "C" int emip_debug_set(int key, int value) {
     if (key == 0 && (value == 1 || value == 2)) {
         g_gemm_nbuf = value;
+        return EMIP_OK;
+    }
+    if (key == 1 && (value == 0 || value == 128128 || value == 128064 || value == 64128 || value == 64064)) {
+        g_gemm_tile = value;
+        return EMIP_OK;
+    }
+    if (key == 2) {
+        g_gemm_dbg = value;
+        return EMIP_OK;
+    }
+    if (key == 3) {
+        g_gemm_glds = value ? 1 : 0;
         return EMIP_OK;
     }
     return EMIP_E_INVALID;
