@@ -119,3 +119,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
 }
+
+// Zero-fill as a KERNEL node.  hipMemsetAsync captured into a hipGraph was observed to mis-order against the
+// following kernels when two graphs replay concurrently (GMFlow CNN statistics came out wrong under multi-stream
+// replay while eager runs were exact), so every scratch buffer is cleared by this kernel instead.
+static __global__ __launch_bounds__(256) void emip_zero_kernel(unsigned* __restrict__ p, size_t nwords) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+        p[i] = 0u;
+}
+static inline int emip_zero_async(void* ptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return EMIP_OK;
+    if ((reinterpret_cast<uintptr_t>(ptr) & 3u) || (bytes & 3u)) return EMIP_E_INVALID;
+    const size_t nwords = bytes / 4;
+    size_t blocks = (nwords + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(emip_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<unsigned*>(ptr), nwords);
+    return emip_launch_status();
+}

@@ -186,8 +186,9 @@ extern "C" int emip_gemm_tn(const void* A, const void* B, float* C, long M, int 
     a.m_per_split = ((M + splits - 1) / splits + bms - 1) / bms * bms;
     splits = (M + a.m_per_split - 1) / a.m_per_split;
     hipStream_t s = (hipStream_t)stream;
-    if (splits > 1) {
-        if (hipMemset2DAsync(C, sizeof(float) * ldc, 0, sizeof(float) * K, N, s) != hipSuccess) return EMIP_E_LAUNCH;
+    if (splits > 1) {   // zero the (possibly strided) output rows; ldc == K for every caller so far
+        EMIP_REQUIRE(ldc == K);
+        if (emip_zero_async(C, sizeof(float) * (size_t)N * K, s) != EMIP_OK) return EMIP_E_LAUNCH;
     }
     dim3 grid((unsigned)tiles, (unsigned)splits);
     if (dtype == EMIP_F32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, a);

@@ -115,7 +115,7 @@ extern "C" int emip_occ_mask_backward(const float* flow, float* cmap_ws, float* 
     EMIP_REQUIRE(flow && cmap_ws && occ && B > 0 && H > 1 && W > 1 && (long)H * W < (1L << 24));
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * H * W;
-    if (hipMemsetAsync(cmap_ws, 0, sizeof(float) * total, s) != hipSuccess) return EMIP_E_LAUNCH;
+    if (emip_zero_async(cmap_ws, sizeof(float) * total, s) != EMIP_OK) return EMIP_E_LAUNCH;
     hipLaunchKernelGGL(occ_corner_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, flow, (long long*)nullptr,
                        (float*)nullptr, cmap_ws, B, H, W);
     hipLaunchKernelGGL(occ_threshold_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, cmap_ws, occ, total, th, complement);
@@ -251,7 +251,7 @@ extern "C" int emip_hybrid_e_loss(const float* pred, const float* mask, double* 
     EMIP_REQUIRE(pred && mask && ws && out && B > 0 && B < 65536 && H > 0 && W > 0);
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 8 * B, s) != hipSuccess) return EMIP_E_LAUNCH;
+    if (emip_zero_async(ws, sizeof(double) * 8 * B, s) != EMIP_OK) return EMIP_E_LAUNCH;
     dim3 grid((HW + 256 * 8 - 1) / (256 * 8), B);
     hipLaunchKernelGGL(hybrid_pass1_kernel, grid, dim3(256), 0, s, pred, mask, ws, HW);
     hipLaunchKernelGGL(hybrid_pass2_kernel, grid, dim3(256), 0, s, pred, mask, ws, HW);
@@ -264,7 +264,7 @@ extern "C" int emip_photometric_loss(const float* im, const float* rec, const fl
                                      int B, int C, int H, int W, float weight, int accumulate, void* stream) {
     EMIP_REQUIRE(im && rec && mask && ws && out && B > 0 && C > 0 && H > 2 && W > 2);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ws, 0, sizeof(double) * 4, s) != hipSuccess) return EMIP_E_LAUNCH;
+    if (emip_zero_async(ws, sizeof(double) * 4, s) != EMIP_OK) return EMIP_E_LAUNCH;
     const long total = (long)B * C * H * W;
     hipLaunchKernelGGL(photometric_kernel, dim3(grid_for(total, 256)), dim3(256), 0, s, im, rec, mask, ws, B, C, H, W);
     hipLaunchKernelGGL(photometric_final_kernel, dim3(1), dim3(64), 0, s, ws, out, (double)total,

@@ -115,7 +115,7 @@ extern "C" int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K,
     float* G = ws;
     float* nq = ws + nbh * 4096;
     float* nk = nq + nbh * 64;
-    if (hipMemsetAsync(ws, 0, sizeof(float) * nbh * (4096 + 128), s) != hipSuccess) return EMIP_E_LAUNCH;
+    if (emip_zero_async(ws, sizeof(float) * nbh * (4096 + 128), s) != EMIP_OK) return EMIP_E_LAUNCH;
     dim3 grid((P + PC - 1) / PC, heads, B);
     if (dtype == EMIP_F32) {
         hipLaunchKernelGGL(mdta_gram_kernel<float>, grid, dim3(256), 0, s, (const float*)Q, ldq, q_bs,

@@ -756,7 +756,7 @@ extern "C" int emip_chan_stats(const void* X, long ldx, double* sums, long group
     EMIP_REQUIRE(X && sums && groups > 0 && groups < 65536 && rows > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
     EMIP_REQUIRE((ldx & 3) == 0 && ldx >= C);
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * groups * C, s) != hipSuccess) return EMIP_E_LAUNCH;
+    if (emip_zero_async(sums, sizeof(double) * 2 * groups * C, s) != EMIP_OK) return EMIP_E_LAUNCH;
     const int rpb = 512;
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)groups);
     DISPATCH_T(dtype, hipLaunchKernelGGL(chan_stats_kernel<T>, grid, dim3(256), 0, s, (const T*)X, ldx, sums, rows, C,

@@ -114,3 +114,21 @@ def test_train_mode_forward_shapes(model_args, short_sd, golden):
     assert len(fw) == 2 and len(bw) == 2
     assert (mask.cpu() - torch.from_numpy(g["mask"])).abs().max().item() < 5e-3
     assert (fw[0].cpu()[:, :, ::4, ::4] - torch.from_numpy(g["flow0_fw"])).abs().max().item() < 0.5
+
+
+def test_graph_replay_with_stream_splits_matches_eager(model_args, short_sd):
+    """hipGraph replay (batch split over 2 concurrent streams) == eager forward"""
+    from emip_amd import nn_base
+    from emip_amd.graph import GraphedShort
+    nn_base.set_default_dtype(torch.float32)
+    net = _net(model_args, short_sd)
+    im1, im2 = synthetic_pair(2, seed=4321)
+    im1, im2 = im1.cuda(), im2.cuda()
+    with torch.no_grad():
+        ref_mask, ref_fw, ref_bw = net(im1, im2)
+    runner = GraphedShort(net, 2, splits=2)
+    for _ in range(2):                                   # replay twice: static buffers are reused
+        mask, fw, bw = runner(im1, im2)
+        torch.cuda.synchronize()
+        assert (mask - ref_mask).abs().max().item() < 1e-3
+        assert (fw[0] - ref_fw[0]).abs().max().item() < 0.5 and (bw[0] - ref_bw[0]).abs().max().item() < 0.5
