@@ -34,12 +34,12 @@ def _algo_flops(name, a):
         M, N, K, batch = a[6], a[7], a[8], a[16]
         lds_dma = (K % 64 == 0) and (a[9] % 64 == 0)         # bf16: dense GEMMs with whole K tiles use the LDS-DMA loop
         K = {344: 340}.get(K, K)
-        return 2.0 * M * N * K * batch, (M, N, batch, False, 3 if lds_dma else 1)
+        return 2.0 * M * N * K * batch, (M, N, batch, False, 3 if lds_dma else 1, a[8])
     if name == "emip_conv2d":
         B, H, W, Cin, Cout, KH, KW, s, p = a[5], a[6], a[7], a[8], a[10], a[11], a[12], a[13], a[14]
         Ho, Wo = (H + 2 * p - KH) // s + 1, (W + 2 * p - KW) // s + 1
         cin = {8: 3, 136: 130}.get(Cin, Cin)
-        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin, (B * Ho * Wo, Cout, 1, True, 1)
+        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin, (B * Ho * Wo, Cout, 1, True, 1, KH * KW * Cin)
     return 0.0, None
 
 
@@ -61,7 +61,7 @@ def kernel_breakdown(net, im1, im2):
         if tile is not None and tile[0] == "attn":
             key = "attn_kernel<bf16,%d,%d,%d>" % tile[1:]
         elif tile is not None:
-            t = lib.emip_gemm_tile(tile[0], tile[1], tile[2])
+            t = lib.emip_gemm_tile(tile[0], tile[1], tile[2], tile[5])
             key = "gemm_kernel<bf16,%d,%d,%s,%d>" % (t // 1000, t % 1000, "conv" if tile[3] else "dense", tile[4])
         d = agg.setdefault(key, [0.0, 0.0, 0])
         d[0] += ms

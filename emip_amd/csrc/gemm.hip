@@ -391,7 +391,7 @@ int launch(GemmArgs& a, int batch, hipStream_t s) {
 
 // tile choice: least padded work, then the larger tile; small problems take the smaller tile so
 // that the grid still covers the 256 CUs.
-void pick_tile(long M, long N, long batch, int& bm, int& bn) {
+void pick_tile(long M, long N, long batch, int& bm, int& bn, long K = 0) {
     auto waste = [&](int tm_, int tn_) {
         const long tm = (M + tm_ - 1) / tm_, tn = (N + tn_ - 1) / tn_;
         return tm * tm_ * tn * tn_;
@@ -399,14 +399,17 @@ void pick_tile(long M, long N, long batch, int& bm, int& bn) {
     auto blocks = [&](int tm_, int tn_) { return ((M + tm_ - 1) / tm_) * ((N + tn_ - 1) / tn_) * batch; };
     bn = (waste(128, 64) < waste(128, 128)) ? 64 : 128;
     bm = 128;
-    if (blocks(bm, bn) < 1024 || waste(64, bn) * 10 < waste(128, bn) * 9) bm = 64;
+    // short K: workgroups are latency-bound, prefer many small ones; long K (>= 1024): each workgroup streams
+    // many K tiles, so keep the big tile (half the operand traffic per flop) as long as every CU gets one.
+    const long min_blocks = K >= 1024 ? 256 : 1024;
+    if (blocks(bm, bn) < min_blocks || waste(64, bn) * 10 < waste(128, bn) * 9) bm = 64;
     if (bn == 128 && blocks(bm, bn) < 256) bn = 64;
 }
 
 template <typename T, bool CONV>
 int dispatch(GemmArgs& a, int batch, hipStream_t s) {
     int bm, bn;
-    pick_tile(a.M, a.N, batch, bm, bn);
+    pick_tile(a.M, a.N, batch, bm, bn, a.K);
     if (g_gemm_tile) { bm = g_gemm_tile / 1000; bn = g_gemm_tile % 1000; }
     if (bm == 128 && bn == 128) return launch<T, 128, 128, CONV>(a, batch, s);
     if (bm == 128 && bn == 64) return launch<T, 128, 64, CONV>(a, batch, s);
@@ -466,9 +469,9 @@ extern "C" int emip_conv2d(const void* X, const void* W, void* Y, const float* b
 }
 
 // the block tile the dispatcher picks for an (M, N, batch) problem, as BM*1000 + BN (introspection for bench.py)
-extern "C" int emip_gemm_tile(long M, long N, long batch) {
+extern "C" int emip_gemm_tile(long M, long N, long batch, long K) {
     int bm, bn;
-    pick_tile(M, N, batch, bm, bn);
+    pick_tile(M, N, batch, bm, bn, K);
     return bm * 1000 + bn;
 }
 

@@ -50,8 +50,8 @@ int emip_gemm(const void* A, const void* A2, const void* W, void* C, const float
               int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, int batch, long bsA, long bsW,
               long bsC, long bsR, int dtype, void* stream);
 
-/* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch) problem. */
-int emip_gemm_tile(long M, long N, long batch);
+/* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
+int emip_gemm_tile(long M, long N, long batch, long K);
 
 /* Tuning knob for experiments (not part of the drop-in contract): key 0 = LDS buffers of the GEMM main loop. */
 int emip_debug_set(int key, int value);
