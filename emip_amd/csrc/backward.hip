@@ -1,0 +1,487 @@
+// Backward building blocks of the EMIP training step (row T of SURVEY.md section 8): the HBM-bound pieces that sit
+// between the MFMA contractions (emip_gemm for dgrad, emip_gemm_tn / emip_conv2d_wgrad for weight gradients).
+//   softmax over rows (+ additive group mask, + valid length) and its backward   -> unfused attention backward
+//   2-D transpose with zero padding                                              -> K^T operand of dQ = dS K
+//   GELU backward, depthwise-3x3 weight gradient                                 -> PVT Mlp / MDTA depthwise
+//   per-channel (dy, dy*xhat) sums + apply                                       -> train-mode BatchNorm backward
+//   adjoint of bilinear resampling (channels-last and planar)                    -> NCD decoder, mask / flow x8
+// All channels-last, 8-16 B per lane; reductions combine per-workgroup partials with f32 atomics.
+#include "common.h"
+
+namespace {
+
+inline int grid_for(long n, int threads) {
+    long b = (n + threads - 1) / threads;
+    if (b > 4096) b = 4096;
+    return (int)(b < 1 ? 1 : b);
+}
+
+// ---- softmax over the first L columns of rows of width ld (columns >= L are written as 0) --------------------
+// one wave per row; s = x*scale (+ mask2 when gid_q[row % period] != gid_k[col]).  L <= 2048.
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const T* __restrict__ X, T* __restrict__ Y, long rows,
+                                                           int L, long ld, float scale, const int* __restrict__ gq,
+                                                           const int* __restrict__ gk, long period, long win_stride) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nw = (long)gridDim.x * 4;
+    for (long r = wave; r < rows; r += nw) {
+        const T* x = X + r * ld;
+        T* y = Y + r * ld;
+        int qg = 0;
+        const int* gkw = nullptr;
+        if (gq) {
+            const long local = r % period;               // row inside its (batch, window) block
+            const long win = (r / period) % (win_stride > 0 ? win_stride : 1);
+            qg = gq[win * period + local];
+            gkw = gk + win * (long)L;
+        }
+        float v[32];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = -INFINITY;
+            if (c < L) {
+                float s = to_f32<T>(x[c]) * scale;
+                if (gq && gkw[c] != qg) s += -100.0f;
+                v[i] = s;
+                mx = fmaxf(mx, s);
+            }
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int c = lane + 64 * i;
+            if (c < L) {
+                v[i] = expf(v[i] - mx);
+                sum += v[i];
+            }
+        }
+        sum = wave_sum(sum);
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int c = lane + 64 * i;
+            if (c < ld) y[c] = from_f32<T>(c < L ? v[i] * inv : 0.f);
+        }
+    }
+}
+
+// dS = P * (dP - rowsum(P*dP)) * scale   (columns >= L -> 0)
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const T* __restrict__ P, const T* __restrict__ DP,
+                                                               T* __restrict__ DS, long rows, int L, long ld,
+                                                               float scale) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nw = (long)gridDim.x * 4;
+    for (long r = wave; r < rows; r += nw) {
+        const T* p = P + r * ld;
+        const T* dp = DP + r * ld;
+        float pv[32], dv[32];
+        float dot = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int c = lane + 64 * i;
+            pv[i] = dv[i] = 0.f;
+            if (c < L) {
+                pv[i] = to_f32<T>(p[c]);
+                dv[i] = to_f32<T>(dp[c]);
+                dot += pv[i] * dv[i];
+            }
+        }
+        dot = wave_sum(dot);
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const int c = lane + 64 * i;
+            if (c < ld) DS[r * ld + c] = from_f32<T>(c < L ? pv[i] * (dv[i] - dot) * scale : 0.f);
+        }
+    }
+}
+
+// Y[z][c][r] = r < R ? X[z][r][c] : 0   for c < C, r < Rpad   (X rows of stride ldx, Y rows of stride Rpad)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ X, long ldx, long bsx,
+                                                            T* __restrict__ Y, long bsy, int R, int C, int Rpad) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const long z = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < C) ? to_f32<T>(X[z * bsx + (long)r * ldx + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < C && r < Rpad) Y[z * bsy + (long)c * Rpad + r] = from_f32<T>(tile[tx][i]);
+    }
+}
+
+// ---- GELU backward: dz = dy * (Phi(z) + z * phi(z)) --------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ Z, long ldz, const T* __restrict__ DY,
+                                                       long lddy, T* __restrict__ DZ, long lddz, long M, int C) {
+    const int nv = C >> 2;
+    const long total = M * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nv);
+        const long row = idx / nv;
+        float z[4], dy[4], o[4];
+        Vec4<T>::load(Z + row * ldz + vi * 4, z);
+        Vec4<T>::load(DY + row * lddy + vi * 4, dy);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float cdf = 0.5f * (1.f + erff(z[j] * 0.70710678118654752440f));
+            const float pdf = 0.3989422804014327f * expf(-0.5f * z[j] * z[j]);
+            o[j] = dy[j] * (cdf + z[j] * pdf);
+        }
+        Vec4<T>::store(DZ + row * lddz + vi * 4, o);
+    }
+}
+
+// ---- depthwise 3x3 weight / bias gradient: dW[tap][c] += sum_pix dY[pix][c] * X[pix+tap][c];  db[c] += sum dY -----
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ X, long ldx, const T* __restrict__ DY,
+                                                           long lddy, float* __restrict__ dW, float* __restrict__ db,
+                                                           int B, int H, int Wd, int C, int rows_per_block) {
+    // grid: (channel groups of 64 x row chunks, B); thread = (channel quad, pixel lane)
+    const int nq = 16;                       // 16 channel quads = 64 channels per block
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;   // 16 pixel lanes
+    const int cgroups = (C + 63) / 64;
+    const int cg = blockIdx.x % cgroups, chunk = blockIdx.x / cgroups;
+    const long b = blockIdx.y;
+    const int c = cg * 64 + cq * 4;
+    float aw[9][4], ab[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) aw[t][j] = 0.f;
+    const int y0 = chunk * rows_per_block, y1 = min(H, y0 + rows_per_block);
+    if (c < C) {
+        for (int y = y0; y < y1; ++y) {
+            for (int x = pl; x < Wd; x += 16) {
+                float dy[4];
+                Vec4<T>::load(DY + ((b * H + y) * (long)Wd + x) * lddy + c, dy);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) ab[j] += dy[j];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int iy = y + ky - 1;
+                    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int ix = x + kx - 1;
+                        if ((unsigned)ix >= (unsigned)Wd) continue;
+                        float xv[4];
+                        Vec4<T>::load(X + ((b * H + iy) * (long)Wd + ix) * ldx + c, xv);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) aw[ky * 3 + kx][j] = fmaf(dy[j], xv[j], aw[ky * 3 + kx][j]);
+                    }
+                }
+            }
+        }
+    }
+    __shared__ float red[10][16][4][16 + 1];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[t][cq][j][pl] = aw[t][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[9][cq][j][pl] = ab[j];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 10 * 64; i += 256) {
+        const int t = i / 64, cc = i % 64;
+        float s = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) s += red[t][cc >> 2][cc & 3][l];
+        const int ch = cg * 64 + cc;
+        if (ch < C) {
+            if (t < 9) atomicAdd(dW + t * C + ch, s);
+            else if (db) atomicAdd(db + ch, s);
+        }
+    }
+    (void)nq;
+}
+
+// ---- train-mode BatchNorm backward ------------------------------------------------------------------------------
+// pass 1: per channel s1 = sum dy', s2 = sum dy' * xhat   (dy' = dy masked by the ReLU of the forward output)
+// pass 2: dx = gamma * rstd * (dy' - s1/n - xhat * s2/n);  dgamma = s2, dbeta = s1.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_stats_kernel(const T* __restrict__ X, long ldx, const T* __restrict__ DY,
+                                                           long lddy, const T* __restrict__ OUT, long ldo,
+                                                           const double* __restrict__ fsums, float eps,
+                                                           float* __restrict__ s12, long rows, int C,
+                                                           int rows_per_block) {
+    __shared__ float red[256 * 8];
+    const int nv = C >> 2;
+    const int plan = 256 / nv;
+    const int vi = threadIdx.x % nv, rl = threadIdx.x / nv;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    if (rl < plan) {
+        float mean[4], rstd[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = vi * 4 + j;
+            const double m = fsums[c * 2] / (double)rows;
+            const double var = fmax(fsums[c * 2 + 1] / (double)rows - m * m, 0.0);
+            mean[j] = (float)m;
+            rstd[j] = (float)(1.0 / sqrt(var + (double)eps));
+        }
+        for (long r = r0 + rl; r < r1; r += plan) {
+            float x[4], dy[4], o[4];
+            Vec4<T>::load(X + r * ldx + vi * 4, x);
+            Vec4<T>::load(DY + r * lddy + vi * 4, dy);
+            if (OUT) Vec4<T>::load(OUT + r * ldo + vi * 4, o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float g = (OUT && o[j] <= 0.f) ? 0.f : dy[j];
+                s1[j] += g;
+                s2[j] = fmaf(g, (x[j] - mean[j]) * rstd[j], s2[j]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        red[threadIdx.x * 8 + j] = s1[j];
+        red[threadIdx.x * 8 + 4 + j] = s2[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < nv) {
+        float ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int l = 0; l < plan; ++l)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ts[j] += red[(l * nv + threadIdx.x) * 8 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(s12 + (threadIdx.x * 4 + j) * 2, ts[j]);
+            atomicAdd(s12 + (threadIdx.x * 4 + j) * 2 + 1, ts[4 + j]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ X, long ldx, const T* __restrict__ DY,
+                                                           long lddy, const T* __restrict__ OUT, long ldo,
+                                                           T* __restrict__ DX, long lddx,
+                                                           const double* __restrict__ fsums, float eps,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ s12, long rows, int C) {
+    const int nv = C >> 2;
+    const long total = rows * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nv);
+        const long r = idx / nv;
+        float x[4], dy[4], o[4], dx[4];
+        Vec4<T>::load(X + r * ldx + vi * 4, x);
+        Vec4<T>::load(DY + r * lddy + vi * 4, dy);
+        if (OUT) Vec4<T>::load(OUT + r * ldo + vi * 4, o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = vi * 4 + j;
+            const double m = fsums[c * 2] / (double)rows;
+            const double var = fmax(fsums[c * 2 + 1] / (double)rows - m * m, 0.0);
+            const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float xh = (x[j] - (float)m) * rstd;
+            const float g = (OUT && o[j] <= 0.f) ? 0.f : dy[j];
+            dx[j] = gamma[c] * rstd * (g - s12[c * 2] / (float)rows - xh * s12[c * 2 + 1] / (float)rows);
+        }
+        Vec4<T>::store(DX + r * lddx + vi * 4, dx);
+    }
+}
+
+// dgamma += s2, dbeta += s1
+__global__ void bn_bwd_acc_kernel(const float* __restrict__ ws, float* __restrict__ dg, float* __restrict__ db, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        dg[c] += ws[c * 2 + 1];
+        db[c] += ws[c * 2];
+    }
+}
+
+// ---- adjoint of bilinear resampling --------------------------------------------------------------------------------
+__device__ __forceinline__ void bl_src(int dst, int in, int out, int align, int& i0, int& i1, float& l1) {
+    float src;
+    if (align) {
+        const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f;
+        src = scale * (float)dst;
+    } else {
+        const float scale = (float)in / (float)out;
+        src = scale * ((float)dst + 0.5f) - 0.5f;
+        if (src < 0.f) src = 0.f;
+    }
+    i0 = (int)src;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    l1 = src - (float)i0;
+}
+
+// channels-last: DX[b][y][x][c] (f32 accumulation buffer, zero-filled by the caller) += w * DY[b][oy][ox][c]
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ DY, long lddy, float* __restrict__ DX,
+                                                           int B, int H, int Wd, int C, int Ho, int Wo, int align,
+                                                           float mul) {
+    const int nv = C >> 2;
+    const long total = (long)B * Ho * Wo * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nv);
+        const long pix = idx / nv;
+        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+        const long b = pix / ((long)Wo * Ho);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bl_src(oy, H, Ho, align, y0, y1, ly);
+        bl_src(ox, Wd, Wo, align, x0, x1, lx);
+        float g[4];
+        Vec4<T>::load(DY + pix * lddy + vi * 4, g);
+        float* base = DX + b * H * Wd * (long)C + vi * 4;
+        const float w00 = (1.f - ly) * (1.f - lx) * mul, w01 = (1.f - ly) * lx * mul;
+        const float w10 = ly * (1.f - lx) * mul, w11 = ly * lx * mul;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            atomicAdd(base + ((long)y0 * Wd + x0) * C + j, w00 * g[j]);
+            atomicAdd(base + ((long)y0 * Wd + x1) * C + j, w01 * g[j]);
+            atomicAdd(base + ((long)y1 * Wd + x0) * C + j, w10 * g[j]);
+            atomicAdd(base + ((long)y1 * Wd + x1) * C + j, w11 * g[j]);
+        }
+    }
+}
+
+// planar f32 DY [B][C][Ho][Wo] -> channels-last f32 accumulation DX [B][H][W][ldx] channels xc..xc+C-1
+__global__ __launch_bounds__(256) void bilinear_planar_bwd_kernel(const float* __restrict__ DY, float* __restrict__ DX,
+                                                                  long ldx, int xc, int B, int H, int Wd, int C, int Ho,
+                                                                  int Wo, int align, float mul) {
+    const long total = (long)B * C * Ho * Wo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wo), oy = (int)((idx / Wo) % Ho);
+        const int c = (int)((idx / ((long)Wo * Ho)) % C);
+        const long b = idx / ((long)Wo * Ho * C);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bl_src(oy, H, Ho, align, y0, y1, ly);
+        bl_src(ox, Wd, Wo, align, x0, x1, lx);
+        const float g = DY[idx] * mul;
+        float* base = DX + b * H * Wd * ldx + xc + c;
+        atomicAdd(base + ((long)y0 * Wd + x0) * ldx, (1.f - ly) * (1.f - lx) * g);
+        atomicAdd(base + ((long)y0 * Wd + x1) * ldx, (1.f - ly) * lx * g);
+        atomicAdd(base + ((long)y1 * Wd + x0) * ldx, ly * (1.f - lx) * g);
+        atomicAdd(base + ((long)y1 * Wd + x1) * ldx, ly * lx * g);
+    }
+}
+
+}  // namespace
+
+#define DISPATCH_T(dtype, ...)                          \
+    do {                                                \
+        if ((dtype) == EMIP_F32) {                      \
+            typedef float T;                            \
+            __VA_ARGS__;                                \
+        } else {                                        \
+            typedef bf16_t T;                           \
+            __VA_ARGS__;                                \
+        }                                               \
+    } while (0)
+#define REQ_DT(dtype) EMIP_REQUIRE((dtype) == EMIP_F32 || (dtype) == EMIP_BF16)
+
+extern "C" int emip_softmax_rows(const void* X, void* Y, long rows, int L, long ld, float scale, const int* gid_q,
+                                 const int* gid_k, long period, long nwin, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && rows > 0 && L > 0 && L <= 2048 && ld >= L && ld <= 2048);
+    EMIP_REQUIRE((gid_q == nullptr) == (gid_k == nullptr));
+    if (gid_q) EMIP_REQUIRE(period > 0 && nwin > 0);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)X, (T*)Y, rows, L, ld, scale, gid_q, gid_k,
+                                         period, nwin));
+    return emip_launch_status();
+}
+
+extern "C" int emip_softmax_bwd_rows(const void* P, const void* DP, void* DS, long rows, int L, long ld, float scale,
+                                     int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(P && DP && DS && rows > 0 && L > 0 && L <= 2048 && ld >= L && ld <= 2048);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_bwd_rows_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)P, (const T*)DP, (T*)DS, rows, L, ld, scale));
+    return emip_launch_status();
+}
+
+extern "C" int emip_transpose_pad(const void* X, long ldx, long bsx, void* Y, long bsy, int batch, int R, int C,
+                                  int Rpad, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && batch > 0 && batch < 65536 && R > 0 && C > 0 && Rpad >= R && ldx >= C);
+    dim3 grid((Rpad + 31) / 32, (C + 31) / 32, batch);
+    EMIP_REQUIRE(grid.y < 65536);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_pad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)X,
+                                         ldx, bsx, (T*)Y, bsy, R, C, Rpad));
+    return emip_launch_status();
+}
+
+extern "C" int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy, void* DZ, long lddz, long M, int C,
+                             int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(Z && DY && DZ && M > 0 && C >= 4 && (C & 3) == 0 && (ldz & 3) == 0 && (lddy & 3) == 0 &&
+                 (lddz & 3) == 0 && ldz >= C && lddy >= C && lddz >= C);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(grid_for(M * (C >> 2), 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)Z, ldz, (const T*)DY, lddy, (T*)DZ, lddz, M, C));
+    return emip_launch_status();
+}
+
+// dW f32 [9][C] and db f32 [C] (may be NULL) are ACCUMULATED into
+extern "C" int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, long lddy, float* dW, float* db, int B,
+                                    int H, int Wd, int C, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && DY && dW && B > 0 && B < 65536 && H > 0 && Wd > 0 && C >= 4 && (C & 3) == 0);
+    EMIP_REQUIRE((ldx & 3) == 0 && (lddy & 3) == 0 && ldx >= C && lddy >= C);
+    const int rpb = 4;
+    dim3 grid(((C + 63) / 64) * ((H + rpb - 1) / rpb), B);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_wgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)X,
+                                         ldx, (const T*)DY, lddy, dW, db, B, H, Wd, C, rpb));
+    return emip_launch_status();
+}
+
+// x: conv output (pre-BN) [rows][C]; out: the ReLU'd forward output (NULL when no ReLU followed); fsums: the forward's
+// emip_chan_stats sums (groups = 1).  dgamma/dbeta (f32 [C]) are ACCUMULATED into.  ws: f32 [2*C] scratch.
+extern "C" int emip_bn_train_bwd(const void* X, long ldx, const void* DY, long lddy, const void* OUT, long ldo, void* DX,
+                                 long lddx, const double* fsums, const float* gamma, float* dgamma, float* dbeta,
+                                 float* ws, long rows, int C, float eps, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && DY && DX && fsums && gamma && dgamma && dbeta && ws && rows > 0 && C >= 4 && C <= 1024 &&
+                 (C & 3) == 0);
+    EMIP_REQUIRE((ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C && lddy >= C && lddx >= C);
+    if (OUT) EMIP_REQUIRE((ldo & 3) == 0 && ldo >= C);
+    hipStream_t s = (hipStream_t)stream;
+    if (emip_zero_async(ws, sizeof(float) * 2 * C, s) != EMIP_OK) return EMIP_E_LAUNCH;
+    const int rpb = 512;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_stats_kernel<T>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0,
+                                         s, (const T*)X, ldx, (const T*)DY, lddy, (const T*)OUT, ldo, fsums, eps, ws,
+                                         rows, C, rpb));
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(grid_for(rows * (C >> 2), 256)), dim3(256), 0, s,
+                                         (const T*)X, ldx, (const T*)DY, lddy, (const T*)OUT, ldo, (T*)DX, lddx, fsums,
+                                         eps, gamma, ws, rows, C));
+    hipLaunchKernelGGL(bn_bwd_acc_kernel, dim3((C + 255) / 256), dim3(256), 0, s, ws, dgamma, dbeta, C);
+    return emip_launch_status();
+}
+
+// DX: f32 [B][H][W][C] accumulation buffer (zero-filled by the caller or carrying other contributions)
+extern "C" int emip_bilinear_bwd(const void* DY, long lddy, float* DX, int B, int H, int Wd, int C, int Ho, int Wo,
+                                 int align_corners, float mul, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(DY && DX && B > 0 && H > 0 && Wd > 0 && Ho > 0 && Wo > 0 && C >= 4 && (C & 3) == 0 &&
+                 (lddy & 3) == 0 && lddy >= C);
+    const long total = (long)B * Ho * Wo * (C >> 2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(bilinear_bwd_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)DY, lddy, DX, B, H, Wd, C, Ho, Wo,
+                                         align_corners, mul));
+    return emip_launch_status();
+}
+
+extern "C" int emip_bilinear_planar_bwd(const float* DY, float* DX, long ldx, int xc, int B, int H, int Wd, int C,
+                                        int Ho, int Wo, int align_corners, float mul, void* stream) {
+    EMIP_REQUIRE(DY && DX && B > 0 && H > 0 && Wd > 0 && Ho > 0 && Wo > 0 && C >= 1 && xc >= 0 && ldx >= xc + C);
+    const long total = (long)B * C * Ho * Wo;
+    hipLaunchKernelGGL(bilinear_planar_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream, DY,
+                       DX, ldx, xc, B, H, Wd, C, Ho, Wo, align_corners, mul);
+    return emip_launch_status();
+}

@@ -23,11 +23,15 @@ struct TnArgs {
     long lda, ldb, ldc;
     long m_per_split;
     int tiles_n, tiles_k;
+    // CONV: B[m][k] is the im2col view of an NHWC tensor X (m = output pixel, k = (ky, kx, ci), ci fastest)
+    int H, Wd, Cin, Ho, Wo, KW, stride, pad;
+    // batching over blockIdx.z (element strides)
+    long bsA, bsB, bsC;
 };
 
 __device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
-template <typename T>
+template <typename T, bool CONV>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
     constexpr int ES = sizeof(T);
     constexpr bool BF = ES == 2;
@@ -46,8 +50,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
     const int n0 = tile_n * 128, k0 = tile_k * 128;
     const long m_lo = (long)blockIdx.y * p.m_per_split;
     const long m_hi = min(p.M, m_lo + p.m_per_split);
-    const T* __restrict__ A = reinterpret_cast<const T*>(p.A);
-    const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B);
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (long)blockIdx.z * p.bsA;
+    const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B) + (long)blockIdx.z * p.bsB;
+    float* __restrict__ Cp = p.C + (long)blockIdx.z * p.bsC;
 
     uint4 ra[NS], rb[NS];
     auto load_stage = [&](long m0) {
@@ -60,7 +65,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
             const int na = n0 + c * (16 / ES), kb = k0 + c * (16 / ES);
             const int nac = min(na, max(p.N - 16 / ES, 0)), kbc = min(kb, max(p.K - 16 / ES, 0));
             ra[i] = mask4(*reinterpret_cast<const uint4*>(A + mc * p.lda + nac), m < m_hi && na < p.N);
-            rb[i] = mask4(*reinterpret_cast<const uint4*>(Bp + mc * p.ldb + kbc), m < m_hi && kb < p.K);
+            if (CONV) {
+                const int hw = p.Ho * p.Wo;
+                const int bimg = (int)(mc / hw);
+                const int rem = (int)(mc - (long)bimg * hw);
+                const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+                const int tap = kbc / p.Cin, ci = kbc - tap * p.Cin;
+                const int ky = tap / p.KW, kx = tap - ky * p.KW;
+                const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+                const bool ok = m < m_hi && kb < p.K && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.Wd - 1);
+                rb[i] = mask4(*reinterpret_cast<const uint4*>(Bp + (((long)bimg * p.H + iyc) * p.Wd + ixc) * p.ldb + ci), ok);
+            } else {
+                rb[i] = mask4(*reinterpret_cast<const uint4*>(Bp + mc * p.ldb + kbc), m < m_hi && kb < p.K);
+            }
         }
     };
     auto store_stage = [&]() {
@@ -155,7 +173,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
             for (int j = 0; j < 4; ++j) {
                 const int n = n0 + wn * 64 + 16 * a + 4 * q + j;
                 if (n >= p.N) continue;
-                float* dst = p.C + (long)n * p.ldc + k;
+                float* dst = Cp + (long)n * p.ldc + k;
                 if (atomic) atomicAdd(dst, acc[a][b][j]);
                 else *dst = acc[a][b][j];
             }
@@ -164,34 +182,58 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
 
 }  // namespace
 
-// C must be zero-filled by the caller when the launch splits M (it always may: the function zero-fills itself).
-extern "C" int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc,
-                            int dtype, void* stream) {
-    EMIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
-    EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
-    const int vec = dtype == EMIP_F32 ? 4 : 8;
-    EMIP_REQUIRE(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= N && ldb >= K && ldc >= K);
-    EMIP_REQUIRE(aligned16(A) && aligned16(B));
-    TnArgs a{};
-    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
-    a.tiles_n = (N + 127) / 128;
-    a.tiles_k = (K + 127) / 128;
+namespace {
+template <bool CONV>
+int launch_tn(TnArgs& a, int batch, int dtype, hipStream_t s) {
+    a.tiles_n = (a.N + 127) / 128;
+    a.tiles_k = (a.K + 127) / 128;
     const int bms = dtype == EMIP_F32 ? 32 : 64;
-    const long tiles = (long)a.tiles_n * a.tiles_k;
+    const long tiles = (long)a.tiles_n * a.tiles_k * batch;
     long splits = (1024 + tiles - 1) / tiles;                       // aim at >= ~1024 workgroups
-    const long max_splits = (M + 4 * bms - 1) / (4 * bms);          // but >= 4 stages of work per workgroup
+    const long max_splits = (a.M + 4 * bms - 1) / (4 * bms);        // but >= 4 stages of work per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
     if (splits > 65535) splits = 65535;
-    a.m_per_split = ((M + splits - 1) / splits + bms - 1) / bms * bms;
-    splits = (M + a.m_per_split - 1) / a.m_per_split;
-    hipStream_t s = (hipStream_t)stream;
-    if (splits > 1) {   // zero the (possibly strided) output rows; ldc == K for every caller so far
-        EMIP_REQUIRE(ldc == K);
-        if (emip_zero_async(C, sizeof(float) * (size_t)N * K, s) != EMIP_OK) return EMIP_E_LAUNCH;
+    a.m_per_split = ((a.M + splits - 1) / splits + bms - 1) / bms * bms;
+    splits = (a.M + a.m_per_split - 1) / a.m_per_split;
+    if (splits > 1) {   // partial tiles are combined with atomics: clear the output first (dense rows only)
+        if (a.ldc != a.K || (batch > 1 && a.bsC != (long)a.N * a.K)) return EMIP_E_INVALID;
+        if (emip_zero_async(a.C, sizeof(float) * (size_t)a.N * a.K * batch, s) != EMIP_OK) return EMIP_E_LAUNCH;
     }
-    dim3 grid((unsigned)tiles, (unsigned)splits);
-    if (dtype == EMIP_F32) hipLaunchKernelGGL(gemm_tn_kernel<float>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(gemm_tn_kernel<bf16_t>, grid, dim3(256), 0, s, a);
+    dim3 grid((unsigned)(a.tiles_n * a.tiles_k), (unsigned)splits, (unsigned)batch);
+    if (dtype == EMIP_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, CONV>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, CONV>), grid, dim3(256), 0, s, a);
     return emip_launch_status();
+}
+}  // namespace
+
+extern "C" int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc,
+                            int batch, long bsA, long bsB, long bsC, int dtype, void* stream) {
+    EMIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536);
+    EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= N && ldb >= K && ldc >= K);
+    EMIP_REQUIRE(bsA % vec == 0 && bsB % vec == 0 && aligned16(A) && aligned16(B));
+    TnArgs a{};
+    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.bsA = bsA; a.bsB = bsB; a.bsC = bsC;
+    return launch_tn<false>(a, batch, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+// dW[co][ky][kx][ci] = sum_{b,oy,ox} dY[b,oy,ox,co] * X[b, oy*s-p+ky, ox*s-p+kx, ci]   (f32, packed like the forward weights)
+extern "C" int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx,
+                                 int Cout, long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream) {
+    EMIP_REQUIRE(dY && X && dW && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 &&
+                 pad >= 0);
+    EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(Cin % vec == 0 && Cout % vec == 0 && ldx % vec == 0 && lddy % vec == 0 && ldx >= Cin && lddy >= Cout);
+    EMIP_REQUIRE(aligned16(dY) && aligned16(X));
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
+    EMIP_REQUIRE(Ho > 0 && Wo > 0 && (long)B * Ho * Wo < 2147483647L && (long)KH * KW * Cin < 2147483647L);
+    TnArgs a{};
+    a.A = dY; a.B = X; a.C = dW; a.M = (long)B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin;
+    a.lda = lddy; a.ldb = ldx; a.ldc = a.K;
+    a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
+    return launch_tn<true>(a, 1, dtype, reinterpret_cast<hipStream_t>(stream));
 }

@@ -305,8 +305,30 @@ def gemm_tn(a, b):
     Mb, K, ldb = rows(b)
     assert M == Mb and a.dtype == b.dtype
     c = torch.empty((N, K), dtype=torch.float32, device=a.device)
-    _lib.call("emip_gemm_tn", _p(a), _p(b), _p(c), M, N, K, lda, ldb, K, dt_code(a.dtype), _stream())
+    _lib.call("emip_gemm_tn", _p(a), _p(b), _p(c), M, N, K, lda, ldb, K, 1, 0, 0, 0, dt_code(a.dtype), _stream())
     return c
+
+
+def gemm_tn_batched(a, b, batch, M, N, K, lda, ldb, bsA, bsB):
+    """per batch z: c[z][n, k] = sum_m a[z][m, n] * b[z][m, k] -> f32 [batch, N, K]"""
+    _dev(a)
+    c = torch.empty((batch, N, K), dtype=torch.float32, device=a.device)
+    _lib.call("emip_gemm_tn", _p(a), _p(b), _p(c), M, N, K, lda, ldb, K, batch, bsA, bsB, N * K, dt_code(a.dtype),
+              _stream())
+    return c
+
+
+def conv2d_wgrad(dy, x, kh, kw, stride, pad):
+    """dy [B,Ho,Wo,Cout], x [B,H,W,Cin] channels-last -> dW f32 [Cout, kh*kw*Cin] (packed like the forward weights)"""
+    _dev(x)
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[-1]
+    _, _, ldx = rows(x)
+    _, _, lddy = rows(dy)
+    dw = torch.empty((Cout, kh * kw * Cin), dtype=torch.float32, device=x.device)
+    _lib.call("emip_conv2d_wgrad", _p(dy), _p(x), _p(dw), B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad,
+              dt_code(x.dtype), _stream())
+    return dw
 
 
 def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta):
@@ -315,4 +337,78 @@ def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta):
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     _lib.call("emip_layernorm_bwd", _p(x), ldx, _p(dy), lddy, _p(dx), C, _p(gamma), _p(dgamma), _p(dbeta), M, C,
               float(eps), dt_code(x.dtype), _stream())
+    return dx
+
+
+# ---- backward building blocks ---------------------------------------------------------------------------------------
+def softmax_rows(x, L, scale=1.0, gid_q=None, gid_k=None, period=0, nwin=0, out=None):
+    M, _, ld = rows(x)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.call("emip_softmax_rows", _p(x), _p(out), M, L, ld, float(scale), _p(gid_q), _p(gid_k), period, nwin,
+              dt_code(x.dtype), _stream())
+    return out
+
+
+def softmax_bwd_rows(p, dp, L, scale=1.0, out=None):
+    M, _, ld = rows(p)
+    if out is None:
+        out = torch.empty_like(p)
+    _lib.call("emip_softmax_bwd_rows", _p(p), _p(dp), _p(out), M, L, ld, float(scale), dt_code(p.dtype), _stream())
+    return out
+
+
+def transpose_pad(x, rpad):
+    """x [Z, R, C] (row stride = x.stride(1)) -> [Z, C, rpad] with zero padding of the R axis"""
+    _dev(x)
+    Z, R, C = x.shape
+    y = torch.empty((Z, C, rpad), dtype=x.dtype, device=x.device)
+    _lib.call("emip_transpose_pad", _p(x), x.stride(1), x.stride(0), _p(y), C * rpad, Z, R, C, rpad, dt_code(x.dtype),
+              _stream())
+    return y
+
+
+def gelu_bwd(z, dy):
+    M, C, ldz = rows(z)
+    _, _, lddy = rows(dy)
+    dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    _lib.call("emip_gelu_bwd", _p(z), ldz, _p(dy), lddy, _p(dz), C, M, C, dt_code(z.dtype), _stream())
+    return dz
+
+
+def dwconv3x3_wgrad(x, dy, dw, db=None):
+    B, H, W, C = x.shape
+    _, _, ldx = rows(x)
+    _, _, lddy = rows(dy)
+    _lib.call("emip_dwconv3x3_wgrad", _p(x), ldx, _p(dy), lddy, _p(dw), _p(db), B, H, W, C, dt_code(x.dtype), _stream())
+    return dw
+
+
+def bn_train_bwd(x, dy, out, fsums, gamma, dgamma, dbeta, eps):
+    M, C, ldx = rows(x)
+    _, _, lddy = rows(dy)
+    ldo = rows(out)[2] if out is not None else 0
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    ws = torch.empty(2 * C, dtype=torch.float32, device=x.device)
+    _lib.call("emip_bn_train_bwd", _p(x), ldx, _p(dy), lddy, _p(out), ldo, _p(dx), C, _p(fsums), _p(gamma), _p(dgamma),
+              _p(dbeta), _p(ws), M, C, float(eps), dt_code(x.dtype), _stream())
+    return dx
+
+
+def bilinear_bwd(dy, H, W, align_corners, mul=1.0):
+    B, Ho, Wo, C = dy.shape
+    _, _, lddy = rows(dy)
+    dx = torch.zeros((B, H, W, C), dtype=torch.float32, device=dy.device)
+    _lib.call("emip_bilinear_bwd", _p(dy), lddy, _p(dx), B, H, W, C, Ho, Wo, int(align_corners), float(mul),
+              dt_code(dy.dtype), _stream())
+    return dx
+
+
+def bilinear_planar_bwd(dy, H, W, align_corners, mul=1.0):
+    """dy planar f32 [B,C,Ho,Wo] -> f32 channels-last [B,H,W,C]"""
+    _dev(dy)
+    B, C, Ho, Wo = dy.shape
+    dx = torch.zeros((B, H, W, C), dtype=torch.float32, device=dy.device)
+    _lib.call("emip_bilinear_planar_bwd", _p(dy.contiguous()), _p(dx), C, 0, B, H, W, C, Ho, Wo, int(align_corners),
+              float(mul), _stream())
     return dx

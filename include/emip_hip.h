@@ -175,12 +175,49 @@ int emip_photometric_loss(const float* im, const float* rec, const float* mask, 
 
 /* Weight gradient of nn.Linear / 1x1 conv:  C[n][k] = sum_m A[m][n] * B[m][k]  (A = dY [M][N], B = X [M][K], both
  * as the forward leaves them in HBM), f32 output; M is split over workgroups and combined with f32 atomics. */
-int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc, int dtype,
-                 void* stream);
+int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc, int batch,
+                 long bsA, long bsB, long bsC, int dtype, void* stream);
+
+/* Weight gradient of an NHWC conv, packed like the forward weights: dW[co][ky][kx][ci] (f32) =
+ * sum over output pixels of dY[pix][co] * X[pix shifted by the tap][ci]  (zero padding honoured). */
+int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout,
+                      long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream);
 
 /* LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (f32 atomics).  mean/rstd are recomputed from x. */
 int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx, const float* gamma,
                        float* dgamma, float* dbeta, long M, int C, float eps, int dtype, void* stream);
+
+/* Row softmax of the first L columns (columns L..ld-1 are written as 0): Y = softmax(X*scale + mask), mask = -100
+ * where gid_q[win][row] != gid_k[win][col] (rows are ordered [batch][win][period]); and its backward
+ * dS = P * (dP - rowsum(P*dP)) * scale.  Used by the unfused attention backward (P is recomputed, never stored by fwd). */
+int emip_softmax_rows(const void* X, void* Y, long rows, int L, long ld, float scale, const int* gid_q, const int* gid_k,
+                      long period, long nwin, int dtype, void* stream);
+int emip_softmax_bwd_rows(const void* P, const void* DP, void* DS, long rows, int L, long ld, float scale, int dtype,
+                          void* stream);
+
+/* Y[z][c][r] = r < R ? X[z][r][c] : 0 (r < Rpad): the K^T operand of dQ = dS K. */
+int emip_transpose_pad(const void* X, long ldx, long bsx, void* Y, long bsy, int batch, int R, int C, int Rpad,
+                       int dtype, void* stream);
+
+/* dz = dy * d/dz gelu(z) (exact erf form, lib/pvt_v2.py:50). */
+int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy, void* DZ, long lddz, long M, int C, int dtype,
+                  void* stream);
+
+/* Depthwise 3x3 weight/bias gradient, ACCUMULATED into dW f32 [9][C] and db f32 [C] (db may be NULL). */
+int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, long lddy, float* dW, float* db, int B, int H, int Wd,
+                         int C, int dtype, void* stream);
+
+/* Train-mode BatchNorm2d (+ReLU when OUT != NULL) backward.  X: pre-BN conv output, OUT: the forward output,
+ * fsums: the forward's emip_chan_stats (groups = 1); dgamma/dbeta accumulated; ws: f32 [2*C]. */
+int emip_bn_train_bwd(const void* X, long ldx, const void* DY, long lddy, const void* OUT, long ldo, void* DX, long lddx,
+                      const double* fsums, const float* gamma, float* dgamma, float* dbeta, float* ws, long rows, int C,
+                      float eps, int dtype, void* stream);
+
+/* Adjoints of emip_bilinear / emip_bilinear_planar: scatter-add into an f32 channels-last accumulation buffer. */
+int emip_bilinear_bwd(const void* DY, long lddy, float* DX, int B, int H, int Wd, int C, int Ho, int Wo,
+                      int align_corners, float mul, int dtype, void* stream);
+int emip_bilinear_planar_bwd(const float* DY, float* DX, long ldx, int xc, int B, int H, int Wd, int C, int Ho, int Wo,
+                             int align_corners, float mul, void* stream);
 
 /* ---- optimizer ----------------------------------------------------------------------------------- */
 

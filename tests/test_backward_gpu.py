@@ -75,3 +75,123 @@ def test_layernorm_backward(dtype, M, C):
     dx = ops.layernorm_bwd(x, dy, g.cuda(), 1e-6, dg, db)
     tol = 2e-4 if dtype == torch.float32 else 2e-2
     assert rel(dx, xr.grad) < tol and rel(dg, gr.grad) < tol and rel(db, br.grad) < tol
+
+
+def _pack_conv_w(w):  # [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin]
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [(2, 44, 44, 64, 96, 3, 1, 1), (2, 30, 26, 96, 128, 3, 2, 1),
+                                                  (2, 88, 88, 64, 64, 8, 8, 0), (1, 44, 44, 1936, 72, 3, 1, 1),
+                                                  (2, 64, 48, 8, 64, 7, 4, 3)])
+def test_conv_wgrad_and_dgrad(dtype, B, H, W, Cin, Cout, k, s, p):
+    from emip_amd import ops
+    x, xf = prep(rnd(B, H, W, Cin, seed=1), dtype)
+    w4 = rnd(Cout, Cin, k, k, seed=2, scale=1 / math.sqrt(Cin * k * k)).to(dtype).float()
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    dy, dyf = prep(rnd(B, Ho, Wo, Cout, seed=3), dtype)
+    xr = xf.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    wr = w4.clone().requires_grad_(True)
+    F.conv2d(xr, wr, None, stride=s, padding=p).backward(dyf.permute(0, 3, 1, 2))
+    dw = ops.conv2d_wgrad(dy, x, k, k, s, p)
+    tol = 1e-4 if dtype == torch.float32 else 4e-3
+    assert rel(dw, _pack_conv_w(wr.grad)) < tol
+    if s == 1:   # dgrad of a stride-1 conv = the forward conv with flipped, transposed weights
+        wflip = w4.flip(2, 3).permute(1, 0, 2, 3).contiguous()            # [Cin, Cout, k, k]
+        wd, _ = prep(_pack_conv_w(wflip), dtype)
+        dx = ops.conv2d(dy, wd, k, k, 1, k - 1 - p)
+        assert rel(dx.permute(0, 3, 1, 2), xr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_tn_batched(dtype):
+    from emip_amd import ops
+    Bz, M, N, K = 6, 484, 128, 64
+    a, af = prep(rnd(Bz, M, N, seed=1), dtype)
+    b, bf = prep(rnd(Bz, M, K, seed=2), dtype)
+    c = ops.gemm_tn_batched(a, b, Bz, M, N, K, N, K, M * N, M * K)
+    assert rel(c, af.transpose(1, 2) @ bf) < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_softmax_rows_fwd_bwd(dtype):
+    from emip_amd import ops
+    M, L, ld = 3000, 121, 128
+    x, xf = prep(rnd(M, ld, seed=1) * 3, dtype)
+    dp, dpf = prep(rnd(M, ld, seed=2), dtype)
+    p = ops.softmax_rows(x, L, scale=0.125)
+    ref = (xf[:, :L] * 0.125).softmax(-1)
+    assert rel(p[:, :L], ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert p[:, L:].abs().max().item() == 0
+    pf = p.float().cpu()[:, :L]
+    ds = ops.softmax_bwd_rows(p, dp, L, scale=0.125)
+    refds = pf * (dpf[:, :L] - (pf * dpf[:, :L]).sum(-1, keepdim=True)) * 0.125
+    assert rel(ds[:, :L], refds) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert ds[:, L:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose_gelu_dwconv_wgrad(dtype):
+    from emip_amd import ops
+    k, kf = prep(rnd(6, 121, 64, seed=1), dtype)
+    kt = ops.transpose_pad(k, 128)
+    assert torch.equal(kt[:, :, :121].float().cpu(), kf.transpose(1, 2)) and kt[:, :, 121:].abs().max().item() == 0
+    z, zf = prep(rnd(500, 256, seed=2) * 2, dtype)
+    dy, dyf = prep(rnd(500, 256, seed=3), dtype)
+    zr = zf.clone().requires_grad_(True)
+    F.gelu(zr).backward(dyf)
+    assert rel(ops.gelu_bwd(z, dy), zr.grad) < (1e-5 if dtype == torch.float32 else 1e-2)
+    B, H, W, C = 2, 22, 22, 320
+    x, xf = prep(rnd(B, H, W, C, seed=4), dtype)
+    g, gf = prep(rnd(B, H, W, C, seed=5), dtype)
+    w = rnd(C, 1, 3, 3, seed=6).requires_grad_(True)
+    b = rnd(C, seed=7).requires_grad_(True)
+    F.conv2d(xf.permute(0, 3, 1, 2), w, b, padding=1, groups=C).backward(gf.permute(0, 3, 1, 2))
+    dw = torch.zeros(9, C, device="cuda:0")
+    db = torch.zeros(C, device="cuda:0")
+    ops.dwconv3x3_wgrad(x, g, dw, db)
+    assert rel(dw, w.grad.view(C, 9).t()) < (1e-4 if dtype == torch.float32 else 5e-3)
+    assert rel(db, b.grad) < (1e-4 if dtype == torch.float32 else 5e-3)
+    # dgrad of the depthwise conv = the forward depthwise kernel with the taps reversed
+    wt = w.detach().view(C, 9).flip(1).t().contiguous().cuda()
+    xr = xf.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.conv2d(xr, w.detach(), None, padding=1, groups=C).backward(gf.permute(0, 3, 1, 2))
+    dx = ops.dwconv3x3(g, wt)
+    assert rel(dx.permute(0, 3, 1, 2), xr.grad) < (1e-4 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_train_backward(dtype):
+    from emip_amd import ops
+    B, H, W, C = 3, 20, 22, 96
+    x, xf = prep(rnd(B, H, W, C, seed=1) * 2 + 0.5, dtype)
+    dy, dyf = prep(rnd(B, H, W, C, seed=2), dtype)
+    g = (1 + 0.1 * rnd(C, seed=3))
+    bb = 0.1 * rnd(C, seed=4)
+    xr = xf.permute(0, 3, 1, 2).clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), bb.clone().requires_grad_(True)
+    out_ref = F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.0, 1e-5))
+    out_ref.backward(dyf.permute(0, 3, 1, 2))
+    sums = ops.chan_stats(x, 1)
+    out = ops.chan_norm_apply(x, sums, 1, 1e-5, relu_inner=True, gamma=g.cuda(), beta=bb.cuda())
+    dg = torch.zeros(C, device="cuda:0")
+    db = torch.zeros(C, device="cuda:0")
+    dx = ops.bn_train_bwd(x, dy, out, sums, g.cuda(), dg, db, 1e-5)
+    tol = 2e-4 if dtype == torch.float32 else 3e-2
+    assert rel(dx.permute(0, 3, 1, 2), xr.grad) < tol and rel(dg, gr.grad) < tol and rel(db, br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bilinear_backward(dtype):
+    from emip_amd import ops
+    x = rnd(2, 32, 11, 11, seed=1).requires_grad_(True)
+    dy, dyf = prep(rnd(2, 22, 22, 32, seed=2), dtype)
+    F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True).backward(dyf.permute(0, 3, 1, 2))
+    dx = ops.bilinear_bwd(dy, 11, 11, True)
+    assert rel(dx.permute(0, 3, 1, 2), x.grad) < 1e-5
+    pc = rnd(2, 1, 44, 44, seed=3).requires_grad_(True)
+    g = rnd(2, 1, 352, 352, seed=4)
+    F.interpolate(pc, scale_factor=8, mode="bilinear").backward(g)
+    dpc = ops.bilinear_planar_bwd(g.cuda(), 44, 44, False)
+    assert rel(dpc.permute(0, 3, 1, 2), pc.grad) < 1e-5
