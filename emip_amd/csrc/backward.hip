@@ -485,3 +485,112 @@ extern "C" int emip_bilinear_planar_bwd(const float* DY, float* DX, long ldx, in
                        DX, ldx, xc, B, H, Wd, C, Ho, Wo, align_corners, mul);
     return emip_launch_status();
 }
+
+// ---- helpers for strided-conv input gradients ----------------------------------------------------------------------
+namespace {
+// Z[b][oy*s][ox*s][:] = DY[b][oy][ox][:], every other element of Z (size H x W) zero: the transposed conv of a
+// strided conv is then the stride-1 conv of Z with the flipped, transposed weights.
+template <typename T>
+__global__ __launch_bounds__(256) void zero_insert_kernel(const T* __restrict__ DY, long lddy, T* __restrict__ Z, int B,
+                                                          int Ho, int Wo, int H, int Wd, int C, int s) {
+    const int nv = C >> 2;
+    const long total = (long)B * H * Wd * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nv);
+        const long pix = idx / nv;
+        const int x = (int)(pix % Wd), y = (int)((pix / Wd) % H);
+        const long b = pix / ((long)Wd * H);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (y % s == 0 && x % s == 0 && y / s < Ho && x / s < Wo)
+            Vec4<T>::load(DY + ((b * Ho + y / s) * (long)Wo + x / s) * lddy + vi * 4, v);
+        Vec4<T>::store(Z + pix * C + vi * 4, v);
+    }
+}
+// non-overlapping patches (k == stride, pad 0): DX[b][oy*k+ky][ox*k+kx][ci] = P[(b,oy,ox)][(ky,kx,ci)]
+template <typename T>
+__global__ __launch_bounds__(256) void depatchify_kernel(const T* __restrict__ P, T* __restrict__ DX, int B, int Ho,
+                                                         int Wo, int k, int C) {
+    const int nv = C >> 2;
+    const int H = Ho * k, Wd = Wo * k;
+    const long total = (long)B * H * Wd * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nv);
+        const long pix = idx / nv;
+        const int x = (int)(pix % Wd), y = (int)((pix / Wd) % H);
+        const long b = pix / ((long)Wd * H);
+        const long m = (b * Ho + y / k) * Wo + x / k;
+        const int tap = (y % k) * k + (x % k);
+        float v[4];
+        Vec4<T>::load(P + m * ((long)k * k * C) + (long)tap * C + vi * 4, v);
+        Vec4<T>::store(DX + pix * C + vi * 4, v);
+    }
+}
+}  // namespace
+
+extern "C" int emip_zero_insert(const void* DY, long lddy, void* Z, int B, int Ho, int Wo, int H, int Wd, int C,
+                                int stride, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(DY && Z && B > 0 && Ho > 0 && Wo > 0 && H >= (Ho - 1) * stride + 1 && Wd >= (Wo - 1) * stride + 1 &&
+                 C >= 4 && (C & 3) == 0 && (lddy & 3) == 0 && lddy >= C && stride >= 1);
+    const long total = (long)B * H * Wd * (C >> 2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(zero_insert_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)DY, lddy, (T*)Z, B, Ho, Wo, H, Wd, C, stride));
+    return emip_launch_status();
+}
+
+extern "C" int emip_depatchify(const void* P, void* DX, int B, int Ho, int Wo, int k, int C, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(P && DX && B > 0 && Ho > 0 && Wo > 0 && k >= 1 && C >= 4 && (C & 3) == 0);
+    const long total = (long)B * Ho * k * Wo * k * (C >> 2);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(depatchify_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)P, (T*)DX, B, Ho, Wo, k, C));
+    return emip_launch_status();
+}
+
+// ---- column sums (bias gradients): out[c] += sum_rows X[row][c], any C (multiple of 4) ----------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ X, long ldx, float* __restrict__ out,
+                                                     long rows, int C, int rows_per_block) {
+    __shared__ float red[16][4][17];
+    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int cgroups = (C + 63) / 64;
+    const int cg = blockIdx.x % cgroups;
+    const long chunk = blockIdx.x / cgroups;
+    const int c = cg * 64 + cq * 4;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        const long r0 = chunk * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+        for (long r = r0 + pl; r < r1; r += 16) {
+            float v[4];
+            Vec4<T>::load(X + r * ldx + c, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += v[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[cq][j][pl] = s[j];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int q = threadIdx.x >> 2, j = threadIdx.x & 3;
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 16; ++l) t += red[q][j][l];
+        const int ch = cg * 64 + threadIdx.x;
+        if (ch < C) atomicAdd(out + ch, t);
+    }
+}
+}  // namespace
+
+// out f32 [C] is ACCUMULATED into
+extern "C" int emip_colsum(const void* X, long ldx, float* out, long rows, int C, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && out && rows > 0 && C >= 4 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C);
+    const int rpb = 256;
+    const long chunks = (rows + rpb - 1) / rpb;
+    const long blocks = chunks * ((C + 63) / 64);
+    EMIP_REQUIRE(blocks < 2147483647L);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colsum_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)X, ldx, out, rows, C, rpb));
+    return emip_launch_status();
+}

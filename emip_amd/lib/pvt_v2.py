@@ -11,7 +11,20 @@ import torch
 import torch.nn as nn
 
 from .. import ops
+from ..autograd import ConvFn, DwConvFn, LayerNormFn, LinearFn, SraAttentionFn
 from ..nn_base import EmipModule, f32, pack_conv, pack_dw, pack_linear, to_cl, to_planar
+
+
+def _lin_packs(w, dt):
+    """forward pack [N,K] and input-gradient pack [K,N] of a Linear weight"""
+    return pack_linear(w, dt), w.detach().t().to(dt).contiguous()
+
+
+def _conv_dgrad_pack(w, dt, k, s, p):
+    """weights for the input gradient of a conv: W^T for non-overlapping patch convs, else flipped + transposed"""
+    if k == s and p == 0:
+        return pack_conv(w, dt).t().contiguous()                       # [k*k*Cin, Cout]
+    return pack_conv(w.detach().flip(2, 3).permute(1, 0, 2, 3), dt)    # [Cin, k*k*Cout]
 
 
 class DWConv(EmipModule):
@@ -33,7 +46,19 @@ class Mlp(EmipModule):
         self.dwconv = DWConv(hidden_features)
         self.fc2 = nn.Linear(hidden_features, out_features)
 
+    def run_train(self, h, residual):
+        dt = self.cdtype
+        dw = self.dwconv.dwconv
+        (w1, w1t), (w2, w2t), wd, wdf = self.packed(
+            "mlp_t", (self.fc1.weight, self.fc2.weight, dw.weight),
+            lambda a, b, c: (_lin_packs(a, dt), _lin_packs(b, dt), pack_dw(c), pack_dw(c.detach().flip(2, 3))))
+        t = LinearFn.apply(h, self.fc1.weight, self.fc1.bias, None, w1, w1t)
+        t = DwConvFn.apply(t, dw.weight, dw.bias, wd, wdf, True)
+        return LinearFn.apply(t, self.fc2.weight, self.fc2.bias, residual, w2, w2t)
+
     def run(self, h, residual):
+        if torch.is_grad_enabled():
+            return self.run_train(h, residual)
         dt = self.cdtype
         w1, b1, wd, bd, w2, b2 = self.packed(
             "mlp", (self.fc1.weight, self.fc1.bias, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias,
@@ -59,8 +84,29 @@ class Attention(EmipModule):
             self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = nn.LayerNorm(dim)
 
+    def run_train(self, h, residual):
+        dt, C, heads, sr = self.cdtype, self.dim, self.num_heads, self.sr_ratio
+        B, H, W, _ = h.shape
+        (wq, wqt), (wkv, wkvt), (wp, wpt) = self.packed(
+            "lin_t", (self.q.weight, self.kv.weight, self.proj.weight),
+            lambda a, b, c: (_lin_packs(a, dt), _lin_packs(b, dt), _lin_packs(c, dt)))
+        q = LinearFn.apply(h, self.q.weight, self.q.bias, None, wq, wqt)
+        if sr > 1:
+            wsr, wsrd = self.packed("sr_t", (self.sr.weight,),
+                                    lambda a: (pack_conv(a, dt), _conv_dgrad_pack(a, dt, sr, sr, 0)))
+            s_ = ConvFn.apply(h, self.sr.weight, self.sr.bias, wsr, wsrd, sr, sr, 0, None)
+            s_ = LayerNormFn.apply(s_, self.norm.weight, self.norm.bias, self.norm.eps)
+        else:
+            s_ = h
+        Lk = s_.shape[1] * s_.shape[2]
+        kv = LinearFn.apply(s_, self.kv.weight, self.kv.bias, None, wkv, wkvt)
+        a = SraAttentionFn.apply(q.view(B, H * W, C), kv.view(B, Lk, 2 * C), heads, self.scale).view(B, H, W, C)
+        return LinearFn.apply(a, self.proj.weight, self.proj.bias, residual, wp, wpt)
+
     def run(self, h, residual):
         """h: normed tokens [B,H,W,C]; returns residual + proj(attn) written in place."""
+        if torch.is_grad_enabled():
+            return self.run_train(h, residual)
         dt, C, heads, sr = self.cdtype, self.dim, self.num_heads, self.sr_ratio
         B, H, W, _ = h.shape
         assert C // heads == 64, "the fused attention kernel is built for head_dim 64"
@@ -101,6 +147,9 @@ class Block(EmipModule):
     def run(self, x):
         if self.training and self.drop_path_rate > 0:
             raise NotImplementedError("stochastic depth (train mode) is not built yet; call .eval()")
+        if torch.is_grad_enabled():
+            x = self.attn.run(LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), x)
+            return self.mlp.run(LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x)
         g1, b1, g2, b2 = self.packed("ln", (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias),
                                      lambda a, b, c, d: (f32(a), f32(b), f32(c), f32(d)))
         x = self.attn.run(ops.layernorm(x, g1, b1, self.norm1.eps), x)
@@ -121,6 +170,12 @@ class OverlapPatchEmbed(EmipModule):
     def run(self, x):
         dt = self.cdtype
         cin = x.shape[-1]  # the image arrives with its 3 channels zero-padded to 8
+        if torch.is_grad_enabled():
+            k, st = self.patch_size, self.stride
+            wp, wdg = self.packed("pe_t", (self.proj.weight,),
+                                  lambda a: (pack_conv(a, dt, cin_pad=cin), _conv_dgrad_pack(a, dt, k, st, k // 2)))
+            y = ConvFn.apply(x, self.proj.weight, self.proj.bias, wp, wdg, k, st, k // 2, cin)
+            return LayerNormFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps)
         w, b, g, be = self.packed("pe", (self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias),
                                   lambda a, bb, c, d: (pack_conv(a, dt, cin_pad=cin), f32(bb), f32(c), f32(d)))
         y = ops.conv2d(x, w, self.patch_size, self.patch_size, self.stride, self.patch_size // 2, bias=b)
@@ -155,6 +210,10 @@ class PyramidVisionTransformerV2(EmipModule):
             for blk in getattr(self, f"block{i + 1}"):
                 x = blk.run(x)
             norm = getattr(self, f"norm{i + 1}")
+            if torch.is_grad_enabled():
+                x = LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+                outs.append(x)
+                continue
             g, b = self.packed(f"n{i}", (norm.weight, norm.bias), lambda a, c: (f32(a), f32(c)))
             x = ops.layernorm(x, g, b, norm.eps)
             outs.append(x)

@@ -412,3 +412,26 @@ def bilinear_planar_bwd(dy, H, W, align_corners, mul=1.0):
     _lib.call("emip_bilinear_planar_bwd", _p(dy.contiguous()), _p(dx), C, 0, B, H, W, C, Ho, Wo, int(align_corners),
               float(mul), _stream())
     return dx
+
+
+def zero_insert(dy, H, W, stride):
+    B, Ho, Wo, C = dy.shape
+    _, _, lddy = rows(dy)
+    z = torch.empty((B, H, W, C), dtype=dy.dtype, device=dy.device)
+    _lib.call("emip_zero_insert", _p(dy), lddy, _p(z), B, Ho, Wo, H, W, C, stride, dt_code(dy.dtype), _stream())
+    return z
+
+
+def depatchify(p, B, Ho, Wo, k, C):
+    assert p.is_contiguous()
+    dx = torch.empty((B, Ho * k, Wo * k, C), dtype=p.dtype, device=p.device)
+    _lib.call("emip_depatchify", _p(p), _p(dx), B, Ho, Wo, k, C, dt_code(p.dtype), _stream())
+    return dx
+
+
+def colsum(x):
+    """sum over rows of a channels-last tensor -> f32 [C]"""
+    M, C, ldx = rows(x)
+    out = torch.zeros(C, dtype=torch.float32, device=x.device)
+    _lib.call("emip_colsum", _p(x), ldx, _p(out), M, C, dt_code(x.dtype), _stream())
+    return out

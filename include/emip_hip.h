@@ -219,6 +219,15 @@ int emip_bilinear_bwd(const void* DY, long lddy, float* DX, int B, int H, int Wd
 int emip_bilinear_planar_bwd(const float* DY, float* DX, long ldx, int xc, int B, int H, int Wd, int C, int Ho, int Wo,
                              int align_corners, float mul, void* stream);
 
+/* Input-gradient helpers for strided convs: zero insertion (then the stride-1 conv with flipped/transposed weights is
+ * the transposed conv) and the un-patchify copy of non-overlapping patch convs (k == stride, pad 0: SRA's sr conv). */
+int emip_zero_insert(const void* DY, long lddy, void* Z, int B, int Ho, int Wo, int H, int Wd, int C, int stride,
+                     int dtype, void* stream);
+int emip_depatchify(const void* P, void* DX, int B, int Ho, int Wo, int k, int C, int dtype, void* stream);
+
+/* out[c] += sum over rows of X[row][c] (bias gradients); out is f32 [C], accumulated into. */
+int emip_colsum(const void* X, long ldx, float* out, long rows, int C, int dtype, void* stream);
+
 /* ---- optimizer ----------------------------------------------------------------------------------- */
 
 /* Element-wise gradient clamp to +-clip (utils/utils.py:1-11; clip <= 0 disables) fused with one AdamW step
