@@ -33,8 +33,10 @@ class LinearFn(Function):
     """y = x W^T + b (+ res).  wp: W packed [N,K] in the activation dtype, wpt: W^T packed [K,N]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, wp, wpt):
-        y = ops.gemm(x, wp, bias=bias, res=res)
+    def forward(ctx, x, weight, bias, res, wp, wpt, bpack=None):
+        # wp may carry zero-padded output rows (N padded to a multiple of 8: the 1-channel mask head); bpack is the
+        # matching padded bias
+        y = ops.gemm(x, wp, bias=bias if bpack is None else bpack, res=res)
         ctx.save_for_backward(x, weight)
         ctx.wpt, ctx.has_bias, ctx.has_res = wpt, bias is not None, res is not None
         return y
@@ -44,10 +46,14 @@ class LinearFn(Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = ops.gemm(dy, ctx.wpt) if ctx.needs_input_grad[0] else None
-        dw = ops.gemm_tn(dy, x).view_as(weight) if ctx.needs_input_grad[1] else None
-        db = colsum_f32(dy) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = None
+        if ctx.needs_input_grad[1]:
+            n = weight.shape[0]
+            kw = weight.numel() // n                      # x may carry zero-padded columns beyond the weight's K
+            dw = ops.gemm_tn(dy, x)[:n, :kw].contiguous().view_as(weight)
+        db = colsum_f32(dy)[:weight.shape[0]].contiguous() if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dres, None, None
+        return dx, dw, db, dres, None, None, None
 
 
 class ConvFn(Function):
@@ -174,3 +180,171 @@ class SraAttentionFn(Function):
             ops.copy_cols(dK.view(B * Lp, 64), 0, 64, dkv_pad.view(B * Lp, 2 * C), 64 * h)
             ops.copy_cols(dV.view(B * Lp, 64), 0, 64, dkv_pad.view(B * Lp, 2 * C), C + 64 * h)
         return dq, dkv_pad[:, :Lk].contiguous(), None, None
+
+
+class BNReluFn(Function):
+    """train-mode BatchNorm2d (+ReLU) on a conv output: batch statistics, running buffers updated by the caller."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, relu):
+        sums = ops.chan_stats(x, 1)
+        y = ops.chan_norm_apply(x, sums, 1, eps, relu_inner=relu, gamma=gamma, beta=beta)
+        ctx.save_for_backward(x, y, gamma, sums)
+        ctx.cfg = (eps, relu)
+        ctx.mark_non_differentiable(sums)
+        return y, sums
+
+    @staticmethod
+    def backward(ctx, dy, _dsums):
+        x, y, gamma, sums = ctx.saved_tensors
+        eps, relu = ctx.cfg
+        dg = torch.zeros_like(gamma)
+        db = torch.zeros_like(gamma)
+        dx = ops.bn_train_bwd(x, dy.contiguous(), y if relu else None, sums, gamma, dg, db, eps)
+        return dx, dg, db, None, None
+
+
+class BilinearFn(Function):
+    """channels-last bilinear resize (nn.Upsample x2, align_corners=True)"""
+
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, align):
+        ctx.cfg = (x.shape[1], x.shape[2], align, x.dtype)
+        return ops.bilinear(x, Ho, Wo, align)
+
+    @staticmethod
+    def backward(ctx, dy):
+        H, W, align, dt = ctx.cfg
+        return ops.bilinear_bwd(dy.contiguous(), H, W, align).to(dt), None, None, None
+
+
+class BilinearPlanarFn(Function):
+    """channels xc..xc+C of a channels-last tensor -> planar f32 [B,C,Ho,Wo] (x8 mask logits / train-mode flow)"""
+
+    @staticmethod
+    def forward(ctx, x, xc, C, Ho, Wo, align, mul):
+        ctx.cfg = (x.shape, xc, C, align, mul, x.dtype)
+        return ops.bilinear_planar(x, xc, C, Ho, Wo, align, mul)
+
+    @staticmethod
+    def backward(ctx, dy):
+        shape, xc, C, align, mul, dt = ctx.cfg
+        g = ops.bilinear_planar_bwd(dy.contiguous(), shape[1], shape[2], align, mul)       # f32 [B,H,W,C]
+        if shape[-1] == C and xc == 0:
+            return g.to(dt), None, None, None, None, None, None
+        dx = torch.zeros(shape, dtype=dt, device=dy.device)
+        ops.copy_cols(g, 0, C, dx, xc)
+        return dx, None, None, None, None, None, None
+
+
+class MulFn(Function):
+    """a * b (* c) elementwise"""
+
+    @staticmethod
+    def forward(ctx, a, b, c):
+        ctx.save_for_backward(a, b, c)
+        return ops.eltwise(a, b, 0) if c is None else ops.eltwise(a, b, 1, c3=c)
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, c = ctx.saved_tensors
+        dy = dy.contiguous()
+        if c is None:
+            return ops.eltwise(dy, b, 0), ops.eltwise(dy, a, 0), None
+        return ops.eltwise(dy, b, 1, c3=c), ops.eltwise(dy, a, 1, c3=c), ops.eltwise(dy, a, 1, c3=b)
+
+
+class ConcatFn(Function):
+    """channel concatenation of channels-last tensors (optionally zero-padded to cpad channels)"""
+
+    @staticmethod
+    def forward(ctx, cpad, *parts):
+        widths = [p.shape[-1] for p in parts]
+        total = sum(widths)
+        cpad = cpad or total
+        out = torch.empty(parts[0].shape[:-1] + (cpad,), dtype=parts[0].dtype, device=parts[0].device)
+        off = 0
+        for i, p in enumerate(parts):
+            last = i == len(parts) - 1
+            ops.copy_cols(p, 0, widths[i], out, off, (cpad - off) if last else widths[i])
+            off += widths[i]
+        ctx.widths = widths
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        grads, off = [], 0
+        for w in ctx.widths:
+            g = torch.empty(dy.shape[:-1] + (w,), dtype=dy.dtype, device=dy.device)
+            ops.copy_cols(dy, off, w, g, 0)
+            grads.append(g)
+            off += w
+        return (None,) + tuple(grads)
+
+
+class GateFn(Function):
+    """y = gelu(z[:, :Ch]) * z[:, Ch:], zero-padded to cpad channels"""
+
+    @staticmethod
+    def forward(ctx, z, ch, cpad):
+        ctx.save_for_backward(z)
+        ctx.ch = ch
+        return ops.gate_fwd(z, ch, cpad)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (z,) = ctx.saved_tensors
+        return ops.gate_bwd(z, dy.contiguous(), ctx.ch), None, None
+
+
+class MdtaFn(Function):
+    """channel attention of the MDTA block: out[p, c1] = sum_c2 softmax(qhat^T khat * tau)[c1, c2] v[p, c2]
+    q [B,h,w,128], kv [B,h,w,256] (k | v), temperature [heads,1,1]"""
+
+    @staticmethod
+    def forward(ctx, q, kv, temperature):
+        B, h, w, C = q.shape
+        P, heads = h * w, C // 64
+        temp = temperature.detach().reshape(-1).contiguous()
+        ws, attn = ops.mdta_attn_ws(q.view(B, P, C), kv.view(B, P, 2 * C)[..., :C], temp, B, heads, P)
+        o = torch.empty_like(q)
+        for hd in range(heads):
+            ops.gemm_batched(kv.view(B, P, 2 * C)[..., C + 64 * hd:], attn[:, hd], o.view(B, P, C)[..., 64 * hd:],
+                             batch=B, M=P, N=64, K=64, lda=2 * C, ldw=64, ldc=C, bsA=P * 2 * C, bsW=heads * 4096,
+                             bsC=P * C)
+        ctx.save_for_backward(q, kv, temperature, ws, attn)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, kv, temperature, ws, attn = ctx.saved_tensors
+        do = do.contiguous()
+        B, h, w, C = q.shape
+        P, heads = h * w, C // 64
+        q3, kv3, do3 = q.view(B, P, C), kv.view(B, P, 2 * C), do.view(B, P, C)
+        temp = temperature.detach().reshape(-1).contiguous()
+        dA = torch.empty((B, heads, 64, 64), dtype=torch.float32, device=q.device)
+        for hd in range(heads):       # dA[c1,c2] = sum_p do[p,c1] v[p,c2]
+            dA[:, hd] = ops.gemm_tn_batched(do3[..., 64 * hd:], kv3[..., C + 64 * hd:], B, P, 64, 64, C, 2 * C, P * C,
+                                            P * 2 * C)
+        dG, dGT, sq, sk, dtau = ops.mdta_bwd_small(ws, temp, attn, dA, B, heads)
+        dq = torch.empty_like(q)
+        dkv = torch.empty_like(kv)
+        dq3, dkv3 = dq.view(B, P, C), dkv.view(B, P, 2 * C)
+        for hd in range(heads):
+            qh, kh = q3[..., 64 * hd:64 * hd + 64], kv3[..., 64 * hd:64 * hd + 64]
+            attnT = ops.transpose_pad(attn[:, hd], 64)                                          # [B,64(c2),64(c1)]
+            # dV[p,c2] = sum_c1 do[p,c1] A[c1,c2]
+            ops.gemm_batched(do3[..., 64 * hd:], attnT, dkv3[..., C + 64 * hd:], B, P, 64, 64, C, 64, 2 * C, P * C,
+                             4096, P * 2 * C)
+            # dQ[p,c1] = sum_c2 dG[c1,c2] K[p,c2] + sq[c1] Q[p,c1]
+            ops.gemm_batched(kh, dG[:, hd], dq3[..., 64 * hd:], B, P, 64, 64, 2 * C, 64, C, P * 2 * C, heads * 4096,
+                             P * C)
+            ops.colscale_add(dq3[..., 64 * hd:64 * hd + 64], qh, sq[:, hd], heads * 64, P,
+                             dq3[..., 64 * hd:64 * hd + 64])
+            # dK[p,c2] = sum_c1 dG[c1,c2] Q[p,c1] + sk[c2] K[p,c2]
+            ops.gemm_batched(qh, dGT[:, hd], dkv3[..., 64 * hd:], B, P, 64, 64, C, 64, 2 * C, P * C, heads * 4096,
+                             P * 2 * C)
+            ops.colscale_add(dkv3[..., 64 * hd:64 * hd + 64], kh, sk[:, hd], heads * 64, P,
+                             dkv3[..., 64 * hd:64 * hd + 64])
+        return dq, dkv, dtau.view_as(temperature)

@@ -594,3 +594,164 @@ extern "C" int emip_colsum(const void* X, long ldx, float* out, long rows, int C
                                          (const T*)X, ldx, out, rows, C, rpb));
     return emip_launch_status();
 }
+
+// ---- gated GELU (GDFN of the MDTA block): y = gelu(z[:, :Ch]) * z[:, Ch:2Ch] ----------------------------------------
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const T* __restrict__ Z, long ldz, T* __restrict__ Y, long ldy,
+                                                       long M, int Ch, int Cpad) {
+    const int nv = Cpad >> 2;
+    const long total = M * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % nv) * 4;
+        const long r = idx / nv;
+        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        if (c < Ch) {
+            float a[4], b[4];
+            Vec4<T>::load(Z + r * ldz + c, a);
+            Vec4<T>::load(Z + r * ldz + Ch + c, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = gelu_erf(a[j]) * b[j];
+        }
+        Vec4<T>::store(Y + r * ldy + c, o);
+    }
+}
+// dz[:, :Ch] = dy * z2 * gelu'(z1);  dz[:, Ch:] = dy * gelu(z1)
+template <typename T>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const T* __restrict__ Z, long ldz, const T* __restrict__ DY,
+                                                       long lddy, T* __restrict__ DZ, long lddz, long M, int Ch) {
+    const int nv = Ch >> 2;
+    const long total = M * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % nv) * 4;
+        const long r = idx / nv;
+        float a[4], b[4], g[4], d1[4], d2[4];
+        Vec4<T>::load(Z + r * ldz + c, a);
+        Vec4<T>::load(Z + r * ldz + Ch + c, b);
+        Vec4<T>::load(DY + r * lddy + c, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float cdf = 0.5f * (1.f + erff(a[j] * 0.70710678118654752440f));
+            const float pdf = 0.3989422804014327f * expf(-0.5f * a[j] * a[j]);
+            d1[j] = g[j] * b[j] * (cdf + a[j] * pdf);
+            d2[j] = g[j] * a[j] * cdf;
+        }
+        Vec4<T>::store(DZ + r * lddz + c, d1);
+        Vec4<T>::store(DZ + r * lddz + Ch + c, d2);
+    }
+}
+// Y[r][c] = A[r][c] + s[(r / rows_per_group)][c] * B[r][c]      (column-scaled add, s f32)
+template <typename T>
+__global__ __launch_bounds__(256) void colscale_add_kernel(const T* __restrict__ A, long lda, const T* __restrict__ Bp,
+                                                           long ldb, const float* __restrict__ S, long lds,
+                                                           T* __restrict__ Y, long ldy, long M, int C,
+                                                           long rows_per_group) {
+    const int nv = C >> 2;
+    const long total = M * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % nv) * 4;
+        const long r = idx / nv;
+        const float* s = S + (r / rows_per_group) * lds + c;
+        float a[4], b[4], o[4];
+        Vec4<T>::load(A + r * lda + c, a);
+        Vec4<T>::load(Bp + r * ldb + c, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = fmaf(s[j], b[j], a[j]);
+        Vec4<T>::store(Y + r * ldy + c, o);
+    }
+}
+}  // namespace
+
+extern "C" int emip_gate_fwd(const void* Z, long ldz, void* Y, long ldy, long M, int Ch, int Cpad, int dtype,
+                             void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(Z && Y && M > 0 && Ch >= 4 && (Ch & 3) == 0 && (Cpad & 3) == 0 && Cpad >= Ch && (ldz & 3) == 0 &&
+                 (ldy & 3) == 0 && ldz >= 2 * Ch && ldy >= Cpad);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gate_fwd_kernel<T>, dim3(grid_for(M * (Cpad >> 2), 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)Z, ldz, (T*)Y, ldy, M, Ch, Cpad));
+    return emip_launch_status();
+}
+
+extern "C" int emip_gate_bwd(const void* Z, long ldz, const void* DY, long lddy, void* DZ, long lddz, long M, int Ch,
+                             int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(Z && DY && DZ && M > 0 && Ch >= 4 && (Ch & 3) == 0 && (ldz & 3) == 0 && (lddy & 3) == 0 &&
+                 (lddz & 3) == 0 && ldz >= 2 * Ch && lddz >= 2 * Ch && lddy >= Ch);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(gate_bwd_kernel<T>, dim3(grid_for(M * (Ch >> 2), 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)Z, ldz, (const T*)DY, lddy, (T*)DZ, lddz, M, Ch));
+    return emip_launch_status();
+}
+
+extern "C" int emip_colscale_add(const void* A, long lda, const void* Bp, long ldb, const float* S, long lds, void* Y,
+                                 long ldy, long M, int C, long rows_per_group, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(A && Bp && S && Y && M > 0 && C >= 4 && (C & 3) == 0 && rows_per_group > 0 && (lda & 3) == 0 &&
+                 (ldb & 3) == 0 && (ldy & 3) == 0 && lda >= C && ldb >= C && ldy >= C);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(colscale_add_kernel<T>, dim3(grid_for(M * (C >> 2), 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)A, lda, (const T*)Bp, ldb, S, lds, (T*)Y, ldy, M,
+                                         C, rows_per_group));
+    return emip_launch_status();
+}
+
+// ---- MDTA channel attention backward, small-matrix part ----------------------------------------------------------------
+// per (b, head): inputs G (raw Gram f32 [64][64]), nq, nk (sums of squares f32 [64]), temperature, A (softmax, T),
+// dA (f32 [64][64]).  outputs: dGraw (T [64][64]) = dGhat * tau / (|q||k|), dGrawT (its transpose),
+// sq[c] = dnq[c] / |q_c| and sk[c] (f32, the column scales of the normalisation terms), dtau[head] += sum dGhat*Ghat/tau.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(64) void mdta_bwd_small_kernel(const float* __restrict__ G, const float* __restrict__ nq2,
+                                                            const float* __restrict__ nk2,
+                                                            const float* __restrict__ temperature,
+                                                            const T* __restrict__ A, const float* __restrict__ dA,
+                                                            T* __restrict__ dG, T* __restrict__ dGT,
+                                                            float* __restrict__ sq, float* __restrict__ sk,
+                                                            float* __restrict__ dtau, int heads) {
+    __shared__ float sdg[64][65];    // dGhat * Ghat  (for the column sums) then dGraw
+    const long bh = blockIdx.x;
+    const int head = (int)(bh % heads);
+    const int c1 = threadIdx.x;
+    const float tau = temperature[head];
+    const float qn = fmaxf(sqrtf(nq2[bh * 64 + c1]), 1e-12f);
+    float a[64], dgh[64];
+    float dot = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 64; ++c2) {
+        a[c2] = to_f32<T>(A[(bh * 64 + c1) * 64 + c2]);
+        dot += a[c2] * dA[(bh * 64 + c1) * 64 + c2];
+    }
+    float rowsum = 0.f, tsum = 0.f;
+#pragma unroll
+    for (int c2 = 0; c2 < 64; ++c2) {
+        const float kn = fmaxf(sqrtf(nk2[bh * 64 + c2]), 1e-12f);
+        dgh[c2] = a[c2] * (dA[(bh * 64 + c1) * 64 + c2] - dot);                 // d Ghat
+        const float gn = G[(bh * 64 + c1) * 64 + c2] / (qn * kn);               // Ghat / tau
+        const float ghat = gn * tau;
+        rowsum += dgh[c2] * ghat;
+        tsum += dgh[c2] * gn;
+        sdg[c1][c2] = dgh[c2] * ghat;
+        const float draw = dgh[c2] * tau / (qn * kn);
+        dG[(bh * 64 + c1) * 64 + c2] = from_f32<T>(draw);
+        dGT[(bh * 64 + c2) * 64 + c1] = from_f32<T>(draw);
+    }
+    // d|q_c1| = -rowsum / |q_c1|; the Q update is dnq * Q / |q| -> column scale sq = -rowsum / |q|^2 (0 when clamped)
+    sq[bh * 64 + c1] = sqrtf(nq2[bh * 64 + c1]) > 1e-12f ? -rowsum / (qn * qn) : 0.f;
+    atomicAdd(dtau + head, tsum);
+    __syncthreads();
+    float colsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 64; ++r) colsum += sdg[r][c1];
+    const float kn1 = fmaxf(sqrtf(nk2[bh * 64 + c1]), 1e-12f);
+    sk[bh * 64 + c1] = sqrtf(nk2[bh * 64 + c1]) > 1e-12f ? -colsum / (kn1 * kn1) : 0.f;
+}
+}  // namespace
+
+extern "C" int emip_mdta_bwd_small(const float* G, const float* nq2, const float* nk2, const float* temperature,
+                                   const void* A, const float* dA, void* dG, void* dGT, float* sq, float* sk,
+                                   float* dtau, int B, int heads, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(G && nq2 && nk2 && temperature && A && dA && dG && dGT && sq && sk && dtau && B > 0 && heads > 0);
+    const unsigned nbh = (unsigned)B * heads;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(mdta_bwd_small_kernel<T>, dim3(nbh), dim3(64), 0, (hipStream_t)stream, G, nq2,
+                                         nk2, temperature, (const T*)A, dA, (T*)dG, (T*)dGT, sq, sk, dtau, heads));
+    return emip_launch_status();
+}

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
+from ...autograd import BilinearFn, BilinearPlanarFn, BNReluFn, ConcatFn, ConvFn, LinearFn, MulFn
 from ...nn_base import EmipModule, f32, fold_bn, pack_conv, to_cl, to_planar
 
 
@@ -26,6 +27,11 @@ class ConvBR(EmipModule):
 
     def run(self, x, out=None):
         dt = self.cdtype
+        if torch.is_grad_enabled():
+            y = conv_bn_relu_autograd(self, self.conv, self.bn, x, self.k, self.s, self.p)
+            if out is not None:
+                raise RuntimeError("in-place concat outputs are an inference-only optimisation")
+            return y
         if self.training:
             return conv_bn_train(self, self.conv, self.bn, x, self.k, self.s, self.p, out=out)
         w, b = self.packed("w", (self.conv.weight, self.bn.weight, self.bn.bias, self.bn.running_mean,
@@ -55,6 +61,29 @@ def conv_bn_train(owner, conv, bn, x, k, s, p, out=None, relu=True):
         bn.running_var.mul_(1 - m).add_((var * n / max(n - 1, 1)).float() * m)
         bn.num_batches_tracked.add_(1)
     return ops.chan_norm_apply(y, sums, 1, bn.eps, relu_inner=relu, gamma=g, beta=be, out=out if out is not None else y)
+
+
+def _update_running_stats(bn, sums, n):
+    with torch.no_grad():
+        mean = sums[0, :, 0] / n
+        var = (sums[0, :, 1] / n - mean * mean).clamp_min(0)
+        m = bn.momentum
+        bn.running_mean.mul_(1 - m).add_(mean.float() * m)
+        bn.running_var.mul_(1 - m).add_((var * n / max(n - 1, 1)).float() * m)
+        bn.num_batches_tracked.add_(1)
+
+
+def conv_bn_relu_autograd(owner, conv, bn, x, k, s, p, relu=True):
+    """differentiable conv + BatchNorm (batch statistics in train mode, running statistics in eval mode) + ReLU"""
+    dt = owner.cdtype
+    wp, wdg = owner.packed("wag", (conv.weight,), lambda cw: (
+        pack_conv(cw, dt), pack_conv(cw.detach().flip(2, 3).permute(1, 0, 2, 3), dt)))
+    y = ConvFn.apply(x, conv.weight, conv.bias, wp, wdg, k, s, p, None)
+    if not owner.training:
+        raise NotImplementedError("gradients through eval-mode BatchNorm are not built (train.py always calls .train())")
+    y, sums = BNReluFn.apply(y, bn.weight, bn.bias, bn.eps, relu)
+    _update_running_stats(bn, sums, y.shape[0] * y.shape[1] * y.shape[2])
+    return y
 
 
 class DimensionalReduction(EmipModule):
@@ -93,8 +122,32 @@ class NeighborConnectionDecoder(EmipModule):
     def _up2(x):
         return ops.bilinear(x, 2 * x.shape[1], 2 * x.shape[2], True)
 
+    def run_train(self, zt5, zt4, zt3):
+        dt = self.cdtype
+        up = lambda t: BilinearFn.apply(t, 2 * t.shape[1], 2 * t.shape[2], True)
+        up5, up4 = up(zt5), up(zt4)
+        zt4_1 = MulFn.apply(self.conv_upsample1.run(up5), zt4, None)
+        zt3_1 = MulFn.apply(self.conv_upsample2.run(up(zt4_1)), self.conv_upsample3.run(up4), zt3)
+        zt4_2 = self.conv_concat2.run(ConcatFn.apply(None, zt4_1, self.conv_upsample4.run(up5)))
+        zt3_2 = self.conv_concat3.run(ConcatFn.apply(None, zt3_1, self.conv_upsample5.run(up(zt4_2))))
+        x = self.conv4.run(zt3_2)
+        w5 = self.conv5.weight
+        # the 1x1 head has N = 1: pad it to 8 output channels so that the backward GEMMs keep 16-byte rows
+        def build(a, b):
+            w8 = torch.zeros(8, a.shape[1], device=a.device)
+            w8[0] = a.detach().reshape(-1)
+            b8 = torch.zeros(8, device=a.device)
+            b8[0] = b.detach()[0]
+            return w8.to(dt).contiguous(), w8.t().to(dt).contiguous(), b8
+        wp, wpt, b8 = self.packed("c5t", (w5, self.conv5.bias), build)
+        pc = LinearFn.apply(x, w5, self.conv5.bias, None, wp, wpt, b8)          # [B,44,44,8], channel 0 = logits
+        self.last_pc = pc
+        return BilinearPlanarFn.apply(pc, 0, 1, 8 * pc.shape[1], 8 * pc.shape[2], False, 1.0)
+
     def run(self, zt5, zt4, zt3):
         """channels-last inputs [B,11,11,c], [B,22,22,c], [B,44,44,c] -> planar f32 logits [B,1,352,352]"""
+        if torch.is_grad_enabled():
+            return self.run_train(zt5, zt4, zt3)
         dt, c = self.cdtype, self.channel
         B = zt5.shape[0]
         up5, up4 = self._up2(zt5), self._up2(zt4)

@@ -60,6 +60,13 @@ class CoUpdater(EmipModule):
         x = corr.view(B, h, w, n)
         c0, bn, c3 = self.conv_corr[0], self.conv_corr[1], self.conv_corr[3]
         w3, b3 = self.packed("cc3", (c3.weight, c3.bias), lambda a, b: (pack_conv(a, dt), f32(b)))
+        if torch.is_grad_enabled():
+            from ...autograd import ConvFn
+            from .create_backbone import conv_bn_relu_autograd
+            y = conv_bn_relu_autograd(self, c0, bn, x, 3, 1, 1)
+            w3p, w3d = self.packed("cc3t", (c3.weight,), lambda a: (
+                pack_conv(a, dt), pack_conv(a.detach().flip(2, 3).permute(1, 0, 2, 3), dt)))
+            return ConvFn.apply(y, c3.weight, c3.bias, w3p, w3d, 3, 1, 1, None)
         if self.training:
             y = conv_bn_train(self, c0, bn, x, 3, 1, 1)
         else:

@@ -15,6 +15,7 @@ import torch
 import torch.nn as nn
 
 from .... import ops
+from ....autograd import DwConvFn, GateFn, LayerNormFn, LinearFn, MdtaFn
 from ....nn_base import EmipModule, f32, pack_dw, pack_linear, to_cl, to_planar
 
 
@@ -89,8 +90,44 @@ class TransformerBlock_MDTA(EmipModule):
                                  a.project_out.weight, f.project_in.weight, f.dwconv.weight, f.project_out.weight),
                            build)
 
+    def run_train(self, x, y):
+        dt = self.cdtype
+        a, f = self.attn, self.ffn
+        hid = f.hidden
+        hid_pad = (hid + 7) // 8 * 8
+
+        def lin(wt):
+            w2 = wt.detach().reshape(wt.shape[0], -1)
+            return pack_linear(w2, dt), w2.t().to(dt).contiguous()
+
+        def build(q, qd, kv, kvd, po, pin, dw, pout):
+            wo = pout.detach().float().reshape(pout.shape[0], hid)
+            wo = torch.cat([wo, wo.new_zeros(wo.shape[0], hid_pad - hid)], 1)
+            return dict(q=lin(q), kv=lin(kv), po=lin(po), pin=lin(pin),
+                        pout=(wo.to(dt).contiguous(), wo.t().to(dt).contiguous()),
+                        qd=(pack_dw(qd), pack_dw(qd.detach().flip(2, 3))),
+                        kvd=(pack_dw(kvd), pack_dw(kvd.detach().flip(2, 3))),
+                        dw=(pack_dw(dw), pack_dw(dw.detach().flip(2, 3))))
+        w = self.packed("wt", (a.q.weight, a.q_dwconv.weight, a.kv.weight, a.kv_dwconv.weight, a.project_out.weight,
+                               f.project_in.weight, f.dwconv.weight, f.project_out.weight), build)
+        n1, n2, n3 = self.norm1.body, self.norm2.body, self.norm3.body
+        xn = LayerNormFn.apply(x, n1.weight, n1.bias, 1e-5)
+        yn = LayerNormFn.apply(y, n2.weight, n2.bias, 1e-5)
+        q = LinearFn.apply(xn, a.q.weight, None, None, *w["q"])
+        q = DwConvFn.apply(q, a.q_dwconv.weight, None, w["qd"][0], w["qd"][1], False)
+        kv = LinearFn.apply(yn, a.kv.weight, None, None, *w["kv"])
+        kv = DwConvFn.apply(kv, a.kv_dwconv.weight, None, w["kvd"][0], w["kvd"][1], False)
+        o = MdtaFn.apply(q, kv, a.temperature)
+        x1 = LinearFn.apply(o, a.project_out.weight, None, x, *w["po"])
+        t = LinearFn.apply(LayerNormFn.apply(x1, n3.weight, n3.bias, 1e-5), f.project_in.weight, None, None, *w["pin"])
+        t = DwConvFn.apply(t, f.dwconv.weight, None, w["dw"][0], w["dw"][1], False)
+        t = GateFn.apply(t, hid, hid_pad)
+        return LinearFn.apply(t, f.project_out.weight, None, x1, *w["pout"])
+
     def run(self, x, y):
         """x, y: channels-last [B,h,w,C]; returns a new tensor x + attn(x, y) + ffn(...)"""
+        if torch.is_grad_enabled():
+            return self.run_train(x, y)
         w = self._weights()
         B, h, wd, C = x.shape
         P, heads = h * wd, self.heads

@@ -435,3 +435,51 @@ def colsum(x):
     out = torch.zeros(C, dtype=torch.float32, device=x.device)
     _lib.call("emip_colsum", _p(x), ldx, _p(out), M, C, dt_code(x.dtype), _stream())
     return out
+
+
+def gate_fwd(z, ch, cpad):
+    M, _, ldz = rows(z)
+    y = torch.empty(z.shape[:-1] + (cpad,), dtype=z.dtype, device=z.device)
+    _lib.call("emip_gate_fwd", _p(z), ldz, _p(y), cpad, M, ch, cpad, dt_code(z.dtype), _stream())
+    return y
+
+
+def gate_bwd(z, dy, ch):
+    M, _, ldz = rows(z)
+    _, _, lddy = rows(dy)
+    dz = torch.empty(z.shape, dtype=z.dtype, device=z.device)
+    _lib.call("emip_gate_bwd", _p(z), ldz, _p(dy), lddy, _p(dz), z.shape[-1], M, ch, dt_code(z.dtype), _stream())
+    return dz
+
+
+def colscale_add(a, b, s, lds, rows_per_group, out):
+    """out[r, c] = a[r, c] + s[r // rows_per_group, c] * b[r, c]"""
+    M, C, lda = rows(a)
+    _, _, ldb = rows(b)
+    _, _, ldy = rows(out)
+    _lib.call("emip_colscale_add", _p(a), lda, _p(b), ldb, _p(s), lds, _p(out), ldy, M, C, rows_per_group,
+              dt_code(a.dtype), _stream())
+    return out
+
+
+def mdta_attn_ws(q, kv_k, temperature, B, heads, P):
+    """like mdta_attn, also returning the f32 workspace [G | nq^2 | nk^2] the backward needs"""
+    _dev(q)
+    ws = torch.empty(B * heads * (4096 + 128), dtype=torch.float32, device=q.device)
+    attn = torch.empty((B, heads, 64, 64), dtype=q.dtype, device=q.device)
+    _lib.call("emip_mdta_attn", _p(q), q.stride(-2), q.stride(0), _p(kv_k), kv_k.stride(-2), kv_k.stride(0),
+              _p(temperature), _p(ws), _p(attn), B, heads, P, dt_code(q.dtype), _stream())
+    return ws, attn
+
+
+def mdta_bwd_small(ws, temperature, attn, dA, B, heads):
+    nbh = B * heads
+    G, nq2, nk2 = ws[:nbh * 4096], ws[nbh * 4096:nbh * 4096 + nbh * 64], ws[nbh * 4096 + nbh * 64:]
+    dG = torch.empty_like(attn)
+    dGT = torch.empty_like(attn)
+    sq = torch.empty((B, heads, 64), dtype=torch.float32, device=attn.device)
+    sk = torch.empty((B, heads, 64), dtype=torch.float32, device=attn.device)
+    dtau = torch.zeros(heads, dtype=torch.float32, device=attn.device)
+    _lib.call("emip_mdta_bwd_small", _p(G), _p(nq2), _p(nk2), _p(temperature), _p(attn), _p(dA), _p(dG), _p(dGT),
+              _p(sq), _p(sk), _p(dtau), B, heads, dt_code(attn.dtype), _stream())
+    return dG, dGT, sq, sk, dtau

@@ -225,6 +225,18 @@ int emip_zero_insert(const void* DY, long lddy, void* Z, int B, int Ho, int Wo, 
                      int dtype, void* stream);
 int emip_depatchify(const void* P, void* DX, int B, int Ho, int Wo, int k, int C, int dtype, void* stream);
 
+/* Gated GELU of the MDTA feed-forward (PromptInteract.py:383): y = gelu(z[:, :Ch]) * z[:, Ch:2Ch] (zero for
+ * Ch <= c < Cpad) and its backward; column-scaled add Y = A + S[group][c] * B (normalisation terms of the MDTA
+ * backward); the 64x64 part of the MDTA channel-attention backward. */
+int emip_gate_fwd(const void* Z, long ldz, void* Y, long ldy, long M, int Ch, int Cpad, int dtype, void* stream);
+int emip_gate_bwd(const void* Z, long ldz, const void* DY, long lddy, void* DZ, long lddz, long M, int Ch, int dtype,
+                  void* stream);
+int emip_colscale_add(const void* A, long lda, const void* Bp, long ldb, const float* S, long lds, void* Y, long ldy,
+                      long M, int C, long rows_per_group, int dtype, void* stream);
+int emip_mdta_bwd_small(const float* G, const float* nq2, const float* nk2, const float* temperature, const void* A,
+                        const float* dA, void* dG, void* dGT, float* sq, float* sk, float* dtau, int B, int heads,
+                        int dtype, void* stream);
+
 /* out[c] += sum over rows of X[row][c] (bias gradients); out is f32 [C], accumulated into. */
 int emip_colsum(const void* X, long ldx, float* out, long rows, int C, int dtype, void* stream);
 
