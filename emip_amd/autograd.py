@@ -348,3 +348,41 @@ class MdtaFn(Function):
             ops.colscale_add(dkv3[..., 64 * hd:64 * hd + 64], kh, sk[:, hd], heads * 64, P,
                              dkv3[..., 64 * hd:64 * hd + 64])
         return dq, dkv, dtau.view_as(temperature)
+
+
+class HybridELossFn(Function):
+    """hybrid_e_loss (loss/loss_pred.py:4-22) -> f32 [1]; gradient w.r.t. the logits only."""
+
+    @staticmethod
+    def forward(ctx, pred, mask):
+        pred, mask = pred.contiguous(), mask.contiguous()
+        out, ws = ops.hybrid_e_loss_fwd_ws(pred, mask)
+        ctx.save_for_backward(pred, mask, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, mask, ws = ctx.saved_tensors
+        return ops.hybrid_e_loss_bwd(pred, mask, ws, g.contiguous().float()), None
+
+
+class UnflowPairLossFn(Function):
+    """0.5 * (photometric(im1, warp(im2, fw), m1) + photometric(im2, warp(im1, bw), m2)) (loss_flow.py:96-131) -> f32 [1];
+    gradient w.r.t. the two flows through the warps (the occlusion masks are thresholded, hence constant)."""
+
+    @staticmethod
+    def forward(ctx, fw, bw, im1, im2, m1, m2):
+        r1, r2 = ops.flow_warp(im2, fw), ops.flow_warp(im1, bw)
+        out = torch.empty(1, dtype=torch.float32, device=fw.device)
+        ws1 = ops.photometric_loss_ws(im1, r1, m1, out, 0.5, False)
+        ws2 = ops.photometric_loss_ws(im2, r2, m2, out, 0.5, True)
+        ctx.save_for_backward(fw, bw, im1, im2, m1, m2, r1, r2, ws1, ws2)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        fw, bw, im1, im2, m1, m2, r1, r2, ws1, ws2 = ctx.saved_tensors
+        g = g.contiguous().float()
+        d1 = ops.photometric_loss_bwd(im1, r1, m1, ws1, g, 0.5)
+        d2 = ops.photometric_loss_bwd(im2, r2, m2, ws2, g, 0.5)
+        return ops.flow_warp_bwd(im2, fw, d1), ops.flow_warp_bwd(im1, bw, d2), None, None, None, None

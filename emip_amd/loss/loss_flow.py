@@ -1,4 +1,4 @@
-"""unFlowLoss (forward) on MI355X: /root/reference/loss/loss_flow.py:60-138.
+"""unFlowLoss on MI355X: /root/reference/loss/loss_flow.py:60-138.
 
 total = sum over the flow pyramid (w_scales = 1) of 0.5 * (photometric(im1, warp(im2, fw), 1-occ1) +
 photometric(im2, warp(im1, bw), 1-occ2)); occlusion masks come from the backward flows of scale 0 and are
@@ -7,6 +7,7 @@ At 352x352 the 'area' resize of the images and the 'nearest' resize of the masks
 import torch
 
 from .. import ops
+from ..autograd import UnflowPairLossFn
 
 
 class unFlowLoss(torch.nn.Module):
@@ -18,11 +19,14 @@ class unFlowLoss(torch.nn.Module):
         for i, flow in enumerate(flows):
             assert flow.shape[-2:] == im1.shape[-2:], "only the full-resolution pyramid of EMIP is built"
             fw, bw = flow[:, :2].contiguous(), flow[:, 2:].contiguous()
+            if i == 0:
+                m1 = ops.occ_mask_backward(bw.detach(), complement=True)       # 1 - occlusion(backward flow)
+                m2 = ops.occ_mask_backward(fw.detach(), complement=True)
+            if torch.is_grad_enabled() and flow.requires_grad:
+                total = total + UnflowPairLossFn.apply(fw, bw, im1, im2, m1, m2)
+                continue
             r1 = ops.flow_warp(im2, fw)
             r2 = ops.flow_warp(im1, bw)
-            if i == 0:
-                m1 = ops.occ_mask_backward(bw, complement=True)       # 1 - occlusion(backward flow)
-                m2 = ops.occ_mask_backward(fw, complement=True)
             ops.photometric_loss(im1, r1, m1, total, weight=0.5, accumulate=True)
             ops.photometric_loss(im2, r2, m2, total, weight=0.5, accumulate=True)
         return total[0], total[0], 0.0, flows[0].abs().mean()

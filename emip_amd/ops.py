@@ -483,3 +483,82 @@ def mdta_bwd_small(ws, temperature, attn, dA, B, heads):
     _lib.call("emip_mdta_bwd_small", _p(G), _p(nq2), _p(nk2), _p(temperature), _p(attn), _p(dA), _p(dG), _p(dGT),
               _p(sq), _p(sk), _p(dtau), B, heads, dt_code(attn.dtype), _stream())
     return dG, dGT, sq, sk, dtau
+
+
+def window_rows(src, table, B, nwin, L, n, C, scatter=False, dst=None):
+    """gather [B, n, C] -> [B*nwin, L, C] through table [nwin, L] (scatter: the inverse, into dst [B, n, C])"""
+    _dev(src)
+    if not scatter:
+        dst = torch.empty((B * nwin, L, C), dtype=src.dtype, device=src.device)
+    else:
+        assert dst is not None
+    _lib.call("emip_window_rows", _p(src), _p(dst), _p(table), B, nwin, L, n, C, C, C, int(scatter),
+              dt_code(src.dtype), _stream())
+    return dst
+
+
+def act_fwd(x, act):
+    M, C, ldx = rows(x)
+    y = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _lib.call("emip_act_fwd", _p(x), ldx, _p(y), C, M, C, act, dt_code(x.dtype), _stream())
+    return y
+
+
+def relu_bwd(y, dy):
+    M, C, ldy = rows(y)
+    _, _, lddy = rows(dy)
+    dx = torch.empty(y.shape, dtype=y.dtype, device=y.device)
+    _lib.call("emip_relu_bwd", _p(y), ldy, _p(dy), lddy, _p(dx), C, M, C, dt_code(y.dtype), _stream())
+    return dx
+
+
+def convex_upsample_bwd(logits, flow, dY):
+    """logits [N,H,W,576+], flow f32 [N,H,W,2], dY planar f32 [N,2,8H,8W] -> (dlogits like logits[..., :576], dflow)"""
+    N, H, W = flow.shape[:3]
+    _, _, ldl = rows(logits)
+    dl = torch.empty((N, H, W, 576), dtype=logits.dtype, device=logits.device)
+    df = torch.empty_like(flow)
+    _lib.call("emip_convex_upsample_bwd", _p(logits), ldl, _p(flow), _p(dY), _p(dl), 576, _p(df), N, H, W,
+              dt_code(logits.dtype), _stream())
+    return dl, df
+
+
+def hybrid_e_loss_fwd_ws(pred, mask):
+    B, _, H, W = pred.shape
+    ws = torch.empty((B, 8), dtype=torch.float64, device=pred.device)
+    out = torch.empty(1, dtype=torch.float32, device=pred.device)
+    _lib.call("emip_hybrid_e_loss", _p(pred), _p(mask), _p(ws), _p(out), B, H, W, _stream())
+    return out, ws
+
+
+def hybrid_e_loss_bwd(pred, mask, ws, gout):
+    B, _, H, W = pred.shape
+    dp = torch.empty_like(pred)
+    _lib.call("emip_hybrid_e_loss_bwd", _p(pred), _p(mask), _p(ws), _p(gout), _p(dp), B, H, W, _stream())
+    return dp
+
+
+def photometric_loss_ws(im, rec, mask, out, weight, accumulate):
+    B, C, H, W = im.shape
+    ws = torch.empty(4, dtype=torch.float64, device=im.device)
+    _lib.call("emip_photometric_loss", _p(im), _p(rec), _p(mask), _p(ws), _p(out), B, C, H, W, float(weight),
+              int(accumulate), _stream())
+    return ws
+
+
+def photometric_loss_bwd(im, rec, mask, ws, gout, weight, drec=None):
+    B, C, H, W = im.shape
+    abc = torch.empty((B * C * H * W * 3,), dtype=torch.float32, device=im.device)
+    acc = drec is not None
+    if drec is None:
+        drec = torch.empty_like(rec)
+    _lib.call("emip_photometric_loss_bwd", _p(im), _p(rec), _p(mask), _p(ws), _p(abc), _p(gout), _p(drec), B, C, H, W,
+              float(weight), int(acc), _stream())
+    return drec
+
+
+def flow_warp_bwd(x, flow, dy):
+    B, C, H, W = x.shape
+    df = torch.empty_like(flow)
+    _lib.call("emip_flow_warp_bwd", _p(x), _p(flow), _p(dy), _p(df), B, C, H, W, _stream())
+    return df

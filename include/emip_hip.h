@@ -237,6 +237,31 @@ int emip_mdta_bwd_small(const float* G, const float* nq2, const float* nk2, cons
                         const float* dA, void* dG, void* dGT, float* sq, float* sk, float* dtau, int B, int heads,
                         int dtype, void* stream);
 
+/* Window gather (scatter != 0: the inverse): dst[(b*nwin+win)][t] = src[b][table[win][t]] -- the dense batches the
+ * unfused window-attention backward works on. */
+int emip_window_rows(const void* src, void* dst, const int* table, int B, int nwin, int L, long n, int C, long ld_full,
+                     long ld_win, int scatter, int dtype, void* stream);
+
+/* Standalone activation (EMIP_ACT_RELU / EMIP_ACT_GELU) and ReLU backward (dx = dy where the forward output > 0). */
+int emip_act_fwd(const void* X, long ldx, void* Y, long ldy, long M, int C, int act, int dtype, void* stream);
+int emip_relu_bwd(const void* Yo, long ldy, const void* DY, long lddy, void* DX, long lddx, long M, int C, int dtype,
+                  void* stream);
+
+/* Backward of emip_convex_upsample: dlogits (576 channels) and dflow (f32, zero-filled inside). */
+int emip_convex_upsample_bwd(const void* logits, long ldl, const float* flow, const float* dY, void* dlogits, long lddl,
+                             float* dflow, int N, int H, int Wd, int dtype, void* stream);
+
+/* Loss backward: hybrid_e_loss w.r.t. the logits (ws = the scratch filled by emip_hybrid_e_loss), the photometric
+ * loss w.r.t. the reconstruction (sums = scratch of emip_photometric_loss; abc f32 [3*B*C*H*W]), flow_warp w.r.t. the
+ * flow.  gout: f32 [1] upstream gradient on the device. */
+int emip_hybrid_e_loss_bwd(const float* pred, const float* mask, double* ws, const float* gout, float* dpred, int B,
+                           int H, int W, void* stream);
+int emip_photometric_loss_bwd(const float* im, const float* rec, const float* mask, const double* sums, float* abc,
+                              const float* gout, float* drec, int B, int C, int H, int W, float weight, int accumulate,
+                              void* stream);
+int emip_flow_warp_bwd(const float* X, const float* flow, const float* dY, float* dflow, int B, int C, int H, int W,
+                       void* stream);
+
 /* out[c] += sum over rows of X[row][c] (bias gradients); out is f32 [C], accumulated into. */
 int emip_colsum(const void* X, long ldx, float* out, long rows, int C, int dtype, void* stream);
 
