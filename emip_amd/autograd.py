@@ -386,3 +386,248 @@ class UnflowPairLossFn(Function):
         d1 = ops.photometric_loss_bwd(im1, r1, m1, ws1, g, 0.5)
         d2 = ops.photometric_loss_bwd(im2, r2, m2, ws2, g, 0.5)
         return ops.flow_warp_bwd(im2, fw, d1), ops.flow_warp_bwd(im1, bw, d2), None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# GMFlow stream (frozen weights: input gradients only).  transformer.py / matching.py / gmflow.py of the reference.
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def _to_act(x32, dt):
+    """f32 rows -> activation dtype (a HIP copy kernel, not a torch cast)"""
+    if dt == torch.float32:
+        return x32
+    out = torch.empty(x32.shape, dtype=dt, device=x32.device)
+    C = x32.shape[-1]
+    ops.copy_cols(x32.view(-1, C), 0, C, out.view(-1, C), 0)
+    return out
+
+
+def dense_attention_bwd(q, k, v, do, L, scale, gq=None, gk=None, nwin=1, dscore=None, need_dv=True):
+    """Backward of softmax(q k^T * scale [+ shift mask]) v on dense batches.
+    q, k [Z, Lp, D], v [Zv, Lp, DV] (Zv = 1: shared), do [Z, Lp, DV], activation dtype, contiguous, rows >= L zero.
+    dscore: optional upstream gradient w.r.t. the SCALED scores [Z, Lp, Lp].
+    Returns dq (activation dtype), dk f32, dv f32 | None (all [Z, Lp, *])."""
+    Z, Lp, D = q.shape
+    DV = v.shape[-1]
+    dt, dev = q.dtype, q.device
+    S = torch.empty((Z, Lp, Lp), dtype=dt, device=dev)
+    ops.gemm_batched(q, k, S, Z, Lp, Lp, D, D, D, Lp, Lp * D, Lp * D, Lp * Lp)
+    P = ops.softmax_rows(S.view(Z * Lp, Lp), L, scale, gq, gk, period=Lp, nwin=nwin, out=S.view(Z * Lp, Lp))
+    dV = ops.gemm_tn_batched(P, do, Z, Lp, Lp, DV, Lp, DV, Lp * Lp, Lp * DV) if need_dv else None
+    dP = torch.empty((Z, Lp, Lp), dtype=dt, device=dev)
+    ops.gemm_batched(do, v, dP, Z, Lp, Lp, DV, DV, DV, Lp, Lp * DV, Lp * DV if v.shape[0] == Z else 0, Lp * Lp)
+    dS = ops.softmax_bwd_rows(P, dP.view(Z * Lp, Lp), L, scale, out=dP.view(Z * Lp, Lp))
+    if dscore is not None:
+        assert L == Lp
+        ops.axpby(dS, dscore.reshape(Z * Lp, Lp), 1.0, scale, out=dS)
+    kT = ops.transpose_pad(k, Lp)                                                       # [Z, D, Lp]
+    dq = torch.empty_like(q)
+    ops.gemm_batched(dS, kT, dq, Z, Lp, D, Lp, Lp, Lp, D, Lp * Lp, D * Lp, Lp * D)
+    dK = ops.gemm_tn_batched(dS, q, Z, Lp, Lp, D, Lp, D, Lp * Lp, Lp * D)
+    return dq, dK, dV
+
+
+class WindowAttentionFn(Function):
+    """Swin split-window single-head attention (transformer.py:46-105): fused forward through the index tables;
+    backward gathers each window into a dense batch and runs the unfused formulation."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, h, w, shift, splits):
+        from .model.EMIP_short.motion.gmflow.tables import window_tables
+        B2, n, C = q.shape
+        rows_t, gid = window_tables(h, w, splits, shift, q.device)
+        L = (h // splits) * (w // splits)
+        out = torch.empty((B2, n, C), dtype=q.dtype, device=q.device)
+        ops.attention(q, k, v, out, batch=B2, heads=1, nwin=splits * splits, Lq=L, Lk=L, D=C, DV=C, q_bs=n * C,
+                      k_bs=n * C, v_bs=n * C, o_bs=n * C, ldq=C, ldk=C, ldv=C, ldo=C, q_rows=rows_t, k_rows=rows_t,
+                      q_gid=gid if shift else None, k_gid=gid if shift else None, scale=C ** -0.5)
+        ctx.save_for_backward(q, k, v)
+        ctx.cfg = (h, w, shift, splits)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        from .model.EMIP_short.motion.gmflow.tables import window_tables
+        q, k, v = ctx.saved_tensors
+        h, w, shift, splits = ctx.cfg
+        B2, n, C = q.shape
+        nwin = splits * splits
+        L = n // nwin
+        Lp = _round_up(L, 8)
+        rows_t, gid = window_tables(h, w, splits, shift, q.device)
+        gq = None
+        if shift:
+            gq = torch.zeros((nwin, Lp), dtype=torch.int32, device=q.device)
+            gq[:, :L] = gid
+        g = lambda t: ops.window_rows(t.contiguous(), rows_t, B2, nwin, L, Lp, n, C)
+        dq, dK, dV = dense_attention_bwd(g(q), g(k), g(v), g(do), L, C ** -0.5, gq, gid if shift else None, nwin)
+        s = lambda t: ops.window_rows(t, rows_t, B2, nwin, L, Lp, n, C, scatter=True)
+        return s(dq), s(_to_act(dK, q.dtype)), s(_to_act(dV, q.dtype)), None, None, None, None
+
+
+class GlobalMatchFn(Function):
+    """Global correlation softmax in both directions (matching.py:8-41).  tokens [2B, n, C] (frame 0 | frame 1) ->
+    (expected positions f32 [2B, n, 32] with (x, y) in columns 0..1, scaled correlation [B, n(src), n(tgt)])."""
+
+    @staticmethod
+    def forward(ctx, c0, grid):
+        B2, n, C = c0.shape
+        B = B2 // 2
+        corr = torch.empty((B, n, n), dtype=c0.dtype, device=c0.device)
+        o = torch.empty((B2, n, 32), dtype=torch.float32, device=c0.device)
+        common = dict(batch=B, heads=1, nwin=1, Lq=n, Lk=n, D=C, DV=32, q_bs=n * C, k_bs=n * C, v_bs=0, o_bs=n * 32,
+                      ldq=C, ldk=C, ldv=32, ldo=32, scale=C ** -0.5)
+        ops.attention(c0[:B], c0[B:], grid, o[:B], scores=corr, s_bs=n * n, lds=n, **common)
+        ops.attention(c0[B:], c0[:B], grid, o[B:], **common)
+        ctx.save_for_backward(c0, grid)
+        return o, corr
+
+    @staticmethod
+    def backward(ctx, do, dcorr):
+        c0, grid = ctx.saved_tensors
+        B2, n, C = c0.shape
+        B = B2 // 2
+        assert n % 8 == 0
+        dt = c0.dtype
+        doT = _to_act(do.contiguous(), dt)
+        f0, f1 = c0[:B], c0[B:]
+        scale = C ** -0.5
+        dq_f, dk_f, _ = dense_attention_bwd(f0, f1, grid[None], doT[:B], n, scale, dscore=dcorr.contiguous(),
+                                            need_dv=False)
+        dq_b, dk_b, _ = dense_attention_bwd(f1, f0, grid[None], doT[B:], n, scale, need_dv=False)
+        dc0 = torch.empty_like(c0)
+        ops.axpby(dq_f, _to_act(dk_b, dt), 1.0, 1.0, out=dc0[:B])
+        ops.axpby(dq_b, _to_act(dk_f, dt), 1.0, 1.0, out=dc0[B:])
+        return dc0, None
+
+
+class FlowPropFn(Function):
+    """Flow propagation by feature self-similarity (transformer.py:485-533): softmax(q k^T / sqrt(C)) flow; the flow
+    operand is detached in the reference (gmflow.py:139)."""
+
+    @staticmethod
+    def forward(ctx, q, k, flow):
+        N, n, C = q.shape
+        v = torch.empty((N, n, 32), dtype=q.dtype, device=q.device)
+        ops.copy_cols(flow.view(N * n, 2), 0, 2, v.view(N * n, 32), 0, 32)
+        o = torch.empty((N, n, 32), dtype=torch.float32, device=q.device)
+        ops.attention(q, k, v, o, batch=N, heads=1, nwin=1, Lq=n, Lk=n, D=C, DV=32, q_bs=n * C, k_bs=n * C,
+                      v_bs=n * 32, o_bs=n * 32, ldq=C, ldk=C, ldv=32, ldo=32, scale=C ** -0.5)
+        ctx.save_for_backward(q, k, v)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v = ctx.saved_tensors
+        N, n, C = q.shape
+        dq, dk, _ = dense_attention_bwd(q, k, v, _to_act(do.contiguous(), q.dtype), n, C ** -0.5, need_dv=False)
+        return dq, _to_act(dk, q.dtype), None
+
+
+class CorrespToFlowFn(Function):
+    """columns 0..1 of the expectation (minus the pixel grid when sub_grid) -> flow f32 [N,h,w,2]"""
+
+    @staticmethod
+    def forward(ctx, o, N, h, w, sub_grid):
+        return ops.corresp_to_flow(o, N, h, w, sub_grid)
+
+    @staticmethod
+    def backward(ctx, dflow):
+        N, h, w, _ = dflow.shape
+        do = torch.empty((N, h * w, 32), dtype=torch.float32, device=dflow.device)
+        ops.copy_cols(dflow.contiguous().view(-1, 2), 0, 2, do.view(-1, 32), 0, 32)
+        return do, None, None, None, None
+
+
+class FlowToActFn(Function):
+    """flow f32 [N,h,w,2] -> activation dtype [N,h,w,8] (zero padded): the flow channels of the upsampler input"""
+
+    @staticmethod
+    def forward(ctx, flow, dt):
+        out = torch.empty(flow.shape[:-1] + (8,), dtype=dt, device=flow.device)
+        ops.copy_cols(flow, 0, 2, out, 0, 8)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        g = torch.empty(dy.shape[:-1] + (2,), dtype=torch.float32, device=dy.device)
+        ops.copy_cols(dy.contiguous(), 0, 2, g, 0)
+        return g, None
+
+
+class ConvexUpsampleFn(Function):
+    """gmflow.py:64-77"""
+
+    @staticmethod
+    def forward(ctx, logits, flow):
+        ctx.save_for_backward(logits, flow)
+        return ops.convex_upsample(logits, flow)
+
+    @staticmethod
+    def backward(ctx, dy):
+        logits, flow = ctx.saved_tensors
+        dl, df = ops.convex_upsample_bwd(logits, flow, dy.contiguous())
+        return dl, df
+
+
+class ActFn(Function):
+    """standalone ReLU / exact GELU"""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        y = ops.act_fwd(x, act)
+        ctx.save_for_backward(x if act == ops.ACT_GELU else y)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (t,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        return (ops.gelu_bwd(t, dy) if ctx.act == ops.ACT_GELU else ops.relu_bwd(t, dy)), None
+
+
+class AddFn(Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.eltwise(a, b, 2)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class BcastAddFn(Function):
+    """a[r] + table[r % period] (the window position encoding)"""
+
+    @staticmethod
+    def forward(ctx, a, table, period):
+        return ops.eltwise(a, table, 3, period=period)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, None, None
+
+
+class DropPathAddFn(Function):
+    """residual + scale[b] * branch: stochastic depth on the residual branch (timm DropPath as used by pvt_v2.py:
+    per-sample Bernoulli(keep) / keep).  scale: f32 [B, C] (the per-sample value repeated over channels)."""
+
+    @staticmethod
+    def forward(ctx, residual, branch, scale, rows_per_sample):
+        out = torch.empty_like(residual)
+        ops.colscale_add(residual, branch, scale, scale.shape[1], rows_per_sample, out)
+        ctx.save_for_backward(scale)
+        ctx.rps = rows_per_sample
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        db = torch.empty_like(dy)
+        ops.colscale_add(dy, dy, scale - 1.0, scale.shape[1], ctx.rps, db)        # dy + (s - 1) dy = s dy
+        return dy, db, None, None

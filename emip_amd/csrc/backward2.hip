@@ -14,7 +14,7 @@ inline int grid_for(long n, int threads) {
 template <typename T, bool SCATTER>
 __global__ __launch_bounds__(256) void window_rows_kernel(const T* __restrict__ src, T* __restrict__ dst,
                                                           const int* __restrict__ table, int B, int nwin, int L,
-                                                          long n, int C, long ld_full, long ld_win) {
+                                                          int Lp, long n, int C, long ld_full, long ld_win) {
     const int nv = C >> 2;
     const long total = (long)B * nwin * L * nv;
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
@@ -25,7 +25,7 @@ __global__ __launch_bounds__(256) void window_rows_kernel(const T* __restrict__ 
         const int win = (int)(r % nwin);
         const long b = r / nwin;
         const long full = (b * n + table[win * L + t]) * ld_full + vi * 4;
-        const long wrow = ((b * nwin + win) * (long)L + t) * ld_win + vi * 4;
+        const long wrow = ((b * nwin + win) * (long)Lp + t) * ld_win + vi * 4;
         float v[4];
         if (SCATTER) {
             Vec4<T>::load(src + wrow, v);
@@ -34,6 +34,24 @@ __global__ __launch_bounds__(256) void window_rows_kernel(const T* __restrict__ 
             Vec4<T>::load(src + full, v);
             Vec4<T>::store(dst + wrow, v);
         }
+    }
+}
+
+// y = alpha * a + beta * b
+template <typename T>
+__global__ __launch_bounds__(256) void axpby_kernel(const T* __restrict__ A, long lda, const T* __restrict__ Bm, long ldb,
+                                                    T* __restrict__ Y, long ldy, long M, int C, float alpha, float beta) {
+    const int nv = C >> 2;
+    const long total = M * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % nv) * 4;
+        const long r = idx / nv;
+        float a[4], b[4];
+        Vec4<T>::load(A + r * lda + c, a);
+        Vec4<T>::load(Bm + r * ldb + c, b);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = alpha * a[j] + beta * b[j];
+        Vec4<T>::store(Y + r * ldy + c, a);
     }
 }
 
@@ -127,6 +145,10 @@ __device__ __forceinline__ float hyb_t(float f, float g) {
     const float E = (2.f * f * g + 1e-8f) / den;
     const float dE = (2.f * g * den - (2.f * f * g + 1e-8f) * 2.f * f) / (den * den);
     return 0.5f * (1.f + E) * dE;                                       // dQ/df
+}
+__global__ void hybrid_bwd_zero_kernel(double* __restrict__ acc, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) acc[b * 8 + 5] = 0.0;
 }
 __global__ __launch_bounds__(256) void hybrid_bwd_pass1_kernel(const float* __restrict__ P, const float* __restrict__ M,
                                                                double* __restrict__ acc, int HW) {
@@ -300,20 +322,31 @@ __global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const float* __restr
     } while (0)
 #define REQ_DT(dtype) EMIP_REQUIRE((dtype) == EMIP_F32 || (dtype) == EMIP_BF16)
 
-extern "C" int emip_window_rows(const void* src, void* dst, const int* table, int B, int nwin, int L, long n, int C,
-                                long ld_full, long ld_win, int scatter, int dtype, void* stream) {
+extern "C" int emip_window_rows(const void* src, void* dst, const int* table, int B, int nwin, int L, int Lp, long n,
+                                int C, long ld_full, long ld_win, int scatter, int dtype, void* stream) {
     REQ_DT(dtype);
-    EMIP_REQUIRE(src && dst && table && B > 0 && nwin > 0 && L > 0 && n >= L && C >= 4 && (C & 3) == 0 &&
+    EMIP_REQUIRE(src && dst && table && B > 0 && nwin > 0 && L > 0 && Lp >= L && n >= L && C >= 4 && (C & 3) == 0 &&
                  (ld_full & 3) == 0 && (ld_win & 3) == 0 && ld_full >= C && ld_win >= C);
     const long total = (long)B * nwin * L * (C >> 2);
     if (scatter)
         DISPATCH_T(dtype, hipLaunchKernelGGL((window_rows_kernel<T, true>), dim3(grid_for(total, 256)), dim3(256), 0,
-                                             (hipStream_t)stream, (const T*)src, (T*)dst, table, B, nwin, L, n, C,
+                                             (hipStream_t)stream, (const T*)src, (T*)dst, table, B, nwin, L, Lp, n, C,
                                              ld_full, ld_win));
     else
         DISPATCH_T(dtype, hipLaunchKernelGGL((window_rows_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0,
-                                             (hipStream_t)stream, (const T*)src, (T*)dst, table, B, nwin, L, n, C,
+                                             (hipStream_t)stream, (const T*)src, (T*)dst, table, B, nwin, L, Lp, n, C,
                                              ld_full, ld_win));
+    return emip_launch_status();
+}
+
+extern "C" int emip_axpby(const void* A, long lda, const void* B, long ldb, void* Y, long ldy, long M, int C, float alpha,
+                          float beta, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(A && B && Y && M > 0 && C >= 4 && (C & 3) == 0 && (lda & 3) == 0 && (ldb & 3) == 0 && (ldy & 3) == 0 &&
+                 lda >= C && ldb >= C && ldy >= C);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(axpby_kernel<T>, dim3(grid_for(M * (C >> 2), 256)), dim3(256), 0,
+                                         (hipStream_t)stream, (const T*)A, lda, (const T*)B, ldb, (T*)Y, ldy, M, C, alpha,
+                                         beta));
     return emip_launch_status();
 }
 
@@ -356,6 +389,7 @@ extern "C" int emip_hybrid_e_loss_bwd(const float* pred, const float* mask, doub
     hipStream_t s = (hipStream_t)stream;
     const int HW = H * W;
     dim3 grid((HW + 256 * 8 - 1) / (256 * 8), B);
+    hipLaunchKernelGGL(hybrid_bwd_zero_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, B);   // repeated backward passes
     hipLaunchKernelGGL(hybrid_bwd_pass1_kernel, grid, dim3(256), 0, s, pred, mask, ws, HW);
     hipLaunchKernelGGL(hybrid_bwd_pass2_kernel, grid, dim3(256), 0, s, pred, mask, ws, gout, dpred, B, HW);
     return emip_launch_status();

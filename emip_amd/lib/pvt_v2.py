@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..autograd import ConvFn, DwConvFn, LayerNormFn, LinearFn, SraAttentionFn
+from ..autograd import DropPathAddFn, ConvFn, DwConvFn, LayerNormFn, LinearFn, SraAttentionFn
 from ..nn_base import EmipModule, f32, pack_conv, pack_dw, pack_linear, to_cl, to_planar
 
 
@@ -144,9 +144,28 @@ class Block(EmipModule):
         self.norm2 = norm_layer(dim)
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
 
+    def _drop_scale(self, x, tag):
+        """per-sample DropPath factor Bernoulli(keep) / keep as f32 [B, C]; `forced_drop` (dict tag -> [B] factors)
+        overrides the draw for parity tests against the oracle's drop_masks"""
+        B, C = x.shape[0], x.shape[-1]
+        forced = getattr(self, "forced_drop", None)
+        if forced is not None:
+            s = forced[tag].to(device=x.device, dtype=torch.float32)
+        else:
+            keep = 1.0 - self.drop_path_rate
+            s = torch.floor(keep + torch.rand(B, device=x.device)) / keep
+        return s.view(B, 1).expand(B, C).contiguous()
+
     def run(self, x):
         if self.training and self.drop_path_rate > 0:
-            raise NotImplementedError("stochastic depth (train mode) is not built yet; call .eval()")
+            # stochastic depth: the branch is computed without the fused residual, then scaled per sample
+            if not torch.is_grad_enabled():
+                raise RuntimeError("train-mode DropPath runs on the autograd path: enable grad or call .eval()")
+            rps = x.shape[1] * x.shape[2]
+            a = self.attn.run(LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), None)
+            x = DropPathAddFn.apply(x, a, self._drop_scale(x, "attn"), rps)
+            m = self.mlp.run(LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), None)
+            return DropPathAddFn.apply(x, m, self._drop_scale(x, "mlp"), rps)
         if torch.is_grad_enabled():
             x = self.attn.run(LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), x)
             return self.mlp.run(LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x)

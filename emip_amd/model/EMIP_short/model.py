@@ -2,10 +2,12 @@
 
 Drop-in for /root/reference/model/EMIP_short/model.py: same constructor dictionary, same forward signature and
 return structure, same state_dict keys (including the reference's never-called modules dr2_new, dr3_new,
-downscaling1, upscaling3/4 and backbone.decoder, which exist as parameters only).  The forward is a fixed
-sequence of libemip_hip.so launches on the current stream: both frames go through the PVTv2 and GMFlow-CNN
-streams as ONE batch of 2B images, activations stay channels-last in HBM between kernels, and only the two
-boundary conversions (planar images in, planar mask/flows out) touch the reference's NCHW layout.
+downscaling1, upscaling3/4 and backbone.decoder, which exist as parameters only).  Under torch.no_grad() the forward is a
+fixed sequence of libemip_hip.so launches on the current stream; with grad enabled (train mode) every step is a
+torch.autograd.Function whose forward and backward are the same library's kernels (emip_amd/autograd.py,
+emip_amd/train.py).  Both frames go through the PVTv2 and GMFlow-CNN streams as ONE batch of 2B images, activations
+stay channels-last in HBM between kernels, and only the two boundary conversions (planar images in, planar
+mask/flows out) touch the reference's NCHW layout.
 """
 from typing import Tuple
 
@@ -83,7 +85,10 @@ class CoUpdater(EmipModule):
         fea = self.backbone.feat_net.run(imgs)                         # stages 2..4 of both frames
         gm = self.GMFlow.backbone.run(imgs)                            # [2B,44,44,128]
         ab = self.injector.run(gm, fea[0])                             # camouflage feeder (shared weights)
-        preds, corr = self.GMFlow.run(ab[:B], ab[B:])
+        if torch.is_grad_enabled() and ab.requires_grad:
+            preds, corr = self.GMFlow.run_train(ab)
+        else:
+            preds, corr = self.GMFlow.run(ab[:B], ab[B:])
         cc = self.run_conv_corr(corr)                                  # motion collector, part 1
         fea_new = self.injector1.run(fea[0][:B], cc)
         f1 = self.dr1.run(fea_new)
@@ -94,10 +99,10 @@ class CoUpdater(EmipModule):
         return mask, preds
 
     def forward(self, image1, image2):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            # The backward kernels are not part of this build yet: refuse rather than return tensors that
-            # silently carry no gradient.
-            raise NotImplementedError("emip_amd CoUpdater: run forward under torch.no_grad() (inference build)")
+        if torch.is_grad_enabled() and not self.training and any(p.requires_grad for p in self.parameters()):
+            # gradients are built for the training configuration (batch-statistics BatchNorm, train.py:38); the
+            # reference's inference drivers all run under torch.no_grad() (test.py:21)
+            raise RuntimeError("emip_amd CoUpdater in eval mode: wrap inference in torch.no_grad()")
         B = image1.shape[0]
         mask, preds = self.run(image1, image2)
         flow_fw = [p[:B] for p in preds]

@@ -11,6 +11,8 @@ import torch
 import torch.nn as nn
 
 from ..... import ops
+from .....autograd import (ActFn, BcastAddFn, BilinearPlanarFn, ConcatFn, ConvFn, ConvexUpsampleFn, CorrespToFlowFn,
+                           FlowToActFn, GlobalMatchFn, LinearFn)
 from .....nn_base import EmipModule, f32, pack_conv, pack_linear, to_cl, to_planar
 from .backbone import CNNEncoder
 from .tables import grid_values, position_table
@@ -36,6 +38,39 @@ class GMFlow(EmipModule):
         self.prop_radius_list, self.pred_bidir_flow = g['prop_radius_list'], g['pred_bidir_flow']
         assert self.corr_radius_list == [-1] and self.prop_radius_list == [-1] and self.pred_bidir_flow, \
             "only the shipped configuration (global matching, bidirectional) is built"
+
+    def run_train(self, ab):
+        """differentiable variant of run(): ab = prompted features of both frames [2B,h,w,C] (frame 1 | frame 2).
+        The GMFlow weights are frozen (model.py:61-63), so only input gradients flow."""
+        dt = self.cdtype
+        B2, h, w, C = ab.shape
+        n = h * w
+        splits = self.attn_splits_list[0]
+        pos = position_table(h, w, C, splits, dt, ab.device)
+        c0 = BcastAddFn.apply(ab.view(B2, n, C), pos, n)
+        c0 = self.transformer.run_train(c0, h, w, splits)
+        o, corr = GlobalMatchFn.apply(c0, grid_values(h, w, dt, ab.device))
+        flow = CorrespToFlowFn.apply(o, B2, h, w, True)
+        preds = []
+        if self.training:
+            preds.append(BilinearPlanarFn.apply(flow, 0, 2, 8 * h, 8 * w, True, 8.0))
+        flow = self.feature_flow_attn.run(c0, flow, h, w)
+        cin = C + 8
+        perm = list(range(2, 2 + C)) + [0, 1]
+        up0, up2 = self.upsampler[0], self.upsampler[2]
+
+        def build(p, r):
+            wpad = torch.cat([p.detach()[:, perm], p.new_zeros(p.shape[0], cin - p.shape[1], 3, 3)], 1)
+            r2 = r.detach().reshape(r.shape[0], -1)
+            return (pack_conv(wpad, dt), pack_conv(wpad.flip(2, 3).permute(1, 0, 2, 3), dt), pack_linear(r2, dt),
+                    r2.t().to(dt).contiguous())
+        w0, w0d, w2, w2t = self.packed("up_t", (up0.weight, up2.weight), build)
+        u = ConcatFn.apply(None, c0.view(B2, h, w, C), FlowToActFn.apply(flow, dt))
+        u = ActFn.apply(ConvFn.apply(u, up0.weight, up0.bias, w0, w0d, 3, 1, 1, cin), ops.ACT_RELU)
+        logits = LinearFn.apply(u, up2.weight, up2.bias, None, w2, w2t)
+        preds.append(ConvexUpsampleFn.apply(logits, flow))
+        self.last = dict(tokens=c0, flow_prop=flow)
+        return preds, corr
 
     def run(self, a, b):
         """a, b: channels-last prompted features [B,h,w,C] of frame 1 / frame 2.

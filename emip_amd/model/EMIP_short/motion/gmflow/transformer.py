@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 
 from ..... import ops
+from .....autograd import (ActFn, AddFn, ConcatFn, CorrespToFlowFn, FlowPropFn, LayerNormFn, LinearFn,
+                           WindowAttentionFn)
 from .....nn_base import EmipModule, f32, pack_linear
 from .tables import window_tables
 
@@ -56,6 +58,15 @@ class TransformerLayer(EmipModule):
         return w
 
 
+    def lin(self, name, x, res=None):
+        """differentiable bias-free Linear through the frozen-or-not weight `name`"""
+        mod = self.mlp[int(name[3:])] if name.startswith("mlp") else getattr(self, name)
+        dt = self.cdtype
+        wp, wpt = self.packed("t_" + name, (mod.weight,), lambda a: (pack_linear(a, dt),
+                                                                     a.detach().t().to(dt).contiguous()))
+        return LinearFn.apply(x, mod.weight, mod.bias, res, wp, wpt)
+
+
 class TransformerBlock(EmipModule):
     """self attention, then cross attention + FFN (transformer.py:348-401)."""
 
@@ -94,8 +105,30 @@ class FeatureTransformer(EmipModule):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
+    def run_train(self, c0, h, w, attn_num_splits=2):
+        """differentiable variant of run(): same op stream, out of place, every step a Function over HIP kernels"""
+        B2, n, C = c0.shape
+        B = B2 // 2
+        swap = lambda t: torch.cat((t[B:], t[:B]), 0)            # the other frame's tokens (data movement only)
+        for blk in self.layers:
+            sa, ca = blk.self_attn, blk.cross_attn_ffn
+            shift = sa.with_shift
+            kx, vx = swap(ca.lin("k_proj", c0)), swap(ca.lin("v_proj", c0))
+            msg = WindowAttentionFn.apply(sa.lin("q_proj", c0), sa.lin("k_proj", c0), sa.lin("v_proj", c0), h, w, shift,
+                                          attn_num_splits)
+            msg = LayerNormFn.apply(sa.lin("merge", msg), sa.norm1.weight, sa.norm1.bias, sa.norm1.eps)
+            c1 = AddFn.apply(c0, msg)
+            msg = WindowAttentionFn.apply(ca.lin("q_proj", c1), kx, vx, h, w, shift, attn_num_splits)
+            msg = LayerNormFn.apply(ca.lin("merge", msg), ca.norm1.weight, ca.norm1.bias, ca.norm1.eps)
+            hid = ActFn.apply(ca.lin("mlp0", ConcatFn.apply(None, c1, msg)), ops.ACT_GELU)
+            msg = LayerNormFn.apply(ca.lin("mlp2", hid), ca.norm2.weight, ca.norm2.bias, ca.norm2.eps)
+            c0 = AddFn.apply(c1, msg)
+        return c0
+
     def run(self, c0, h, w, attn_num_splits=2):
         """c0: [2B, h*w, C] tokens, frame-0 features in the first half, frame-1 in the second.  In place."""
+        if torch.is_grad_enabled() and c0.requires_grad:
+            return self.run_train(c0, h, w, attn_num_splits)
         B2, n, C = c0.shape
         B = B2 // 2
         assert n == h * w and C == self.d_model
@@ -141,6 +174,13 @@ class FeatureFlowAttention(EmipModule):
         """feat [N, h*w, C] tokens, flow f32 [N, h, w, 2] -> propagated flow f32 [N, h, w, 2]"""
         dt = feat.dtype
         N, n, C = feat.shape
+        if torch.is_grad_enabled() and feat.requires_grad:
+            packs = self.packed("wt", (self.q_proj.weight, self.k_proj.weight), lambda a, c: (
+                pack_linear(a, dt), a.detach().t().to(dt).contiguous(), pack_linear(c, dt),
+                c.detach().t().to(dt).contiguous()))
+            q = LinearFn.apply(feat, self.q_proj.weight, self.q_proj.bias, None, packs[0], packs[1])
+            k = LinearFn.apply(q, self.k_proj.weight, self.k_proj.bias, None, packs[2], packs[3])
+            return CorrespToFlowFn.apply(FlowPropFn.apply(q, k, flow.detach()), N, h, w, False)
         wq, bq, wk, bk = self.packed("w", (self.q_proj.weight, self.q_proj.bias, self.k_proj.weight,
                                            self.k_proj.bias),
                                      lambda a, b, c, d: (pack_linear(a, dt), f32(b), pack_linear(c, dt), f32(d)))

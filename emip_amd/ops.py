@@ -485,16 +485,27 @@ def mdta_bwd_small(ws, temperature, attn, dA, B, heads):
     return dG, dGT, sq, sk, dtau
 
 
-def window_rows(src, table, B, nwin, L, n, C, scatter=False, dst=None):
-    """gather [B, n, C] -> [B*nwin, L, C] through table [nwin, L] (scatter: the inverse, into dst [B, n, C])"""
+def window_rows(src, table, B, nwin, L, Lp, n, C, scatter=False):
+    """gather [B, n, C] -> [B*nwin, Lp, C] (zero pad rows) through table [nwin, L]; scatter: the inverse -> [B, n, C]"""
     _dev(src)
+    assert src.is_contiguous()
     if not scatter:
-        dst = torch.empty((B * nwin, L, C), dtype=src.dtype, device=src.device)
+        dst = (torch.zeros if Lp > L else torch.empty)((B * nwin, Lp, C), dtype=src.dtype, device=src.device)
     else:
-        assert dst is not None
-    _lib.call("emip_window_rows", _p(src), _p(dst), _p(table), B, nwin, L, n, C, C, C, int(scatter),
+        dst = torch.empty((B, n, C), dtype=src.dtype, device=src.device)
+    _lib.call("emip_window_rows", _p(src), _p(dst), _p(table), B, nwin, L, Lp, n, C, C, C, int(scatter),
               dt_code(src.dtype), _stream())
     return dst
+
+
+def axpby(a, b, alpha, beta, out=None):
+    M, C, lda = rows(a)
+    _, _, ldb = rows(b)
+    if out is None:
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    _lib.call("emip_axpby", _p(a), lda, _p(b), ldb, _p(out), rows(out)[2], M, C, float(alpha), float(beta),
+              dt_code(a.dtype), _stream())
+    return out
 
 
 def act_fwd(x, act):

@@ -237,10 +237,14 @@ int emip_mdta_bwd_small(const float* G, const float* nq2, const float* nk2, cons
                         const float* dA, void* dG, void* dGT, float* sq, float* sk, float* dtau, int B, int heads,
                         int dtype, void* stream);
 
-/* Window gather (scatter != 0: the inverse): dst[(b*nwin+win)][t] = src[b][table[win][t]] -- the dense batches the
- * unfused window-attention backward works on. */
-int emip_window_rows(const void* src, void* dst, const int* table, int B, int nwin, int L, long n, int C, long ld_full,
-                     long ld_win, int scatter, int dtype, void* stream);
+/* Window gather (scatter != 0: the inverse): dst[(b*nwin+win)*Lp + t] = src[b][table[win][t]], t < L <= Lp -- the
+ * dense (row-padded) batches the unfused window-attention backward works on.  Pad rows are not touched. */
+int emip_window_rows(const void* src, void* dst, const int* table, int B, int nwin, int L, int Lp, long n, int C,
+                     long ld_full, long ld_win, int scatter, int dtype, void* stream);
+
+/* Y = alpha * A + beta * B (row-strided, 4-channel granularity). */
+int emip_axpby(const void* A, long lda, const void* B, long ldb, void* Y, long ldy, long M, int C, float alpha,
+               float beta, int dtype, void* stream);
 
 /* Standalone activation (EMIP_ACT_RELU / EMIP_ACT_GELU) and ReLU backward (dx = dy where the forward output > 0). */
 int emip_act_fwd(const void* X, long ldx, void* Y, long ldy, long M, int C, int act, int dtype, void* stream);

@@ -149,3 +149,172 @@ def test_decoder_convcorr_gradients_vs_oracle(short_sd, model_args):
     assert _relerr(dc, rcorr.grad) < 2e-2
     worst = _grads_close(dict(net.named_parameters()), ref, keys, 2e-2)
     print("decoder/conv_corr worst relative gradient error", worst)
+
+
+def test_gmflow_input_gradients_vs_oracle(short_sd):
+    """frozen GMFlow stream: gradient w.r.t. the prompted features through both flow predictions and the correlation"""
+    import json
+    import os
+    from emip_amd import nn_base
+    from emip_amd.model.EMIP_short.motion.gmflow.gmflow import GMFlow
+    from oracle import emip_oracle as O
+    nn_base.set_default_dtype(torch.float32)
+    args = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "model_args.json")))
+    sd = {k[len("GMFlow."):]: v for k, v in short_sd.items() if k.startswith("GMFlow.")}
+    net = GMFlow(feature_channels=128, args=args)
+    net.load_state_dict(sd)
+    net = net.to("cuda:0").train()
+    for q in net.parameters():
+        q.requires_grad_(False)
+    B, h, w, C = 1, 44, 44, 128
+    g = torch.Generator().manual_seed(77)
+    ab = torch.randn(2 * B, C, h, w, generator=g) * 0.5
+    w_lr = torch.randn(2 * B, 2, 8 * h, 8 * w, generator=g) / (8 * h * 8 * w)
+    w_up = torch.randn(2 * B, 2, 8 * h, 8 * w, generator=g) / (8 * h * 8 * w)
+    w_corr = torch.randn(B, h * w, h * w, generator=g) / (h * w)
+    # ---- HIP
+    x = ab.permute(0, 2, 3, 1).contiguous().cuda().requires_grad_(True)
+    with torch.enable_grad():
+        preds, corr = net.run_train(x)
+        loss = (preds[0] * w_lr.cuda()).sum() + (preds[1] * w_up.cuda()).sum() + (corr * w_corr.cuda()).sum()
+        loss.backward()
+    # ---- oracle
+    xr = ab.clone().requires_grad_(True)
+    rsd = {"GMFlow." + k: v for k, v in sd.items()}
+    fw, bw, rcorr, _ = O.gmflow_forward(xr[:B], xr[B:], rsd, "GMFlow", training=True)
+    # oracle corr: [B, tgt, h, w(src)] view of [B, src, tgt]
+    rc = rcorr.permute(0, 2, 3, 1).reshape(B, h * w, h * w)
+    rloss = ((torch.cat((fw[0], bw[0])) * w_lr).sum() + (torch.cat((fw[1], bw[1])) * w_up).sum() + (rc * w_corr).sum())
+    rloss.backward()
+    print("loss", loss.item(), rloss.item())
+    assert abs(loss.item() - rloss.item()) < 1e-3 * max(1.0, abs(rloss.item()))
+    e = _relerr(x.grad.permute(0, 3, 1, 2), xr.grad)
+    print("gmflow input-gradient relative error", e)
+    assert e < 5e-3
+
+
+def _short_net(model_args, short_sd):
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    from emip_amd.train import freeze_like_reference
+    net = CoUpdater(model_args)
+    net.load_state_dict(short_sd)
+    return freeze_like_reference(net.to("cuda:0").train())
+
+
+def test_full_training_step_gradients_vs_oracle(model_args, short_sd):
+    """forward + hybrid_e_loss + unFlowLoss + backward of the whole EMIP-short model (train mode, DropPath masks forced
+    to the oracle's) against torch autograd through the CPU oracle"""
+    from emip_amd import nn_base
+    from emip_amd.filler import synthetic_gt
+    from emip_amd.loss.loss_flow import unFlowLoss
+    from emip_amd.loss.loss_pred import hybrid_e_loss
+    from oracle import emip_oracle as O
+    nn_base.set_default_dtype(torch.float32)
+    net = _short_net(model_args, short_sd)
+    B = 1
+    im1, im2 = synthetic_pair(B, seed=99)
+    gt = synthetic_gt(B, seed=99)
+    # DropPath factors: one draw per (stage, block, branch) and per image of the 2B batch
+    g = torch.Generator().manual_seed(3)
+    blocks = [(i, j) for i in range(4) for j in range(len(getattr(net.backbone.feat_net.pvtv2_en, f"block{i + 1}")))]
+    dm = {}
+    for (i, j) in blocks:
+        blk = getattr(net.backbone.feat_net.pvtv2_en, f"block{i + 1}")[j]
+        keep = 1.0 - blk.drop_path_rate
+        forced = {}
+        for tag in ("attn", "mlp"):
+            s = torch.floor(keep + torch.rand(2 * B, generator=g)) / keep
+            forced[tag] = s
+            dm[(i, j, tag)] = s
+        blk.forced_drop = forced
+    names = ["backbone.feat_net.pvtv2_en.patch_embed1.proj.weight", "backbone.feat_net.pvtv2_en.block1.0.attn.q.weight",
+             "backbone.feat_net.pvtv2_en.block2.3.mlp.fc1.weight", "backbone.feat_net.pvtv2_en.block3.20.attn.kv.weight",
+             "backbone.feat_net.pvtv2_en.block4.2.mlp.fc2.weight", "backbone.feat_net.pvtv2_en.norm4.weight",
+             "injector.transformer.attn.temperature", "injector.transformer.attn.q.weight",
+             "injector.transformer.ffn.project_out.weight", "injector1.transformer.attn.kv.weight",
+             "conv_corr.0.weight", "conv_corr.3.weight", "conv_corr.1.weight", "dr1.reduce.0.conv.weight",
+             "dr3.reduce.1.bn.weight", "decoder.conv_upsample5.conv.weight", "decoder.conv5.weight",
+             "decoder.conv5.bias"]
+    gw = torch.Generator().manual_seed(8)
+    wfl = [torch.randn(2 * B, 2, 352, 352, generator=gw) / (352 * 352) for _ in range(2)]
+    p = dict(net.named_parameters())
+
+    def collect(params, get):
+        out = {n: get(params[n]).detach().float().cpu().clone() for n in names}
+        for q in params.values():
+            if torch.is_tensor(q) and q.grad is not None:
+                q.grad = None
+        return out
+
+    # ---- HIP: one forward, two backward passes (A: hybrid + a smooth linear functional of the flows, B: the real loss)
+    with torch.enable_grad():
+        mask, fw, bw = net(im1.cuda(), im2.cuda())
+        lp = hybrid_e_loss(mask, gt.cuda())
+        lf = unFlowLoss().compute_loss([torch.cat((fw[i], bw[i]), 1) for i in range(len(fw))],
+                                       torch.cat((im1, im2), 1).cuda())[0]
+        lin = sum((torch.cat((fw[i], bw[i]), 0) * wfl[i].cuda()).sum() for i in range(2))
+        (lp + lin).backward(retain_graph=True)
+        frozen_with_grad = [n for n, q in p.items() if not q.requires_grad and q.grad is not None]
+        missing = {n for n, q in p.items() if q.requires_grad and q.grad is None}
+        gA = collect(p, lambda q: q.grad)
+        (lp + lf).backward()
+        gB = collect(p, lambda q: q.grad)
+    # ---- oracle (the two frames go through the backbone separately there: split the masks)
+    ref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in short_sd.items()}
+    dm1 = {k: v[:B] for k, v in dm.items()}
+    dm2 = {k: v[B:] for k, v in dm.items()}
+    rmask, rfw, rbw = O.short_forward(im1, im2, ref, training=True, drop_masks=(dm1, dm2))
+    rlp = O.hybrid_e_loss(rmask, gt)
+    rlf = O.unflow_loss([torch.cat((rfw[i], rbw[i]), 1) for i in range(len(rfw))], torch.cat((im1, im2), 1))
+    rlin = sum((torch.cat((rfw[i], rbw[i]), 0) * wfl[i]).sum() for i in range(2))
+    (rlp + rlin).backward(retain_graph=True)
+    ref_missing = {n for n, q in ref.items() if q.is_floating_point() and q.requires_grad and q.grad is None}
+    rA = collect(ref, lambda q: q.grad)
+    (rlp + rlf).backward()
+    rB = collect(ref, lambda q: q.grad)
+    print("losses", lp.item(), rlp.item(), lf.item(), rlf.item(), lin.item(), rlin.item())
+    assert abs(lp.item() - rlp.item()) < 1e-3 and abs(lf.item() - rlf.item()) < 1e-3
+    assert abs(lin.item() - rlin.item()) < 1e-3 * max(1.0, abs(rlin.item()))
+    print("max |flow_hip - flow_oracle| (px)", (fw[1].detach().cpu() - rfw[1].detach()).abs().max().item())
+
+    def worst_err(g, r, tag):
+        worst = 0.0
+        for n in names:
+            e = ((g[n] - r[n]).abs().max() / max(r[n].abs().max().item(), 1e-6)).item()
+            print(f"  [{tag}] {n}: {e:.3e} (scale {r[n].abs().max().item():.3e})")
+            worst = max(worst, e)
+        return worst
+    wA = worst_err(gA, rA, "smooth")
+    wB = worst_err(gB, rB, "real")
+    print("full-step worst relative gradient error: smooth flow functional", wA, " real unFlowLoss", wB)
+    # A: every kernel on the backward path is exercised with a smooth objective; what is left is ReLU / BatchNorm
+    # mask flips behind conv_corr.0 (1-3 % of a 1.6e-3 gradient, varies run to run with the f32 atomics)
+    assert wA < 5e-2
+    # B: the photometric loss is piecewise (bilinear cell of the warp, |.|, SSIM clamp): 1e-4 px of forward rounding
+    # difference moves a few pixels across a kink, which perturbs the small flow-loss gradients reaching the injector
+    assert wB < 0.3
+    assert not frozen_with_grad
+    # parameters the reference never reaches (dead modules, GMFlow adaptors) stay without gradient on both sides
+    assert missing == {n for n in ref_missing if n in p and p[n].requires_grad}, (sorted(missing ^ ref_missing))[:6]
+
+
+def test_train_step_runs_and_updates(model_args, short_sd):
+    """emip_amd.train.train_step: loss finite, trainable parameters move, frozen ones do not (bf16 compute)"""
+    from emip_amd import nn_base
+    from emip_amd.filler import synthetic_gt
+    from emip_amd.train import build_optimizer, train_step
+    nn_base.set_default_dtype(torch.bfloat16)
+    try:
+        net = _short_net(model_args, short_sd)
+        opt = build_optimizer(net, lr=1e-5, weight_decay=1e-7, clip=0.5)
+        im1, im2 = synthetic_pair(2, seed=5)
+        gt = synthetic_gt(2, seed=5)
+        w_tr = net.decoder.conv5.weight.detach().clone()
+        w_fr = net.GMFlow.upsampler[0].weight.detach().clone()
+        losses = [train_step(net, opt, None, im1.cuda(), im2.cuda(), gt.cuda())[0].item() for _ in range(2)]
+        print("bf16 train losses", losses)
+        assert all(l == l and abs(l) < 1e4 for l in losses)
+        assert (net.decoder.conv5.weight.detach() - w_tr).abs().max().item() > 0
+        assert torch.equal(net.GMFlow.upsampler[0].weight.detach(), w_fr)
+    finally:
+        nn_base.set_default_dtype(torch.float32)
