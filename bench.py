@@ -88,8 +88,74 @@ def cpu_baseline(sd):
                       "%d threads, host has %d logical CPUs)" % (n, torch.get_num_threads(), os.cpu_count())}
 
 
+def main_train(args):
+    """--workload train: BASELINE.json configs[2] / configs[4] -- one EMIP-short training step (forward, hybrid_e_loss +
+    unFlowLoss, backward, bucketed gradient all-reduce over RCCL when N > 1, fused clamp + AdamW) on a batch of 32
+    synthetic pairs per GPU in bf16.  Reported beside, never instead of, the inference headline."""
+    from emip_amd import dist as edist
+    world, rank, local = edist.env_world()
+    dist = None
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist = edist.init("nccl")
+    dev = torch.device("cuda", local)
+    from emip_amd import _lib, nn_base
+    from emip_amd.dp import GradReducer, broadcast_parameters
+    from emip_amd.filler import state_dict_from_manifest, synthetic_gt, synthetic_pair
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    from emip_amd.train import build_optimizer, freeze_like_reference, train_step, trainable
+    _lib.load()
+    g = os.path.join(ROOT, "tests", "golden")
+    margs = json.load(open(os.path.join(g, "model_args.json")))
+    sd = state_dict_from_manifest(json.load(open(os.path.join(g, "short_state_manifest.json"))), 0)
+    nn_base.set_default_dtype(torch.bfloat16)
+    net = CoUpdater(margs)
+    net.load_state_dict(sd)
+    net = freeze_like_reference(net.to(dev).train())
+    broadcast_parameters(net)
+    opt = build_optimizer(net)
+    red = GradReducer(trainable(net)) if world > 1 else None
+    B = args.pairs or 32
+    im1, im2 = synthetic_pair(B, seed=edist.pair_seed(1234, rank))
+    gt = synthetic_gt(B, seed=edist.pair_seed(99, rank))
+    im1, im2, gt = im1.to(dev), im2.to(dev), gt.to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = train_step(net, opt, red, im1, im2, gt)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = train_step(net, opt, red, im1, im2, gt)
+    barrier()
+    dt = edist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "frame_pairs_per_sec_352x352_emip_short_train_step", "value": round(world * B * args.steps / dt, 3),
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "EMIP-short training step (fwd + hybrid_e_loss + unFlowLoss + bwd + clamp/AdamW), "
+                                   "batch=%d 352x352 pairs per GPU, bf16 storage / f32 accumulate and f32 master "
+                                   "weights, DropPath 0.1, GMFlow frozen" % B,
+                       "pairs_per_gpu": B, "parallelism": "dp%d (bucketed all-reduce over RCCL)" % world},
+            "last_loss": [round(float(x), 5) for x in loss],
+            "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=("infer", "train"), default="infer")
+    ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (train workload; default 32)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
@@ -97,6 +163,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=4, help="sub-batches replayed concurrently on separate HIP streams")
     args = ap.parse_args()
+    if args.workload == "train":
+        return main_train(args)
 
     from emip_amd import dist as edist
     world, rank, local = edist.env_world()

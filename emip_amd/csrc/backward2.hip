@@ -125,11 +125,14 @@ __global__ __launch_bounds__(256) void convex_up_bwd_kernel(const T* __restrict_
             p[k] /= den;
             const int iy = y + k / 3 - 1, ix = x + k % 3 - 1;
             u[k] = 0.f;
-            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd) {
-                const long fo = ((n * H + iy) * Wd + ix) * 2;
-                u[k] = 8.f * (gx * F[fo] + gy * F[fo + 1]);          // dL/dp_k
-                atomicAdd(DF + fo, 8.f * p[k] * gx);
-                atomicAdd(DF + fo + 1, 8.f * p[k] * gy);
+            const bool in = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd;      // wave-uniform
+            const long fo = ((n * H + iy) * Wd + ix) * 2;
+            if (in) u[k] = 8.f * (gx * F[fo] + gy * F[fo + 1]);      // dL/dp_k
+            // the 64 lanes of a wave are the 64 sub-pixels of ONE coarse pixel: reduce, then one atomic per tap
+            const float sx = wave_sum(8.f * p[k] * gx), sy = wave_sum(8.f * p[k] * gy);
+            if (in && ij == 0) {
+                atomicAdd(DF + fo, sx);
+                atomicAdd(DF + fo + 1, sy);
             }
             dot += p[k] * u[k];
         }
