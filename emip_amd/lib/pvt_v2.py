@@ -146,7 +146,7 @@ class Block(EmipModule):
 
     def _drop_scale(self, x, tag):
         """per-sample DropPath factor Bernoulli(keep) / keep as f32 [B, C]; `forced_drop` (dict tag -> [B] factors)
-        overrides the draw for parity tests against the oracle's drop_masks"""
+        overrides the draw (parity tests force the same factors on both sides)"""
         B, C = x.shape[0], x.shape[-1]
         forced = getattr(self, "forced_drop", None)
         if forced is not None:
