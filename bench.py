@@ -152,9 +152,69 @@ def main_train(args):
         dist.destroy_process_group()
 
 
+def main_long(args):
+    """--workload long: BASELINE.json configs[3] -- EMIP-long historical-prompt inference, 8 independent video streams
+    per GPU, steady state (5-frame memory window full, memory fed back from the previous step), bf16, eager launches."""
+    from emip_amd import dist as edist
+    world, rank, local = edist.env_world()
+    dist = None
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist = edist.init("nccl")
+    dev = torch.device("cuda", local)
+    from emip_amd import _lib, nn_base
+    from emip_amd.filler import state_dict_from_manifest, synthetic_pair
+    from emip_amd.model.EMIP_long.model_long import Model_long
+    _lib.load()
+    g = os.path.join(ROOT, "tests", "golden")
+    margs = json.load(open(os.path.join(g, "model_args.json")))
+    sd = state_dict_from_manifest(json.load(open(os.path.join(g, "long_state_manifest.json"))), 0)
+    nn_base.set_default_dtype(torch.bfloat16)
+    net = Model_long(margs)
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    S = args.pairs or 8
+    f0, f1 = synthetic_pair(S, seed=edist.pair_seed(1234, rank))
+    f0, f1 = f0.to(dev), f1.to(dev)
+    state = {"k": None, "v": None, "i": 0}
+
+    def step():
+        with torch.no_grad():
+            _, k, v = net.forward_streams(f0, f1, state["i"], state["k"], state["v"])
+        state["k"], state["v"], state["i"] = k, v, state["i"] + 1
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, Model_long.WINDOW + 2)):      # fill the memory window before timing
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = edist.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "stream_frames_per_sec_352x352_emip_long", "value": round(world * S * args.steps / dt, 3),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, Model_long.WINDOW + 2),
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "EMIP-long inference step (short-term forward + LTM memorize/segment over a 5-frame "
+                                   "window + long decoder), %d video streams per GPU, bf16, eager launches" % S,
+                       "streams_per_gpu": S, "memory_frames": int(state["k"].shape[3]),
+                       "parallelism": "dp%d (independent replicas, no collective)" % world}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--workload", choices=("infer", "train"), default="infer")
+    ap.add_argument("--workload", choices=("infer", "train", "long"), default="infer")
     ap.add_argument("--pairs", type=int, default=0, help="pairs per GPU (train workload; default 32)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -165,6 +225,8 @@ def main():
     args = ap.parse_args()
     if args.workload == "train":
         return main_train(args)
+    if args.workload == "long":
+        return main_long(args)
 
     from emip_amd import dist as edist
     world, rank, local = edist.env_world()
@@ -179,6 +241,8 @@ def main():
     from emip_amd.graph import GraphedShort
     from emip_amd.model.EMIP_short.model import CoUpdater
     _lib.load()
+    if os.environ.get("EMIP_TILE_SHARE"):
+        _lib.call("emip_debug_set", 4, int(os.environ["EMIP_TILE_SHARE"]))
     if os.environ.get("EMIP_GEMM_NBUF"):
         _lib.call("emip_debug_set", 0, int(os.environ["EMIP_GEMM_NBUF"]))
     g = os.path.join(ROOT, "tests", "golden")

@@ -368,6 +368,7 @@ int g_gemm_nbuf = 1;  // debug/tuning knob (emip_debug_set)
 int g_gemm_tile = 0;  // 0 = heuristic, else BM*1000+BN
 int g_gemm_dbg = 0;
 int g_gemm_glds = 1;  // LDS-DMA main loop for dense GEMMs
+int g_gemm_share = 1; // concurrent streams sharing the GPU (tile choice assumes 256 / share CUs); measured: no gain
 
 template <typename T, int BM, int BN, bool CONV>
 int launch(GemmArgs& a, int batch, hipStream_t s) {
@@ -401,9 +402,9 @@ void pick_tile(long M, long N, long batch, int& bm, int& bn, long K = 0) {
     bm = 128;
     // short K: workgroups are latency-bound, prefer many small ones; long K (>= 1024): each workgroup streams
     // many K tiles, so keep the big tile (half the operand traffic per flop) as long as every CU gets one.
-    const long min_blocks = K >= 1024 ? 256 : 1024;
+    const long min_blocks = (K >= 1024 ? 256 : 1024) / g_gemm_share;
     if (blocks(bm, bn) < min_blocks || waste(64, bn) * 10 < waste(128, bn) * 9) bm = 64;
-    if (bn == 128 && blocks(bm, bn) < 256) bn = 64;
+    if (bn == 128 && blocks(bm, bn) < 256 / g_gemm_share) bn = 64;
 }
 
 template <typename T, bool CONV>
@@ -491,6 +492,10 @@ extern "C" int emip_debug_set(int key, int value) {
     }
     if (key == 3) {
         g_gemm_glds = value ? 1 : 0;
+        return EMIP_OK;
+    }
+    if (key == 4 && (value == 1 || value == 2 || value == 4 || value == 8)) {
+        g_gemm_share = value;      // launches are issued for one of `value` streams that share the GPU concurrently
         return EMIP_OK;
     }
     return EMIP_E_INVALID;
