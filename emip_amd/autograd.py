@@ -101,10 +101,9 @@ class LayerNormFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma = ctx.saved_tensors
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
-        dx = ops.layernorm_bwd(x, dy.contiguous(), gamma, ctx.eps, dg, db)
-        return dx, dg, db, None
+        dgb = torch.zeros((2,) + tuple(gamma.shape), dtype=gamma.dtype, device=gamma.device)   # one fill for both
+        dx = ops.layernorm_bwd(x, dy.contiguous(), gamma, ctx.eps, dgb[0], dgb[1])
+        return dx, dgb[0], dgb[1], None
 
 
 class DwConvFn(Function):
@@ -128,8 +127,8 @@ class DwConvFn(Function):
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             C = x.shape[-1]
-            dwt = torch.zeros((9, C), dtype=torch.float32, device=x.device)
-            dbt = torch.zeros(C, dtype=torch.float32, device=x.device) if has_bias else None
+            acc = torch.zeros((10, C), dtype=torch.float32, device=x.device)      # 9 taps + bias, one fill
+            dwt, dbt = acc[:9], (acc[9] if has_bias else None)
             ops.dwconv3x3_wgrad(x, dz, dwt, dbt)
             dw = dwt.t().reshape(weight.shape).contiguous()
             db = dbt

@@ -147,63 +147,81 @@ template <typename T>
 __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ X, long ldx, const T* __restrict__ DY,
                                                            long lddy, float* __restrict__ dW, float* __restrict__ db,
                                                            int B, int H, int Wd, int C, int rows_per_block) {
-    // grid: (channel groups of 64 x row chunks, B); thread = (channel quad, pixel lane)
-    const int nq = 16;                       // 16 channel quads = 64 channels per block
-    const int cq = threadIdx.x & 15, pl = threadIdx.x >> 4;   // 16 pixel lanes
+    // grid: (channel groups of 64 x row chunks, B); thread = (16-byte channel vector, pixel lane).  All loads are
+    // unconditional 16-byte loads on clamped addresses, masked afterwards (a load inside a branch is waited for on the spot).
+    constexpr int VEC = 16 / sizeof(T);          // channels per thread: 4 (f32) or 8 (bf16)
+    constexpr int NCV = 64 / VEC;                // channel vectors per 64-channel group
+    constexpr int NPL = 256 / NCV;               // pixel lanes
+    const int cv = threadIdx.x % NCV, pl = threadIdx.x / NCV;
     const int cgroups = (C + 63) / 64;
     const int cg = blockIdx.x % cgroups, chunk = blockIdx.x / cgroups;
     const long b = blockIdx.y;
-    const int c = cg * 64 + cq * 4;
-    float aw[9][4], ab[4] = {0, 0, 0, 0};
+    const int c = cg * 64 + cv * VEC;
+    const bool cok = c + VEC <= C;               // C % VEC == 0 is required by the entry point
+    const int cc = cok ? c : 0;
+    float aw[9][VEC], ab[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) ab[j] = 0.f;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) aw[t][j] = 0.f;
+        for (int j = 0; j < VEC; ++j) aw[t][j] = 0.f;
     const int y0 = chunk * rows_per_block, y1 = min(H, y0 + rows_per_block);
-    if (c < C) {
-        for (int y = y0; y < y1; ++y) {
-            for (int x = pl; x < Wd; x += 16) {
-                float dy[4];
-                Vec4<T>::load(DY + ((b * H + y) * (long)Wd + x) * lddy + c, dy);
+    for (int y = y0; y < y1; ++y) {
+        for (int x = pl; x < Wd; x += NPL) {
+            const uint4 dv = mask4(*reinterpret_cast<const uint4*>(DY + ((b * H + y) * (long)Wd + x) * lddy + cc), cok);
+            float dy[VEC];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) ab[j] += dy[j];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int iy = y + ky - 1;
-                    if ((unsigned)iy >= (unsigned)H) continue;
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int ix = x + kx - 1;
-                        if ((unsigned)ix >= (unsigned)Wd) continue;
-                        float xv[4];
-                        Vec4<T>::load(X + ((b * H + iy) * (long)Wd + ix) * ldx + c, xv);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) aw[ky * 3 + kx][j] = fmaf(dy[j], xv[j], aw[ky * 3 + kx][j]);
-                    }
-                }
+            for (int j = 0; j < VEC; ++j) {
+                dy[j] = to_f32<T>(reinterpret_cast<const T*>(&dv)[j]);
+                ab[j] += dy[j];
             }
+            uint4 xv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int iy = y + t / 3 - 1, ix = x + t % 3 - 1;
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd;
+                const int iyc = min(max(iy, 0), H - 1), ixc = min(max(ix, 0), Wd - 1);
+                xv[t] = mask4(*reinterpret_cast<const uint4*>(X + ((b * H + iyc) * (long)Wd + ixc) * ldx + cc), ok);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < VEC; ++j)
+                    aw[t][j] = fmaf(dy[j], to_f32<T>(reinterpret_cast<const T*>(&xv[t])[j]), aw[t][j]);
         }
     }
-    __shared__ float red[10][16][4][16 + 1];
+    // reduce over the pixel lanes: inside a wave the lanes with the same cv sit NCV apart (xor-shuffle), then 4 waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) red[t][cq][j][pl] = aw[t][j];
+        for (int j = 0; j < VEC; ++j)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) red[9][cq][j][pl] = ab[j];
+            for (int o = NCV; o < 64; o <<= 1) aw[t][j] += __shfl_xor(aw[t][j], o);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+        for (int o = NCV; o < 64; o <<= 1) ab[j] += __shfl_xor(ab[j], o);
+    __shared__ float red[10][64][4];
+    if (lane < NCV) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) red[t][lane * VEC + j][wave] = aw[t][j];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) red[9][lane * VEC + j][wave] = ab[j];
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < 10 * 64; i += 256) {
-        const int t = i / 64, cc = i % 64;
-        float s = 0.f;
-#pragma unroll
-        for (int l = 0; l < 16; ++l) s += red[t][cc >> 2][cc & 3][l];
-        const int ch = cg * 64 + cc;
+        const int t = i / 64, ch64 = i % 64;
+        const float s = red[t][ch64][0] + red[t][ch64][1] + red[t][ch64][2] + red[t][ch64][3];
+        const int ch = cg * 64 + ch64;
         if (ch < C) {
             if (t < 9) atomicAdd(dW + t * C + ch, s);
             else if (db) atomicAdd(db + ch, s);
         }
     }
-    (void)nq;
 }
 
 // ---- train-mode BatchNorm backward ------------------------------------------------------------------------------
@@ -432,8 +450,10 @@ extern "C" int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy,
 extern "C" int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, long lddy, float* dW, float* db, int B,
                                     int H, int Wd, int C, int dtype, void* stream) {
     REQ_DT(dtype);
-    EMIP_REQUIRE(X && DY && dW && B > 0 && B < 65536 && H > 0 && Wd > 0 && C >= 4 && (C & 3) == 0);
-    EMIP_REQUIRE((ldx & 3) == 0 && (lddy & 3) == 0 && ldx >= C && lddy >= C);
+    EMIP_REQUIRE(X && DY && dW && B > 0 && B < 65536 && H > 0 && Wd > 0 && C >= 4);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(C % vec == 0 && ldx % vec == 0 && lddy % vec == 0 && ldx >= C && lddy >= C);
+    EMIP_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)DY) & 15) == 0);
     const int rpb = 4;
     dim3 grid(((C + 63) / 64) * ((H + rpb - 1) / rpb), B);
     DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_wgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)X,
