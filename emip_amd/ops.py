@@ -573,3 +573,20 @@ def flow_warp_bwd(x, flow, dy):
     df = torch.empty_like(flow)
     _lib.call("emip_flow_warp_bwd", _p(x), _p(flow), _p(dy), _p(df), B, C, H, W, _stream())
     return df
+
+
+def mlp_tail(h, wt, bdw, w2, b2, res, out=None):
+    """h [B,H,W,Ch] (fc1 output) -> res + b2 + GELU(dwconv3x3(h) + bdw) w2^T as [B,H,W,N]; the activated hidden tensor
+    stays on chip.  w2 [N, Ch] packed like a Linear weight."""
+    _dev(h)
+    B, H, W, Ch = h.shape
+    N = w2.shape[0]
+    assert w2.shape[1] == Ch and w2.is_contiguous() and w2.dtype == h.dtype
+    _, _, ldh = rows(h)
+    if out is None:
+        out = torch.empty((B, H, W, N), dtype=h.dtype, device=h.device)
+    _, _, ldy = rows(out)
+    ldr = rows(res)[2] if res is not None else 0
+    _lib.call("emip_mlp_tail", _p(h), ldh, _p(wt), _p(bdw), _p(w2), Ch, _p(b2), _p(res), ldr, _p(out), ldy, B, H, W, Ch,
+              N, dt_code(h.dtype), _stream())
+    return out

@@ -237,6 +237,13 @@ int emip_mdta_bwd_small(const float* G, const float* nq2, const float* nk2, cons
                         const float* dA, void* dG, void* dGT, float* sq, float* sk, float* dtau, int B, int heads,
                         int dtype, void* stream);
 
+/* Fused tail of the PVTv2 Mlp (lib/pvt_v2.py:45-54): Y = R + b2 + GELU(dwconv3x3(H) + bdw) W2^T with H the fc1 output
+ * [B][Hh][Ww][Ch] channels-last, Wt the depthwise weights [9][Ch] (f32), W2 [N][Ch]; N in {64,128,320,512}.  The
+ * activated hidden tensor never reaches HBM.  R may alias Y. */
+int emip_mlp_tail(const void* H, long ldh, const float* Wt, const float* bdw, const void* W2, long ldw, const float* b2,
+                  const void* R, long ldr, void* Y, long ldy, int B, int Hh, int Ww, int Ch, int N, int dtype,
+                  void* stream);
+
 /* Window gather (scatter != 0: the inverse): dst[(b*nwin+win)*Lp + t] = src[b][table[win][t]], t < L <= Lp -- the
  * dense (row-padded) batches the unfused window-attention backward works on.  Pad rows are not touched. */
 int emip_window_rows(const void* src, void* dst, const int* table, int B, int nwin, int L, int Lp, long n, int C,

@@ -318,3 +318,34 @@ def test_warp_indices_bit_exact(golden):
     assert np.array_equal(idx.cpu().numpy().astype(np.int32), g["indices"])
     occ = ops.occ_mask_backward(fl)
     assert (occ.cpu().numpy().astype(np.uint8) != g["occ"]).mean() < 1e-4
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,H,W,C,ratio", [(2, 11, 11, 512, 4), (3, 22, 22, 320, 4), (2, 44, 44, 128, 4), (1, 88, 88, 64, 4),
+                                           (8, 88, 88, 64, 2), (1, 5, 7, 320, 1)])
+def test_mlp_tail_matches_unfused(dt, tol, B, H, W, C, ratio):
+    """fused dwconv3x3 + GELU + fc2 + residual == the separate kernels == torch fp32"""
+    from emip_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + C)
+    Ch = C * ratio
+    h = torch.randn(B, H, W, Ch, generator=g)
+    wd = torch.randn(Ch, 1, 3, 3, generator=g) * 0.3
+    bd = torch.randn(Ch, generator=g) * 0.1
+    w2 = torch.randn(C, Ch, generator=g) / Ch ** 0.5
+    b2 = torch.randn(C, generator=g) * 0.1
+    res = torch.randn(B, H, W, C, generator=g)
+    hq, w2q, rq = h.to(dt).float(), w2.to(dt).float(), res.to(dt).float()
+    t = torch.nn.functional.conv2d(hq.permute(0, 3, 1, 2), wd, bd, padding=1, groups=Ch)
+    t = torch.nn.functional.gelu(t).permute(0, 2, 3, 1)
+    if dt == torch.bfloat16:
+        t = t.to(dt).float()
+    ref = rq + t @ w2q.t() + b2
+    dev = "cuda:0"
+    wt = wd.reshape(Ch, 9).t().contiguous().to(dev)
+    y = ops.mlp_tail(h.to(dt).to(dev), wt, bd.to(dev), w2.to(dt).to(dev).contiguous(), b2.to(dev), res.to(dt).to(dev))
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), err
+    # in-place residual (the way the model calls it)
+    r2 = res.to(dt).to(dev).clone()
+    y2 = ops.mlp_tail(h.to(dt).to(dev), wt, bd.to(dev), w2.to(dt).to(dev).contiguous(), b2.to(dev), r2, out=r2)
+    assert torch.equal(y2, y)

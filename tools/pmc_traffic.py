@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; --output-format csv) of `bench.py --no-graph` into
+profiles/pmc_traffic.json: HBM bytes per launch for every kernel symbol, keyed the way bench.py names kernels.
+
+  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> profiles/pmc_traffic.json
+
+gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE under-counts wide coalesced reads by 2x,
+so bytes = (2 * FETCH_SIZE_KB + WRITE_SIZE_KB) * 1024.  The first launches of every symbol (warm-up) are included;
+shapes repeat every step so the per-launch mean is over identical launch sets."""
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def bench_key(name):
+    m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELb([01])ELi(\d+)EE", name)
+    if m:
+        return "gemm_kernel<%s,%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
+                                                "conv" if m.group(4) == "1" else "dense", m.group(5))
+    m = re.search(r"attn_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EE", name)
+    if m:
+        return "attn_kernel<%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
+                                             m.group(4))
+    m = re.search(r"N_1\d+(\w+?)_kernelI", name) or re.search(r"(\w+)_kernel", name)
+    return ("emip_" + m.group(1)) if m else name[:60]
+
+
+def per_kernel(path, counter):
+    tot, cnt = collections.defaultdict(float), collections.defaultdict(set)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"]
+            tot[k] += float(r["Counter_Value"])
+            cnt[k].add(r["Dispatch_Id"])
+    return {k: (tot[k], len(cnt[k])) for k in tot}
+
+
+def main():
+    fetch, write, out = sys.argv[1:4]
+    fe, wr = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
+    res = {}
+    for k in sorted(set(fe) | set(wr)):
+        f, nf = fe.get(k, (0.0, 0))
+        w, nw = wr.get(k, (0.0, 0))
+        n = max(nf, nw, 1)
+        key = bench_key(k)
+        e = res.setdefault(key, {"FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0, "launches_profiled": 0, "symbols": []})
+        e["FETCH_SIZE_KB"] += f
+        e["WRITE_SIZE_KB"] += w
+        e["launches_profiled"] += n
+        e["symbols"].append(k[:120])
+    for e in res.values():
+        n = e["launches_profiled"]
+        e["FETCH_SIZE_KB_per_launch"] = round(e.pop("FETCH_SIZE_KB") / n, 1)
+        e["WRITE_SIZE_KB_per_launch"] = round(e.pop("WRITE_SIZE_KB") / n, 1)
+        e["hbm_bytes_per_launch"] = int((2 * e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"]) * 1024)
+        e["note"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts half of wide coalesced reads"
+    json.dump(res, open(out, "w"), indent=1, sort_keys=True)
+    print("wrote", out, len(res), "kernels")
+
+
+if __name__ == "__main__":
+    main()
