@@ -82,6 +82,28 @@ def kernel_breakdown(net, im1, im2, splits=1):
     return agg
 
 
+def rocprof_avg(key):
+    """average kernel-only duration of the same symbol in the committed rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/r01_bench_kernel_stats_final.csv); a HIP-event pair additionally sees ~2 us of marker latency"""
+    import csv
+    import re
+    path = os.path.join(ROOT, "profiles", "r01_bench_kernel_stats_final.csv")
+    if not os.path.exists(path):
+        return None
+    m = re.match(r"(gemm|attn)_kernel<bf16,(.*)>", key)
+    if not m:
+        return None
+    f = m.group(2).split(",")
+    if m.group(1) == "gemm":
+        pat = "gemm_kernelIDF16bLi%sELi%sELb%dELi%sEE" % (f[0], f[1], 1 if f[2] == "conv" else 0, f[3])
+    else:
+        pat = "attn_kernelIDF16bLi%sELi%sELi%sEE" % (f[0], f[1], f[2])
+    for r in csv.DictReader(open(path)):
+        if pat in r["Name"]:
+            return round(float(r["AverageNs"]) / 1e3, 2)
+    return None
+
+
 def cpu_baseline(sd):
     from emip_amd.filler import synthetic_pair
     from oracle import emip_oracle as O
@@ -334,6 +356,7 @@ def main():
                          "launches": cnt, "avg_launch_us": round(ms / cnt * 1e3, 2),
                          "algorithmic_flops_per_launch": round(fl / cnt), "kernel_ms_per_step": round(ms, 3),
                          "share_of_step_kernel_time": round(ms / total_ms, 3),
+                         "rocprofv3_avg_launch_us": rocprof_avg(dom),
                          "note": "launch durations are per kernel in ISOLATION on the sub-batch shapes the graphs "
                                  "replay; in the timed region %d such streams overlap (sum of isolated kernel time "
                                  "%.1f ms vs %.1f ms wall per step)" % (nsplit, total_ms, dt / args.steps * 1e3),
