@@ -287,7 +287,7 @@ def main():
     net.load_state_dict(sd)
     net = net.to(dev).eval()
 
-    B = PAIRS_PER_GPU
+    B = int(os.environ.get("EMIP_DIAG_PAIRS", PAIRS_PER_GPU))     # diagnosis only: the reported config is 16
     im1, im2 = synthetic_pair(B, seed=edist.pair_seed(1234, rank))
     im1, im2 = im1.to(dev), im2.to(dev)
 
