@@ -101,6 +101,100 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const T* __restri
     }
 }
 
+// ---- 128-column rows (the 121-key SRA attention backward, padded to 128): 16 lanes per row, 8 columns per lane -------
+// One wave covers 4 rows per pass with 16-byte accesses (bf16) instead of one row with 2-byte accesses.
+template <typename T>
+__device__ __forceinline__ void load8(const T* p, float (&v)[8]) {
+    if (sizeof(T) == 2) {
+        const uint4 u = *reinterpret_cast<const uint4*>(p);
+        const T* t = reinterpret_cast<const T*>(&u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = to_f32<T>(t[j]);
+    } else {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]) {
+    if (sizeof(T) == 2) {
+        uint4 u;
+        T* t = reinterpret_cast<T*>(&u);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = from_f32<T>(v[j]);
+        *reinterpret_cast<uint4*>(p) = u;
+    } else {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+}
+__device__ __forceinline__ float group16_sum(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float group16_max(float v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows128_kernel(const T* __restrict__ X, T* __restrict__ Y, long rows,
+                                                              int L, float scale) {
+    const int sub = threadIdx.x & 15;
+    const long g0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 4, ng = ((long)gridDim.x * 256) >> 4;
+    const long iters = (rows + ng - 1) / ng;                       // uniform trip count: shuffles stay convergent
+    for (long it = 0; it < iters; ++it) {
+        const long r = g0 + it * ng;
+        const long rc = r < rows ? r : rows - 1;
+        float v[8];
+        load8<T>(X + rc * 128 + sub * 8, v);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = (sub * 8 + j < L) ? v[j] * scale : -INFINITY;
+            mx = fmaxf(mx, v[j]);
+        }
+        mx = group16_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            v[j] = (sub * 8 + j < L) ? expf(v[j] - mx) : 0.f;
+            sum += v[j];
+        }
+        const float inv = 1.f / group16_sum(sum);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= inv;
+        if (r < rows) store8<T>(Y + r * 128 + sub * 8, v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_rows128_kernel(const T* __restrict__ P, const T* __restrict__ DP,
+                                                                  T* __restrict__ DS, long rows, int L, float scale) {
+    const int sub = threadIdx.x & 15;
+    const long g0 = ((long)blockIdx.x * 256 + threadIdx.x) >> 4, ng = ((long)gridDim.x * 256) >> 4;
+    const long iters = (rows + ng - 1) / ng;
+    for (long it = 0; it < iters; ++it) {
+        const long r = g0 + it * ng;
+        const long rc = r < rows ? r : rows - 1;
+        float pv[8], dv[8];
+        load8<T>(P + rc * 128 + sub * 8, pv);
+        load8<T>(DP + rc * 128 + sub * 8, dv);
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (sub * 8 + j >= L) pv[j] = dv[j] = 0.f;
+            dot += pv[j] * dv[j];
+        }
+        dot = group16_sum(dot);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pv[j] = pv[j] * (dv[j] - dot) * scale;
+        if (r < rows) store8<T>(DS + r * 128 + sub * 8, pv);
+    }
+}
+
 // Y[z][c][r] = r < R ? X[z][r][c] : 0   for c < C, r < Rpad   (X rows of stride ldx, Y rows of stride Rpad)
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ X, long ldx, long bsx,
@@ -410,6 +504,11 @@ extern "C" int emip_softmax_rows(const void* X, void* Y, long rows, int L, long 
     EMIP_REQUIRE(X && Y && rows > 0 && L > 0 && L <= 2048 && ld >= L && ld <= 2048);
     EMIP_REQUIRE((gid_q == nullptr) == (gid_k == nullptr));
     if (gid_q) EMIP_REQUIRE(period > 0 && nwin > 0);
+    if (!gid_q && ld == 128 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_rows128_kernel<T>, dim3(grid_for(rows, 16)), dim3(256), 0,
+                                             (hipStream_t)stream, (const T*)X, (T*)Y, rows, L, scale));
+        return emip_launch_status();
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_rows_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)X, (T*)Y, rows, L, ld, scale, gid_q, gid_k,
                                          period, nwin));
@@ -420,6 +519,11 @@ extern "C" int emip_softmax_bwd_rows(const void* P, const void* DP, void* DS, lo
                                      int dtype, void* stream) {
     REQ_DT(dtype);
     EMIP_REQUIRE(P && DP && DS && rows > 0 && L > 0 && L <= 2048 && ld >= L && ld <= 2048);
+    if (ld == 128 && (((uintptr_t)P | (uintptr_t)DP | (uintptr_t)DS) & 15) == 0) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_bwd_rows128_kernel<T>, dim3(grid_for(rows, 16)), dim3(256), 0,
+                                             (hipStream_t)stream, (const T*)P, (const T*)DP, (T*)DS, rows, L, scale));
+        return emip_launch_status();
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_bwd_rows_kernel<T>, dim3(grid_for(rows, 4)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)P, (const T*)DP, (T*)DS, rows, L, ld, scale));
     return emip_launch_status();
