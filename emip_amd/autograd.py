@@ -101,9 +101,8 @@ class LayerNormFn(Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma = ctx.saved_tensors
-        dgb = torch.zeros((2,) + tuple(gamma.shape), dtype=gamma.dtype, device=gamma.device)   # one fill for both
-        dx = ops.layernorm_bwd(x, dy.contiguous(), gamma, ctx.eps, dgb[0], dgb[1])
-        return dx, dgb[0], dgb[1], None
+        dx, dg, db = ops.layernorm_bwd_fresh(x, dy.contiguous(), gamma, ctx.eps)
+        return dx, dg, db, None
 
 
 class DwConvFn(Function):

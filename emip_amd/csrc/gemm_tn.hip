@@ -182,6 +182,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
 
 }  // namespace
 
+int g_tn_target = 0;   // 0 = heuristic; tools/gemm_tn_bench.py overrides it
+extern "C" int emip_debug_set_tn(int target) { g_tn_target = target > 0 ? target : 0; return EMIP_OK; }
+
 namespace {
 template <bool CONV>
 int launch_tn(TnArgs& a, int batch, int dtype, hipStream_t s) {
@@ -189,7 +192,10 @@ int launch_tn(TnArgs& a, int batch, int dtype, hipStream_t s) {
     a.tiles_k = (a.K + 127) / 128;
     const int bms = dtype == EMIP_F32 ? 32 : 64;
     const long tiles = (long)a.tiles_n * a.tiles_k * batch;
-    long splits = (1024 + tiles - 1) / tiles;                       // aim at >= ~1024 workgroups
+    // workgroups to aim at: every split adds a 128x128 f32 tile of atomics, so few output tiles take ~512 workgroups
+    // and many tiles ~256 (measured on the PVTv2-b5 shapes, tools/gemm_tn_bench.py)
+    const long target = g_tn_target > 0 ? g_tn_target : (tiles <= 4 ? 512 : 256);
+    long splits = (target + tiles - 1) / tiles;
     const long max_splits = (a.M + 4 * bms - 1) / (4 * bms);        // but >= 4 stages of work per workgroup
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

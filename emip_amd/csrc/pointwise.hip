@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             T* __restrict__ DX, long lddx,
                                                             const float* __restrict__ gamma,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            long M, int C, float eps, int lpr_log2) {
+                                                            long M, int C, float eps, int lpr_log2, int nparts,
+                                                            long part_stride) {
     extern __shared__ float red[];   // [2][C]
     const int LPR = 1 << lpr_log2;
     const int lane = threadIdx.x & 63;
@@ -189,9 +190,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
     }
     __syncthreads();
+    // workgroups are spread over `nparts` partial accumulators (the caller sums them): 1/nparts of the contention
+    const long po = (long)(blockIdx.x % nparts) * part_stride;
     for (int i = threadIdx.x; i < C; i += 256) {
-        atomicAdd(dgamma + i, red[i]);
-        atomicAdd(dbeta + i, red[C + i]);
+        atomicAdd(dgamma + po + i, red[i]);
+        atomicAdd(dbeta + po + i, red[C + i]);
     }
 }
 
@@ -699,10 +702,11 @@ extern "C" int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const 
 
 // dgamma / dbeta are ACCUMULATED into (the caller zero-fills them, or keeps accumulating across micro-batches)
 extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx,
-                                  const float* gamma, float* dgamma, float* dbeta, long M, int C, float eps,
-                                  int dtype, void* stream) {
+                                  const float* gamma, float* dgamma, float* dbeta, int nparts, long part_stride, long M,
+                                  int C, float eps, int dtype, void* stream) {
     REQ_DT(dtype);
     EMIP_REQUIRE(X && DY && DX && gamma && dgamma && dbeta && M > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
+    EMIP_REQUIRE(nparts >= 1 && (nparts == 1 || part_stride >= C));
     EMIP_REQUIRE((ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C && lddy >= C && lddx >= C);
     const int nv = C >> 2;
     int lg = 0;
@@ -710,10 +714,12 @@ extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long 
     const int rows_per_wave = 64 >> lg;
     const long waves = (M + rows_per_wave - 1) / rows_per_wave;
     long blocks = (waves + 3) / 4;
-    if (blocks > 1024) blocks = 1024;
+    const long cap = nparts >= 16 ? 4096 : 1024;     // many workgroups only pay off when the atomics are spread out
+    if (blocks > cap) blocks = cap;
     DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256),
                                          2 * C * sizeof(float), (hipStream_t)stream, (const T*)X, ldx, (const T*)DY,
-                                         lddy, (T*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg));
+                                         lddy, (T*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg, nparts,
+                                         part_stride));
     return emip_launch_status();
 }
 

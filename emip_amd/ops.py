@@ -332,12 +332,27 @@ def conv2d_wgrad(dy, x, kh, kw, stride, pad):
 
 
 def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta):
+    """dx; dgamma / dbeta (f32 [C]) are accumulated into"""
     M, C, ldx = rows(x)
     _, _, lddy = rows(dy)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    _lib.call("emip_layernorm_bwd", _p(x), ldx, _p(dy), lddy, _p(dx), C, _p(gamma), _p(dgamma), _p(dbeta), M, C,
+    _lib.call("emip_layernorm_bwd", _p(x), ldx, _p(dy), lddy, _p(dx), C, _p(gamma), _p(dgamma), _p(dbeta), 1, 0, M, C,
               float(eps), dt_code(x.dtype), _stream())
     return dx
+
+
+def layernorm_bwd_fresh(x, dy, gamma, eps):
+    """dx, dgamma, dbeta (fresh f32 [C] tensors); many-row inputs spread the reduction over 32 partial accumulators"""
+    M, C, ldx = rows(x)
+    _, _, lddy = rows(dy)
+    dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    P = 32 if M >= 8192 else 1
+    acc = torch.zeros((P, 2, C), dtype=torch.float32, device=x.device)
+    _lib.call("emip_layernorm_bwd", _p(x), ldx, _p(dy), lddy, _p(dx), C, _p(gamma), _p(acc), _p(acc[0, 1]), P, 2 * C, M,
+              C, float(eps), dt_code(x.dtype), _stream())
+    if P > 1:
+        acc = colsum(acc.view(P, 2 * C)).view(1, 2, C)
+    return dx, acc[0, 0], acc[0, 1]
 
 
 # ---- backward building blocks ---------------------------------------------------------------------------------------

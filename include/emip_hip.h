@@ -55,6 +55,7 @@ int emip_gemm_tile(long M, long N, long batch, long K);
 
 /* Tuning knob for experiments (not part of the drop-in contract): key 0 = LDS buffers of the GEMM main loop. */
 int emip_debug_set(int key, int value);
+int emip_debug_set_tn(int target_workgroups);   /* 0 = heuristic split count of emip_gemm_tn (tuning only) */
 
 /* NHWC convolution as implicit GEMM, weights packed [Cout][KH][KW][Cin], same epilogue.
  * nn.Conv2d call sites: lib/pvt_v2.py:187-188,208 (patch embed), :75,107 (SR conv);
@@ -183,9 +184,12 @@ int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, l
 int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout,
                       long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream);
 
-/* LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (f32 atomics).  mean/rstd are recomputed from x. */
+/* LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (f32 atomics).  mean/rstd are recomputed from x.  Workgroup b
+ * accumulates into dgamma/dbeta + (b % nparts) * part_stride: nparts > 1 spreads the atomics over partial buffers that
+ * the caller sums (nparts = 1: plain accumulation). */
 int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx, const float* gamma,
-                       float* dgamma, float* dbeta, long M, int C, float eps, int dtype, void* stream);
+                       float* dgamma, float* dbeta, int nparts, long part_stride, long M, int C, float eps, int dtype,
+                       void* stream);
 
 /* Row softmax of the first L columns (columns L..ld-1 are written as 0): Y = softmax(X*scale + mask), mask = -100
  * where gid_q[win][row] != gid_k[win][col] (rows are ordered [batch][win][period]); and its backward

@@ -77,6 +77,22 @@ def test_layernorm_backward(dtype, M, C):
     assert rel(dx, xr.grad) < tol and rel(dg, gr.grad) < tol and rel(db, br.grad) < tol
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_backward_many_rows_partial_accumulators(dtype):
+    """the autograd path spreads dgamma / dbeta over 32 partial accumulators for >= 8192 rows"""
+    from emip_amd import ops
+    M, C = 30976, 320
+    x, xf = prep(rnd(M, C, seed=11) * 2 + 0.3, dtype)
+    dy, dyf = prep(rnd(M, C, seed=12), dtype)
+    g = (1 + 0.1 * rnd(C, seed=13))
+    xr = xf.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), torch.zeros(C, requires_grad=True)
+    F.layer_norm(xr, (C,), gr, br, 1e-6).backward(dyf)
+    dx, dg, db = ops.layernorm_bwd_fresh(x, dy, g.cuda(), 1e-6)
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    assert rel(dx, xr.grad) < tol and rel(dg, gr.grad) < tol and rel(db, br.grad) < tol
+
+
 def _pack_conv_w(w):  # [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin]
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
