@@ -132,3 +132,45 @@ def test_graph_replay_with_stream_splits_matches_eager(model_args, short_sd):
         torch.cuda.synchronize()
         assert (mask - ref_mask).abs().max().item() < 1e-3
         assert (fw[0] - ref_fw[0]).abs().max().item() < 0.5 and (bw[0] - ref_bw[0]).abs().max().item() < 0.5
+
+
+def test_full_bench_batch_is_sample_independent_and_frame_symmetric(short_f32):
+    """Size-independent properties at BASELINE.json's full batch (16 pairs, f32 mode): eval-mode outputs of a sample do
+    not depend on its batch mates (16-pair launch == the same pairs run 3 / 1 at a time: odd and unit batches take
+    other tile shapes), and swapping the two frames swaps the two flow directions."""
+    from emip_amd import nn_base
+    nn_base.set_default_dtype(torch.float32)
+    im1, im2 = synthetic_pair(16, seed=2024)
+    im1, im2 = im1.cuda(), im2.cuda()
+    with torch.no_grad():
+        mask, fw, bw = short_f32(im1, im2)
+        m3, fw3, bw3 = short_f32(im1[5:8], im2[5:8])
+        m1, fw1, bw1 = short_f32(im1[15:16], im2[15:16])
+        ms, fws, bws = short_f32(im2[5:8], im1[5:8])
+    assert (mask[5:8] - m3).abs().max().item() < 1e-3 and (mask[15:16] - m1).abs().max().item() < 1e-3
+    assert (fw[0][5:8] - fw3[0]).abs().max().item() < 0.5 and (bw[0][15:16] - bw1[0]).abs().max().item() < 0.5
+    # frame swap: the GMFlow stream is symmetric in its two inputs, so forward and backward flows trade places
+    assert (fws[0] - bw3[0]).abs().max().item() < 0.5 and (bws[0] - fw3[0]).abs().max().item() < 0.5
+    assert torch.isfinite(mask).all() and torch.isfinite(fw[0]).all()
+
+
+def test_bf16_bench_batch_matches_f32(model_args, short_sd, short_f32):
+    """the benchmarked configuration (16 pairs, bf16) against the f32 parity path on the same inputs: mask IoU"""
+    from emip_amd import nn_base
+    im1, im2 = synthetic_pair(16, seed=77)
+    im1, im2 = im1.cuda(), im2.cuda()
+    nn_base.set_default_dtype(torch.float32)
+    with torch.no_grad():
+        ref, _, _ = short_f32(im1, im2)
+    nn_base.set_default_dtype(torch.bfloat16)
+    try:
+        net = _net(model_args, short_sd)
+        with torch.no_grad():
+            out, _, _ = net(im1, im2)
+    finally:
+        nn_base.set_default_dtype(torch.float32)
+    a, b = out > 0, ref > 0
+    iou = ((a & b).sum().item() + 1e-9) / ((a | b).sum().item() + 1e-9)
+    err = (out - ref).abs().max().item() / (ref.abs().max().item() + 1e-6)
+    print(f"bf16 vs f32 at 16 pairs: IoU {iou:.4f}, relative logit error {err:.3f}")
+    assert iou > 0.97 and err < 0.08
