@@ -172,9 +172,10 @@ int emip_hybrid_e_loss(const float* pred, const float* mask, double* ws, float* 
 int emip_photometric_loss(const float* im, const float* rec, const float* mask, double* ws, float* out, int B, int C,
                           int H, int W, float weight, int accumulate, void* stream);
 
-/* ---- backward building blocks (training step, train.py:43-62; more to come) ------------------------------- */
+/* ---- backward kernels (training step, train.py:43-62: loss.backward() through the modules above) ------------ */
 
-/* Weight gradient of nn.Linear / 1x1 conv:  C[n][k] = sum_m A[m][n] * B[m][k]  (A = dY [M][N], B = X [M][K], both
+/* Weight gradient of nn.Linear / 1x1 conv (every Linear of lib/pvt_v2.py, PromptInteract.py, create_backbone.py:119):
+ * C[n][k] = sum_m A[m][n] * B[m][k]  (A = dY [M][N], B = X [M][K], both
  * as the forward leaves them in HBM), f32 output; M is split over workgroups and combined with f32 atomics. */
 int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc, int batch,
                  long bsA, long bsB, long bsC, int dtype, void* stream);
@@ -191,7 +192,8 @@ int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void*
                        float* dgamma, float* dbeta, int nparts, long part_stride, long M, int C, float eps, int dtype,
                        void* stream);
 
-/* Row softmax of the first L columns (columns L..ld-1 are written as 0): Y = softmax(X*scale + mask), mask = -100
+/* Backward of the softmax attentions (lib/pvt_v2.py:113-121; gmflow/transformer.py:46-105,503-533; matching.py:8-41).
+ * Row softmax of the first L columns (columns L..ld-1 are written as 0): Y = softmax(X*scale + mask), mask = -100
  * where gid_q[win][row] != gid_k[win][col] (rows are ordered [batch][win][period]); and its backward
  * dS = P * (dP - rowsum(P*dP)) * scale.  Used by the unfused attention backward (P is recomputed, never stored by fwd). */
 int emip_softmax_rows(const void* X, void* Y, long rows, int L, long ld, float scale, const int* gid_q, const int* gid_k,
@@ -207,17 +209,19 @@ int emip_transpose_pad(const void* X, long ldx, long bsx, void* Y, long bsy, int
 int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy, void* DZ, long lddz, long M, int C, int dtype,
                   void* stream);
 
-/* Depthwise 3x3 weight/bias gradient, ACCUMULATED into dW f32 [9][C] and db f32 [C] (db may be NULL). */
+/* Depthwise 3x3 weight/bias gradient (lib/pvt_v2.py:316-327; PromptInteract.py q/kv/ffn dwconv), ACCUMULATED into dW f32 [9][C] and db f32 [C] (db may be NULL). */
 int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, long lddy, float* dW, float* db, int B, int H, int Wd,
                          int C, int dtype, void* stream);
 
-/* Train-mode BatchNorm2d (+ReLU when OUT != NULL) backward.  X: pre-BN conv output, OUT: the forward output,
+/* Train-mode BatchNorm2d (+ReLU when OUT != NULL) backward (ConvBR, create_backbone.py:22-42; conv_corr, model.py:59-62).  X: pre-BN conv output, OUT: the forward output,
  * fsums: the forward's emip_chan_stats (groups = 1); dgamma/dbeta accumulated; ws: f32 [2*C]. */
 int emip_bn_train_bwd(const void* X, long ldx, const void* DY, long lddy, const void* OUT, long ldo, void* DX, long lddx,
                       const double* fsums, const float* gamma, float* dgamma, float* dbeta, float* ws, long rows, int C,
                       float eps, int dtype, void* stream);
 
-/* Adjoints of emip_bilinear / emip_bilinear_planar: scatter-add into an f32 channels-last accumulation buffer. */
+/* Adjoints of emip_bilinear (scatter-add) / emip_bilinear_planar (gather, no atomics) into an f32 channels-last
+ * accumulation buffer: backward of the decoder's nn.Upsample / F.interpolate (create_backbone.py:52,74-75) and of the
+ * train-mode x8 flow upsampling (gmflow.py:133-136). */
 int emip_bilinear_bwd(const void* DY, long lddy, float* DX, int B, int H, int Wd, int C, int Ho, int Wo,
                       int align_corners, float mul, int dtype, void* stream);
 int emip_bilinear_planar_bwd(const float* DY, float* DX, long ldx, int xc, int B, int H, int Wd, int C, int Ho, int Wo,
@@ -248,7 +252,8 @@ int emip_mlp_tail(const void* H, long ldh, const float* Wt, const float* bdw, co
                   const void* R, long ldr, void* Y, long ldy, int B, int Hh, int Ww, int Ch, int N, int dtype,
                   void* stream);
 
-/* Window gather (scatter != 0: the inverse): dst[(b*nwin+win)*Lp + t] = src[b][table[win][t]], t < L <= Lp -- the
+/* Backward of the swin window split / merge (gmflow/utils.py:5-51, transformer.py:76-101).
+ * Window gather (scatter != 0: the inverse): dst[(b*nwin+win)*Lp + t] = src[b][table[win][t]], t < L <= Lp -- the
  * dense (row-padded) batches the unfused window-attention backward works on.  Pad rows are not touched. */
 int emip_window_rows(const void* src, void* dst, const int* table, int B, int nwin, int L, int Lp, long n, int C,
                      long ld_full, long ld_win, int scatter, int dtype, void* stream);
@@ -262,11 +267,12 @@ int emip_act_fwd(const void* X, long ldx, void* Y, long ldy, long M, int C, int 
 int emip_relu_bwd(const void* Yo, long ldy, const void* DY, long lddy, void* DX, long lddx, long M, int C, int dtype,
                   void* stream);
 
-/* Backward of emip_convex_upsample: dlogits (576 channels) and dflow (f32, zero-filled inside). */
+/* Backward of emip_convex_upsample (gmflow.py:64-77): dlogits (576 channels) and dflow (f32, zero-filled inside). */
 int emip_convex_upsample_bwd(const void* logits, long ldl, const float* flow, const float* dY, void* dlogits, long lddl,
                              float* dflow, int N, int H, int Wd, int dtype, void* stream);
 
-/* Loss backward: hybrid_e_loss w.r.t. the logits (ws = the scratch filled by emip_hybrid_e_loss), the photometric
+/* Loss backward (loss/loss_pred.py:4-22; loss/loss_flow.py:35-49,96-131; loss/warp_utils.py:83-93):
+ * hybrid_e_loss w.r.t. the logits (ws = the scratch filled by emip_hybrid_e_loss), the photometric
  * loss w.r.t. the reconstruction (sums = scratch of emip_photometric_loss; abc f32 [3*B*C*H*W]), flow_warp w.r.t. the
  * flow.  gout: f32 [1] upstream gradient on the device. */
 int emip_hybrid_e_loss_bwd(const float* pred, const float* mask, double* ws, const float* gout, float* dpred, int B,
