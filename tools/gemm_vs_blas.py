@@ -13,6 +13,25 @@ def timeit(fn, iters=30):
     for _ in range(5):
         fn()
     torch.cuda.synchronize()
+    if os.environ.get("GRAPH"):          # replay 50 captured launches: host launch cost (~10 us per call) drops out
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(50):
+                fn()
+        g.replay()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(4):
+            g.replay()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / 200 * 1e3
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     for _ in range(iters):
@@ -24,11 +43,11 @@ def timeit(fn, iters=30):
 
 dev, dt = "cuda:0", torch.bfloat16
 lib = _lib.load()
-if os.environ.get("RING"):
-    _lib.call("emip_debug_set", 5, int(os.environ["RING"]))
+if os.environ.get("RESIDENT"):
+    _lib.call("emip_debug_set", 5, int(os.environ["RESIDENT"]))
 if os.environ.get("TILE"):
     _lib.call("emip_debug_set", 1, int(os.environ["TILE"]))
-shapes = [(15488, 1280, 320), (15488, 320, 1280), (15488, 320, 320), (15488, 640, 320), (61952, 512, 128),
+shapes = [tuple(int(v) for v in t.split('x')) for t in os.environ['SHAPES'].split(',')] if os.environ.get('SHAPES') else [(15488, 1280, 320), (15488, 320, 1280), (15488, 320, 320), (15488, 640, 320), (61952, 512, 128),
           (61952, 128, 512), (61952, 128, 128), (61952, 256, 128), (247808, 256, 64), (247808, 64, 256),
           (247808, 64, 64), (247808, 128, 64), (3872, 2048, 512), (3872, 512, 2048), (3872, 512, 512),
           (3872, 1024, 512), (61952, 1024, 256), (61952, 128, 1024), (8192, 8192, 8192)]
