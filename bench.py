@@ -23,24 +23,34 @@ PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICR
 F_ALG_PAIR_GFLOP = 270.63      # algorithmic forward FLOPs per frame pair
 
 
+PEAK_HBM_TBS = 8.0             # HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
 def _algo_flops(name, a):
-    """algorithmic FLOPs of one emip_gemm / emip_conv2d / emip_attention launch (zero-padded channels not counted)"""
+    """algorithmic FLOPs and algorithmic HBM bytes (every operand read once, every result written once, bf16 = 2 B) of
+    one emip_gemm / emip_conv2d / emip_attention launch; zero-padded channels are not counted"""
     if name == "emip_attention":
         batch, heads, nwin, Lq, Lk, D, DV = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
         dv = 2 if DV == 32 else DV                          # DV=32 carries a 2-channel value (flow / pixel grid)
         bkv = 64
-        return 2.0 * batch * heads * nwin * Lq * Lk * (D + dv), ("attn", D, DV, bkv)
+        z = batch * heads * nwin
+        byt = 2.0 * z * (Lq * D + Lk * D + Lk * dv) + (4.0 if a[-3] else 2.0) * z * Lq * dv
+        if a[4]:                                            # raw scores (the correlation volume) written out
+            byt += 2.0 * z * Lq * Lk
+        return 2.0 * z * Lq * Lk * (D + dv), ("attn", D, DV, bkv), byt
     if name == "emip_gemm":
         M, N, K, batch = a[6], a[7], a[8], a[16]
         lds_dma = (K % 64 == 0) and (a[9] % 64 == 0)         # bf16: dense GEMMs with whole K tiles use the LDS-DMA loop
         K = {344: 340}.get(K, K)
-        return 2.0 * M * N * K * batch, (M, N, batch, False, 3 if lds_dma else 1, a[8])
+        byt = 2.0 * batch * (M * K + N * K + M * N * (2 if a[5] else 1))
+        return 2.0 * M * N * K * batch, (M, N, batch, False, 3 if lds_dma else 1, a[8]), byt
     if name == "emip_conv2d":
         B, H, W, Cin, Cout, KH, KW, s, p = a[5], a[6], a[7], a[8], a[10], a[11], a[12], a[13], a[14]
         Ho, Wo = (H + 2 * p - KH) // s + 1, (W + 2 * p - KW) // s + 1
         cin = {8: 3, 136: 130}.get(Cin, Cin)
-        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin, (B * Ho * Wo, Cout, 1, True, 1, KH * KW * Cin)
-    return 0.0, None
+        byt = 2.0 * (B * H * W * cin + Cout * KH * KW * cin + B * Ho * Wo * Cout * (2 if a[4] else 1))
+        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin, (B * Ho * Wo, Cout, 1, True, 1, KH * KW * Cin), byt
+    return 0.0, None, 0.0
 
 
 def kernel_breakdown(net, im1, im2, splits=1):
@@ -68,17 +78,18 @@ def kernel_breakdown(net, im1, im2, splits=1):
     agg = {}
     for name, a, s, e in rec:
         ms = s.elapsed_time(e)
-        fl, tile = _algo_flops(name, a)
+        fl, tile, byt = _algo_flops(name, a)
         key = name
         if tile is not None and tile[0] == "attn":
             key = "attn_kernel<bf16,%d,%d,%d>" % tile[1:]
         elif tile is not None:
             t = lib.emip_gemm_tile(tile[0], tile[1], tile[2], tile[5])
             key = "gemm_kernel<bf16,%d,%d,%s,%d>" % (t // 1000, t % 1000, "conv" if tile[3] else "dense", tile[4])
-        d = agg.setdefault(key, [0.0, 0.0, 0])
+        d = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
         d[0] += ms
         d[1] += fl
         d[2] += 1
+        d[3] += byt
     return agg
 
 
@@ -332,8 +343,12 @@ def main():
         agg = kernel_breakdown(net, im1, im2, nsplit)
         kernels = {k: v for k, v in agg.items() if v[1] > 0}
         dom = max(kernels, key=lambda k: kernels[k][0])
-        ms, fl, cnt = kernels[dom]
-        achieved = fl / (ms * 1e-3) / 1e12
+        ms, fl, cnt, byt = kernels[dom]
+        tflops = fl / (ms * 1e-3) / 1e12
+        tbs = byt / (ms * 1e-3) / 1e12
+        # roofline side: arithmetic intensity of the launches of this symbol against the ridge point of the chip
+        ridge = PEAK_BF16_TFLOPS / PEAK_HBM_TBS                     # 312.5 FLOP/B
+        hbm_bound = (fl / max(byt, 1.0)) < ridge
         total_ms = sum(v[0] for v in agg.values())
         whole = kernel_breakdown(net, im1, im2, 1).get(dom) if nsplit > 1 else None   # same symbol, unsplit batch
         traffic = None                      # HBM bytes per launch from the committed rocprofv3 PMC passes, if any
@@ -351,8 +366,16 @@ def main():
                        "hipgraph": not args.no_graph, "concurrent_streams": 1 if args.no_graph else args.streams},
             "end_to_end": {"achieved_TFLOPs": round(value / world * F_ALG_PAIR_GFLOP / 1e3, 2),
                            "frac_of_bf16_mfma_peak": round(value / world * F_ALG_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "roofline": ({"bound": "hbm", "kernel": dom, "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_TBS * 1e3,
+                          "unit": "GB/s", "frac": round(tbs / PEAK_HBM_TBS, 4)} if hbm_bound else
+                         {"bound": "mfma", "kernel": dom, "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS,
+                          "unit": "TFLOP/s", "frac": round(tflops / PEAK_BF16_TFLOPS, 4)}),
+        }
+        out["roofline"].update({
+                         "traffic": traffic, "arithmetic_intensity_flop_per_byte": round(fl / max(byt, 1.0), 1),
+                         "ridge_flop_per_byte": round(ridge, 1), "achieved_TFLOPs": round(tflops, 2),
+                         "mfma_frac": round(tflops / PEAK_BF16_TFLOPS, 4),
+                         "algorithmic_bytes_per_launch": round(byt / cnt),
                          "launches": cnt, "avg_launch_us": round(ms / cnt * 1e3, 2),
                          "algorithmic_flops_per_launch": round(fl / cnt), "kernel_ms_per_step": round(ms, 3),
                          "share_of_step_kernel_time": round(ms / total_ms, 3),
@@ -361,9 +384,8 @@ def main():
                                  "replay; in the timed region %d such streams overlap (sum of isolated kernel time "
                                  "%.1f ms vs %.1f ms wall per step)" % (nsplit, total_ms, dt / args.steps * 1e3),
                          "same_kernel_unsplit_batch_TFLOPs": (round(whole[1] / (whole[0] * 1e-3) / 1e12, 2)
-                                                              if whole else None)},
-            "kernel_breakdown_ms": {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]},
-        }
+                                                              if whole else None)})
+        out["kernel_breakdown_ms"] = {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd)
         print(json.dumps(out), flush=True)
