@@ -286,6 +286,14 @@ int emip_flow_warp_bwd(const float* X, const float* flow, const float* dY, float
 /* out[c] += sum over rows of X[row][c] (bias gradients); out is f32 [C], accumulated into. */
 int emip_colsum(const void* X, long ldx, float* out, long rows, int C, int dtype, void* stream);
 
+/* ---- after the path ---------------------------------------------------- */
+
+/* Prediction post-processing of test.py:28-31 on the device: bilinear resize of the mask logits to the source frame
+ * size (align_corners=False), sigmoid, per-image min-max normalisation, x255, PIL 'F'->'L' conversion (clip, truncate).
+ * logits f32 [B][1][H][W] -> out u8 [B][Ho][Wo]; ws: int [2*B] scratch.  No intermediate tensor, no host sync. */
+int emip_postprocess_mask(const float* logits, unsigned char* out, int* ws, int B, int H, int W, int Ho, int Wo,
+                          void* stream);
+
 /* ---- optimizer ----------------------------------------------------------------------------------- */
 
 /* Element-wise gradient clamp to +-clip (utils/utils.py:1-11; clip <= 0 disables) fused with one AdamW step

@@ -545,3 +545,18 @@ def hybrid_e_loss(pred, mask):
     union = (p + mask).sum(dim=(2, 3))
     wiou = 1.0 - (inter + 1 + 1e-8) / (union - inter + 1 + 1e-8)
     return (wbce + eloss + wiou).mean()
+
+
+# --------------------------------------------------------------------------
+# After the path
+
+
+def postprocess_mask(mask, shape):
+    """The reference's prediction post-processing, statement for statement: test.py:28-31 (bilinear resize to the source
+    frame, sigmoid, per-image min-max, x255, PIL 'F' -> 'L').  mask [1,1,H,W] f32 -> uint8 [Ho,Wo] numpy."""
+    import numpy as np
+    from PIL import Image
+    out = F.interpolate(mask, size=tuple(shape), mode="bilinear", align_corners=False)
+    out = out.sigmoid().data.cpu().numpy().squeeze()
+    out = (out - out.min()) / (out.max() - out.min() + 1e-8)
+    return np.asarray(Image.fromarray(out * 255).convert("L"))

@@ -103,3 +103,19 @@ def test_long_stream(golden, long_sd):
                 assert mk.shape[3] == int(g[f"T_{i}"])
                 assert np.allclose(_stats(mk), g[f"k_{i}_stats"], rtol=1e-4, atol=1e-4)
             _close(m[:, :, ::2, ::2], g[f"mask_{i}"], 2e-3, name=f"long mask {i}")
+
+
+def test_postprocess_restatement_known_answers():
+    """oracle.postprocess_mask (test.py:28-31): identity resize of a logit ramp -> min-max normalised sigmoid, x255,
+    truncated like PIL's F -> L conversion"""
+    import numpy as np
+    import torch
+    from oracle import emip_oracle as O
+    x = torch.linspace(-6, 6, 16 * 16).view(1, 1, 16, 16)
+    out = O.postprocess_mask(x, (16, 16))
+    p = torch.sigmoid(x).numpy().squeeze()
+    want = np.floor((p - p.min()) / (p.max() - p.min() + 1e-8) * 255).astype(np.uint8)
+    assert out.dtype == np.uint8 and out.shape == (16, 16)
+    assert np.abs(out.astype(int) - want.astype(int)).max() <= 1 and out.min() == 0 and out.max() >= 254
+    up = O.postprocess_mask(x, (40, 24))
+    assert up.shape == (40, 24) and up[0, 0] == 0 and up[-1, -1] >= 254
