@@ -16,7 +16,7 @@ _CTYPES = {
     "const float*": ctypes.c_void_p, "float*": ctypes.c_void_p,
     "const double*": ctypes.c_void_p, "double*": ctypes.c_void_p,
     "const int*": ctypes.c_void_p, "int*": ctypes.c_void_p,
-    "long long*": ctypes.c_void_p, "unsigned char*": ctypes.c_void_p,
+    "long long*": ctypes.c_void_p, "unsigned char*": ctypes.c_void_p, "const unsigned char*": ctypes.c_void_p,
     "int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
 }
 

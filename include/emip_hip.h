@@ -294,6 +294,16 @@ int emip_colsum(const void* X, long ldx, float* out, long rows, int C, int dtype
 int emip_postprocess_mask(const float* logits, unsigned char* out, int* ws, int B, int H, int W, int Ho, int Wo,
                           void* stream);
 
+/* Input preparation of dataset/dataset.py:257-260,76-79 on the device:
+ * transforms.Resize((Ho, Wo)) on the decoded 8-bit RGB frame -- Pillow's two-pass 8-bit resampling with 22-bit
+ * quantised triangle coefficients, BIT-EXACT -- then ToTensor (/255) and Normalize ((x - mean) / std) in IEEE f32.
+ * img u8 [B][H0][W0][3] (byte strides img_bs / img_rs) -> out f32 [B][3][Ho][Wo]; out_u8 (may be NULL) u8 [B][Ho][Wo][3];
+ * tmp u8 [B][H0][Wo][3] scratch; kh [Wo][ksh], bh [Wo][2] (first tap, tap count), kv [Ho][ksv], bv [Ho][2]: the
+ * coefficient tables (device ints) built by the host for this (H0, W0); mean3 / std3: HOST pointers to 3 floats. */
+int emip_preprocess_rgb(const unsigned char* img, long img_bs, long img_rs, int B, int H0, int W0, const int* kh,
+                        const int* bh, int ksh, const int* kv, const int* bv, int ksv, unsigned char* tmp, float* out,
+                        unsigned char* out_u8, int Ho, int Wo, const float* mean3, const float* std3, void* stream);
+
 /* ---- optimizer ----------------------------------------------------------------------------------- */
 
 /* Element-wise gradient clamp to +-clip (utils/utils.py:1-11; clip <= 0 disables) fused with one AdamW step

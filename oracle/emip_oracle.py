@@ -560,3 +560,18 @@ def postprocess_mask(mask, shape):
     out = out.sigmoid().data.cpu().numpy().squeeze()
     out = (out - out.min()) / (out.max() - out.min() + 1e-8)
     return np.asarray(Image.fromarray(out * 255).convert("L"))
+
+
+def preprocess_rgb(img_u8, size=352):
+    """The reference's per-frame transform (dataset.py:257-260 / :76-79): torchvision Resize((size, size)) on the PIL
+    image (= PIL.Image.resize with BILINEAR, torchvision/transforms/_functional_pil.py), ToTensor (u8 -> f32 / 255, CHW)
+    and Normalize(ImageNet mean, std).  torchvision itself is not installed here; Pillow, which does the arithmetic, is.
+    img_u8: numpy uint8 [H,W,3] -> (f32 tensor [3,size,size], resized uint8 [size,size,3])"""
+    import numpy as np
+    from PIL import Image
+    pil = Image.fromarray(img_u8, "RGB").resize((size, size), Image.BILINEAR)
+    arr = np.asarray(pil)
+    t = torch.from_numpy(arr.copy()).permute(2, 0, 1).contiguous().to(dtype=torch.float32).div(255)
+    mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float32).view(3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float32).view(3, 1, 1)
+    return t.sub_(mean).div_(std), arr
