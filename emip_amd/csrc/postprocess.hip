@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void post_minmax_kernel(const float* __restric
 __device__ __forceinline__ float sigmoid_f32(float x) { return 1.f / (1.f + expf(-x)); }
 
 __global__ __launch_bounds__(256) void post_write_kernel(const float* __restrict__ logits, const int* __restrict__ ws,
-                                                         unsigned char* __restrict__ out, int H, int W, int Ho, int Wo) {
+                                                         unsigned char* __restrict__ out, float* __restrict__ outf, int H,
+                                                         int W, int Ho, int Wo) {
     const int b = blockIdx.y;
     const float* src = logits + (long)b * H * W;
     const float pmin = sigmoid_f32(ord2f(ws[2 * b])), pmax = sigmoid_f32(ord2f(ws[2 * b + 1]));
@@ -78,8 +79,12 @@ __global__ __launch_bounds__(256) void post_write_kernel(const float* __restrict
     const long n = (long)Ho * Wo;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float p = sigmoid_f32(resized_logit(src, H, W, Ho, Wo, (int)(i / Wo), (int)(i % Wo)));
-        const float v = (p - pmin) / den * 255.f;
-        out[(long)b * n + i] = (unsigned char)(v <= 0.f ? 0.f : (v >= 255.f ? 255.f : v));     // clip, truncate
+        const float r = (p - pmin) / den;
+        if (outf) outf[(long)b * n + i] = r;                     // the float map train.py:125-127 feeds to the metrics
+        if (out) {
+            const float v = r * 255.f;
+            out[(long)b * n + i] = (unsigned char)(v <= 0.f ? 0.f : (v >= 255.f ? 255.f : v));     // clip, truncate
+        }
     }
 }
 
@@ -93,6 +98,18 @@ extern "C" int emip_postprocess_mask(const float* logits, unsigned char* out, in
     hipLaunchKernelGGL(post_init_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, B);
     dim3 grid(grid_for((long)Ho * Wo, 256 * 4), B);
     hipLaunchKernelGGL(post_minmax_kernel, grid, dim3(256), 0, s, logits, ws, H, W, Ho, Wo);
-    hipLaunchKernelGGL(post_write_kernel, grid, dim3(256), 0, s, logits, ws, out, H, W, Ho, Wo);
+    hipLaunchKernelGGL(post_write_kernel, grid, dim3(256), 0, s, logits, ws, out, (float*)nullptr, H, W, Ho, Wo);
+    return emip_launch_status();
+}
+
+// same resize + sigmoid + min-max, written as the f32 map in [0, 1] (train.py:125-127: the input of the validation metrics)
+extern "C" int emip_postprocess_mask_f32(const float* logits, float* out, int* ws, int B, int H, int W, int Ho, int Wo,
+                                         void* stream) {
+    EMIP_REQUIRE(logits && out && ws && B > 0 && B < 65536 && H > 0 && W > 0 && Ho > 0 && Wo > 0);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(post_init_kernel, dim3((B + 63) / 64), dim3(64), 0, s, ws, B);
+    dim3 grid(grid_for((long)Ho * Wo, 256 * 4), B);
+    hipLaunchKernelGGL(post_minmax_kernel, grid, dim3(256), 0, s, logits, ws, H, W, Ho, Wo);
+    hipLaunchKernelGGL(post_write_kernel, grid, dim3(256), 0, s, logits, ws, (unsigned char*)nullptr, out, H, W, Ho, Wo);
     return emip_launch_status();
 }

@@ -294,6 +294,15 @@ int emip_colsum(const void* X, long ldx, float* out, long rows, int C, int dtype
 int emip_postprocess_mask(const float* logits, unsigned char* out, int* ws, int B, int H, int W, int Ho, int Wo,
                           void* stream);
 
+int emip_postprocess_mask_f32(const float* logits, float* out, int* ws, int B, int H, int W, int Ho, int Wo,
+                              void* stream);   /* same, as the f32 map in [0,1] that train.py:125-127 hands to the metrics */
+
+/* Validation metrics of train.py:129-137: the pixel sums behind MAE and S-measure
+ * (eval/metrics.py:20-25,100-102,120-213) for one frame.  pred f32 [H][W] (the map passed to `step(pred=...)`),
+ * gt f32 [H][W] in 0..255; acc f64 [40] (layout in csrc/eval_metrics.hip), ws int [2].  Finalised on the host from the
+ * 40 doubles (emip_amd/eval_metrics.py). */
+int emip_eval_frame(const float* pred, const float* gt, double* acc, int* ws, int H, int W, void* stream);
+
 /* Input preparation of dataset/dataset.py:257-260,76-79 on the device:
  * transforms.Resize((Ho, Wo)) on the decoded 8-bit RGB frame -- Pillow's two-pass 8-bit resampling with 22-bit
  * quantised triangle coefficients, BIT-EXACT -- then ToTensor (/255) and Normalize ((x - mean) / std) in IEEE f32.

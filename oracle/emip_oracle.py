@@ -575,3 +575,65 @@ def preprocess_rgb(img_u8, size=352):
     mean = torch.tensor([0.485, 0.456, 0.406], dtype=torch.float32).view(3, 1, 1)
     std = torch.tensor([0.229, 0.224, 0.225], dtype=torch.float32).view(3, 1, 1)
     return t.sub_(mean).div_(std), arr
+
+
+# --------------------------------------------------------------------------
+# Validation metrics (eval/metrics.py), array-level restatement in numpy
+
+
+def metric_prepare(pred, gt):
+    """_prepare_data, eval/metrics.py:20-25"""
+    gt = gt > 128
+    pred = pred / 255
+    if pred.max() != pred.min():
+        pred = (pred - pred.min()) / (pred.max() - pred.min())
+    return pred, gt
+
+
+def metric_mae(pred, gt):
+    """MAE.cal_mae, eval/metrics.py:100-102"""
+    import numpy as np
+    pred, gt = metric_prepare(pred, gt)
+    return float(np.mean(np.abs(pred - gt)))
+
+
+def metric_smeasure(pred, gt, alpha=0.5):
+    """Smeasure.cal_sm and helpers, eval/metrics.py:120-213"""
+    import numpy as np
+    eps = np.spacing(1)
+    pred, gt = metric_prepare(pred, gt)
+    y = np.mean(gt)
+    if y == 0:
+        return float(1 - np.mean(pred))
+    if y == 1:
+        return float(np.mean(pred))
+
+    def s_object(p, g):
+        x = np.mean(p[g == 1])
+        sigma = np.std(p[g == 1], ddof=1)
+        return 2 * x / (np.power(x, 2) + 1 + sigma + eps)
+
+    obj = y * s_object(pred * gt, gt) + (1 - y) * s_object((1 - pred) * (1 - gt), 1 - gt)
+    h, w = gt.shape
+    area = np.sum(gt)
+    cx = int(np.round(np.sum(np.sum(gt, axis=0) * np.arange(w)) / area)) + 1
+    cy = int(np.round(np.sum(np.sum(gt, axis=1) * np.arange(h)) / area)) + 1
+
+    def ssim(p, g):
+        n = p.shape[0] * p.shape[1]
+        x, yv = np.mean(p), np.mean(g)
+        sx = np.sum((p - x) ** 2) / (n - 1)
+        sy = np.sum((g - yv) ** 2) / (n - 1)
+        sxy = np.sum((p - x) * (g - yv)) / (n - 1)
+        a = 4 * x * yv * sxy
+        b = (x ** 2 + yv ** 2) * (sx + sy)
+        if a != 0:
+            return a / (b + eps)
+        return 1 if (a == 0 and b == 0) else 0
+
+    n = h * w
+    w1, w2, w3 = cx * cy / n, cy * (w - cx) / n, (h - cy) * cx / n
+    w4 = 1 - w1 - w2 - w3
+    region = (w1 * ssim(pred[0:cy, 0:cx], gt[0:cy, 0:cx]) + w2 * ssim(pred[0:cy, cx:w], gt[0:cy, cx:w]) +
+              w3 * ssim(pred[cy:h, 0:cx], gt[cy:h, 0:cx]) + w4 * ssim(pred[cy:h, cx:w], gt[cy:h, cx:w]))
+    return float(max(0, alpha * obj + (1 - alpha) * region))

@@ -1,0 +1,53 @@
+"""Validation metrics (eval/metrics.py MAE / Smeasure): oracle restatement and the device reductions against values the
+reference's own classes produced (tests/golden/metrics_micro.npz, oracle/make_golden_metrics.py)."""
+import numpy as np
+import pytest
+import torch
+
+
+def _cases(golden):
+    g = golden("metrics_micro.npz")
+    return [(g["pred%d" % i], g["gt%d" % i].astype(np.float32), float(g["mae%d" % i]), float(g["sm%d" % i]))
+            for i in range(int(g["n"]))]
+
+
+def test_oracle_metrics_match_reference_values(golden):
+    from oracle import emip_oracle as O
+    for pred, gt, mae, sm in _cases(golden):
+        assert abs(O.metric_mae(pred, gt) - mae) < 1e-7
+        assert abs(O.metric_smeasure(pred, gt) - sm) < 1e-7
+
+
+@pytest.mark.gpu
+def test_device_metrics_match_reference_values(golden):
+    from emip_amd.eval_metrics import MAE, FrameMetrics, Smeasure
+    a, b, both = MAE(), Smeasure(), FrameMetrics()
+    want_mae, want_sm = [], []
+    for pred, gt, mae, sm in _cases(golden):
+        p, g = torch.from_numpy(pred).cuda(), torch.from_numpy(gt).cuda()
+        a.step(pred=p, gt=g)
+        b.step(pred=p, gt=g)
+        both.step(pred=p, gt=g)
+        assert abs(a.maes[-1] - mae) < 2e-6, (a.maes[-1], mae)
+        assert abs(b.sms[-1] - sm) < 2e-5, (b.sms[-1], sm)
+        want_mae.append(mae)
+        want_sm.append(sm)
+    assert abs(a.get_results()["mae"] - np.mean(want_mae)) < 2e-6
+    assert abs(b.get_results()["sm"] - np.mean(want_sm)) < 2e-5
+    r = both.get_results()
+    assert abs(r["mae"] - np.mean(want_mae)) < 2e-6 and abs(r["sm"] - np.mean(want_sm)) < 2e-5
+
+
+@pytest.mark.gpu
+def test_logits_to_pred_matches_reference_steps():
+    """train.py:125-127 (upsample to the gt size, sigmoid, min-max) on the device vs torch / numpy on the host"""
+    from emip_amd.eval_metrics import logits_to_pred
+    g = torch.Generator().manual_seed(3)
+    logits = torch.nn.functional.interpolate(torch.randn(1, 1, 11, 11, generator=g) * 3, size=(352, 352), mode="bilinear",
+                                             align_corners=True).contiguous()
+    shape = (480, 854)
+    res = torch.nn.functional.interpolate(logits, size=shape, mode="bilinear", align_corners=False)
+    res = res.sigmoid().numpy().squeeze()
+    res = (res - res.min()) / (res.max() - res.min() + 1e-8)
+    out = logits_to_pred(logits.cuda(), shape)[0].cpu().numpy()
+    assert np.abs(out - res).max() < 2e-6
