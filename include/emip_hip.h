@@ -252,6 +252,12 @@ int emip_mlp_tail(const void* H, long ldh, const float* Wt, const float* bdw, co
                   const void* R, long ldr, void* Y, long ldy, int B, int Hh, int Ww, int Ch, int N, int dtype,
                   void* stream);
 
+/* Fused head of the PVTv2 Mlp (lib/pvt_v2.py:45-54,316-327): G = GELU(dwconv3x3(X W1^T + b1) + bdw), X [B][H][W][C]
+ * channels-last (the LayerNorm-ed tokens), W1 [Ch][C], Wt the depthwise weights [9][Ch] (f32), G [B][H][W][Ch].
+ * The fc1 output stays in LDS (band of image rows x 128-byte channel slab per workgroup); fc2 reads G via emip_gemm. */
+int emip_mlp_head(const void* X, long ldx, const void* W1, const float* b1, const float* Wt, const float* bdw, void* G,
+                  long ldg, int B, int H, int W, int C, int Ch, int dtype, void* stream);
+
 /* Backward of the swin window split / merge (gmflow/utils.py:5-51, transformer.py:76-101).
  * Window gather (scatter != 0: the inverse): dst[(b*nwin+win)*Lp + t] = src[b][table[win][t]], t < L <= Lp -- the
  * dense (row-padded) batches the unfused window-attention backward works on.  Pad rows are not touched. */

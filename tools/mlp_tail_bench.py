@@ -37,5 +37,11 @@ for B in (8, 32):
         u_dw = timeit(lambda: ops.dwconv3x3(h, wt, bd, act=ops.ACT_GELU, out=t))
         u_g = timeit(lambda: ops.gemm(t, w2, bias=b2, res=res, out=o))
         u_f = timeit(lambda: ops.mlp_tail(h, wt, bd, w2, b2, res, out=o))
-        print("B%2d %3dx%-3d C%3d Ch%4d: dwconv %6.1f + fc2 %6.1f = %6.1f us | fused %6.1f us" % (
-            B, H, H, C, Ch, u_dw, u_g, u_dw + u_g, u_f))
+        x = torch.randn(B, H, H, C, device=dev).to(dt)
+        w1 = (torch.randn(Ch, C, device=dev) / C ** 0.5).to(dt)
+        b1 = torch.randn(Ch, device=dev)
+        u_fc1 = timeit(lambda: ops.gemm(x, w1, bias=b1, out=h))
+        u_head = timeit(lambda: ops.mlp_head(x, w1, b1, wt, bd, out=t))
+        print("B%2d %3dx%-3d C%3d Ch%4d: dwconv %6.1f + fc2 %6.1f = %6.1f us | tail fused %6.1f us || fc1 %6.1f + dwconv "
+              "%6.1f = %6.1f us | head fused %6.1f us" % (B, H, H, C, Ch, u_dw, u_g, u_dw + u_g, u_f, u_fc1, u_dw,
+                                                         u_fc1 + u_dw, u_head))
