@@ -140,10 +140,14 @@ def main_train(args):
     from emip_amd import dist as edist
     world, rank, local = edist.env_world()
     dist = None
+    # EMIP_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("EMIP_DIST_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
-        dist = edist.init("nccl")
+        dist = edist.init(backend)
     dev = torch.device("cuda", local)
+    red_dev = dev if backend == "nccl" else "cpu"
     from emip_amd import _lib, nn_base
     from emip_amd.dp import GradReducer, broadcast_parameters
     from emip_amd.filler import state_dict_from_manifest, synthetic_gt, synthetic_pair
@@ -179,7 +183,7 @@ def main_train(args):
     for _ in range(args.steps):
         loss = train_step(net, opt, red, im1, im2, gt)
     barrier()
-    dt = edist.max_over_ranks(time.perf_counter() - t0, dev)
+    dt = edist.max_over_ranks(time.perf_counter() - t0, red_dev)
     if rank == 0:
         print(json.dumps({
             "metric": "frame_pairs_per_sec_352x352_emip_short_train_step", "value": round(world * B * args.steps / dt, 3),
@@ -203,10 +207,14 @@ def main_long(args):
     from emip_amd import dist as edist
     world, rank, local = edist.env_world()
     dist = None
+    # EMIP_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices)
+    backend = os.environ.get("EMIP_DIST_BACKEND", "nccl")
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
-        dist = edist.init("nccl")
+        dist = edist.init(backend)
     dev = torch.device("cuda", local)
+    red_dev = dev if backend == "nccl" else "cpu"
     from emip_amd import _lib, nn_base
     from emip_amd.filler import state_dict_from_manifest, synthetic_pair
     from emip_amd.model.EMIP_long.model_long import Model_long
@@ -241,7 +249,7 @@ def main_long(args):
     for _ in range(args.steps):
         step()
     barrier()
-    dt = edist.max_over_ranks(time.perf_counter() - t0, dev)
+    dt = edist.max_over_ranks(time.perf_counter() - t0, red_dev)
     if rank == 0:
         print(json.dumps({
             "metric": "stream_frames_per_sec_352x352_emip_long", "value": round(world * S * args.steps / dt, 3),
@@ -276,10 +284,13 @@ def main():
     from emip_amd import dist as edist
     world, rank, local = edist.env_world()
     dist = None
+    backend = os.environ.get("EMIP_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo = rehearsal on a smaller box
+    local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     if world > 1:
-        dist = edist.init("nccl")          # "nccl" is RCCL on ROCm; only barriers / the timing max-reduce use it
+        dist = edist.init(backend)         # only barriers / the timing max-reduce use it
     dev = torch.device("cuda", local)
+    red_dev = dev if backend == "nccl" else "cpu"
 
     from emip_amd import _lib, nn_base
     from emip_amd.filler import state_dict_from_manifest, synthetic_pair
@@ -333,7 +344,7 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
-    dt = edist.max_over_ranks(dt, dev)
+    dt = edist.max_over_ranks(dt, red_dev)
 
     out = None
     if rank == 0:
