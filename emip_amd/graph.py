@@ -75,3 +75,84 @@ class GraphedShort:
         self.load(image1, image2)
         self.replay()
         return self.outputs()
+
+
+class _LongPart:
+    def __init__(self, net, streams, size, device, warmup):
+        T, n, C = net.WINDOW, (size // 8) ** 2, 128
+        self.f0 = torch.zeros(streams, 3, size, size, device=device)
+        self.f1 = torch.zeros(streams, 3, size, size, device=device)
+        self.mem_k = torch.zeros(streams, T, n, C, dtype=net.cdtype, device=device)
+        self.mem_v = torch.zeros(streams, T, n, C, dtype=net.cdtype, device=device)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                net.step_cl(self.f0, self.f1, self.mem_k, self.mem_v)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph):
+            self.mask, k, v = net.step_cl(self.f0, self.f1, self.mem_k, self.mem_v)
+            self.mem_k.copy_(k)            # the window slides inside the graph: the next replay reads the new memory
+            self.mem_v.copy_(v)
+
+
+class GraphedLong:
+    """Steady-state EMIP-long step (memory window full, model_long.py:105-107) for `streams` independent video streams,
+    replayed as hipGraphs with the streams split over concurrent HIP streams like GraphedShort.  The memory lives in
+    static channels-last buffers that each replay updates in place; `seed_memory` fills them from the reference-layout
+    tensors `Model_long.forward` returns."""
+
+    def __init__(self, net, streams, size=352, device="cuda:0", warmup=2, splits=4):
+        while splits > 1 and streams % splits:
+            splits -= 1
+        self.net, self.nstreams, self.splits = net, streams, splits
+        self.parts = [_LongPart(net, streams // splits, size, device, warmup) for _ in range(splits)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(splits)]
+        for p in self.parts:
+            p.graph.replay()
+            torch.cuda.synchronize()
+
+    def seed_memory(self, memory_k, memory_v):
+        """memory_k / memory_v: [S,1,128,5,44,44] (the reference layout) -> the static channels-last buffers"""
+        mk, mv = self.net._mem_from_ref(memory_k), self.net._mem_from_ref(memory_v)
+        n = self.nstreams // self.splits
+        for i, p in enumerate(self.parts):
+            p.mem_k.copy_(mk[i * n:(i + 1) * n])
+            p.mem_v.copy_(mv[i * n:(i + 1) * n])
+
+    def load(self, frames0, frames1):
+        n = self.nstreams // self.splits
+        for i, p in enumerate(self.parts):
+            p.f0.copy_(frames0[i * n:(i + 1) * n])
+            p.f1.copy_(frames1[i * n:(i + 1) * n])
+
+    def replay(self):
+        cur = torch.cuda.current_stream()
+        for p, s in zip(self.parts, self.streams):
+            s.wait_stream(cur)
+            with torch.cuda.stream(s):
+                p.graph.replay()
+        for s in self.streams:
+            cur.wait_stream(s)
+
+    def replay_free(self):
+        for p, s in zip(self.parts, self.streams):
+            with torch.cuda.stream(s):
+                p.graph.replay()
+
+    def masks(self):
+        return torch.cat([p.mask for p in self.parts], 0)
+
+    def memory(self):
+        """current memory in the reference layout [S,1,128,5,44,44] (f32)"""
+        k = torch.cat([p.mem_k for p in self.parts], 0)
+        v = torch.cat([p.mem_v for p in self.parts], 0)
+        h = w = int(round(k.shape[2] ** 0.5))
+        return self.net._mem_to_ref(k, h, w), self.net._mem_to_ref(v, h, w)
+
+    def __call__(self, frames0, frames1):
+        self.load(frames0, frames1)
+        self.replay()
+        return self.masks()

@@ -61,9 +61,26 @@ class Model_long(EmipModule):
             raise NotImplementedError("emip_amd Model_long: run forward under torch.no_grad() (inference build)")
         st = self.short_term
         S = frames0.shape[0]
-        mask, _ = st.run(frames0, frames1)
         if index == 0:
+            mask, _ = st.run(frames0, frames1)
             return mask, None, None
+        mk = mv = None
+        if not (index == 1 or memory_k is None):
+            mk, mv = self._lookup(memory_k, memory_v)
+        mask_long, keys, values = self.step_cl(frames0, frames1, mk, mv)
+        h = w = int(round(keys.shape[2] ** 0.5))
+        ref_k, ref_v = self._mem_to_ref(keys, h, w), self._mem_to_ref(values, h, w)
+        object.__setattr__(self, "_mem_cache", ((ref_k.data_ptr(), ref_k._version, tuple(ref_k.shape)),
+                                                (ref_v.data_ptr(), ref_v._version, tuple(ref_v.shape)), keys, values))
+        return mask_long, ref_k, ref_v
+
+    def step_cl(self, frames0, frames1, mem_k, mem_v):
+        """One step on channels-last memory (no layout conversion, no host logic beyond shapes): frames [S,3,H,W],
+        mem_k / mem_v [S,T,h*w,128] or None -> (mask [S,1,H,W], keys, values [S,min(T+1,5),h*w,128]).
+        With a full window the shapes are static, which is what emip_amd.graph.GraphedLong captures."""
+        st = self.short_term
+        S = frames0.shape[0]
+        st.run(frames0, frames1)
         L = st.last
         fea, cc = L["fea"], L["conv_corr"]
         h, w = fea[0].shape[1:3]
@@ -71,21 +88,16 @@ class Model_long(EmipModule):
         f2_3 = st.dr3.run(fea[2][S:])
         pk, pv = self.LTM.memorize_cl(fea[0][:S], cc)                  # [S,h,w,128] each
         pk, pv = pk.view(S, 1, h * w, -1), pv.view(S, 1, h * w, -1)
-        if index == 1 or memory_k is None:
+        if mem_k is None:
             keys, values = pk, pv
         else:
-            mk, mv = self._lookup(memory_k, memory_v)
-            keys = torch.cat([mk, pk], 1)[:, -self.WINDOW:].contiguous()
-            values = torch.cat([mv, pv], 1)[:, -self.WINDOW:].contiguous()
+            keys = torch.cat([mem_k, pk], 1)[:, -self.WINDOW:].contiguous()
+            values = torch.cat([mem_v, pv], 1)[:, -self.WINDOW:].contiguous()
         mem = self.LTM.segment_cl(fea[0][S:], keys, values)             # [S,h,w,256]
         mem = self.long_dr.run(mem)
         fl = self.injector1.run(fea[0][S:], mem)
         fl = self.dr1.run(fl)
-        mask_long = self.decoder.run(f2_3, f2_2, fl)
-        ref_k, ref_v = self._mem_to_ref(keys, h, w), self._mem_to_ref(values, h, w)
-        object.__setattr__(self, "_mem_cache", ((ref_k.data_ptr(), ref_k._version, tuple(ref_k.shape)),
-                                                (ref_v.data_ptr(), ref_v._version, tuple(ref_v.shape)), keys, values))
-        return mask_long, ref_k, ref_v
+        return self.decoder.run(f2_3, f2_2, fl), keys, values
 
     def forward(self, frame0, frame1, index, memory_k, memory_v):
         return self.forward_streams(frame0.unsqueeze(0), frame1.unsqueeze(0), index, memory_k, memory_v)

@@ -78,3 +78,24 @@ def test_memory_fed_back_as_fresh_tensor(long_net):
         _, mk2, mv2 = long_net(seq[0], seq[1], 1, None, None)
         m2, _, _ = long_net(seq[1], seq[2], 2, mk2.clone(), mv2.clone())
     assert (m1 - m2).abs().max().item() < 1e-3   # run-to-run jitter of the f32-atomic Gram accumulation
+
+
+def test_graphed_steady_state_matches_eager(long_net):
+    """hipGraph replay of the steady-state step (window full, memory sliding inside the graph) == eager forward_streams"""
+    from emip_amd.graph import GraphedLong
+    a, b = _seq(500), _seq(77)
+    f = lambda i: (torch.stack([a[i - 1], b[i - 1]]), torch.stack([a[i], b[i]]))
+    with torch.no_grad():
+        mk = mv = None
+        for i in range(1, 6):                                   # fill the 5-frame window eagerly
+            m, mk, mv = long_net.forward_streams(*f(i), i, mk, mv)
+        assert mk.shape[3] == 5
+        runner = GraphedLong(long_net, 2, splits=2)
+        runner.seed_memory(mk, mv)
+        for i in (6, 7):
+            ref, mk, mv = long_net.forward_streams(*f(i), i, mk, mv)
+            out = runner(*f(i))
+            torch.cuda.synchronize()
+            assert (out - ref).abs().max().item() < 1e-3
+            gk, gv = runner.memory()
+            assert (gk - mk).abs().max().item() < 1e-3 and (gv - mv).abs().max().item() < 1e-3
