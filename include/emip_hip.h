@@ -55,6 +55,7 @@ int emip_gemm_tile(long M, long N, long batch, long K);
 
 /* Tuning knob for experiments (not part of the drop-in contract): key 0 = LDS buffers of the GEMM main loop. */
 int emip_debug_set(int key, int value);
+int emip_debug_set_head(int variant);           /* emip_mlp_head tiling: 0 row bands, 2 8x8 patches, 4 14x14 patches */
 int emip_debug_set_tn(int target_workgroups);   /* 0 = heuristic split count of emip_gemm_tn (tuning only) */
 
 /* NHWC convolution as implicit GEMM, weights packed [Cout][KH][KW][Cin], same epilogue.
