@@ -351,10 +351,11 @@ def test_mlp_tail_matches_unfused(dt, tol, B, H, W, C, ratio):
     assert torch.equal(y2, y)
 
 
+@pytest.mark.parametrize("variant", [0, 2, 4])
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("B,H,W,C,ratio", [(2, 11, 11, 512, 4), (3, 22, 22, 320, 4), (2, 44, 44, 128, 4), (1, 88, 88, 64, 4),
                                            (2, 7, 5, 64, 2), (1, 30, 16, 128, 1)])
-def test_mlp_head_matches_unfused(dt, tol, B, H, W, C, ratio):
+def test_mlp_head_matches_unfused(dt, tol, B, H, W, C, ratio, variant):
     """fused fc1 + dwconv3x3 + GELU == torch fp32 on the same (rounded) operands; band splitting with halo rows included"""
     from emip_amd import ops
     g = torch.Generator().manual_seed(B * 100 + C + H)
@@ -372,6 +373,11 @@ def test_mlp_head_matches_unfused(dt, tol, B, H, W, C, ratio):
     ref = ref.permute(0, 2, 3, 1)
     dev = "cuda:0"
     wt = wd.reshape(Ch, 9).t().contiguous().to(dev)
-    y = ops.mlp_head(x.to(dt).to(dev), w1.to(dt).to(dev).contiguous(), b1.to(dev), wt, bd.to(dev))
+    from emip_amd import _lib
+    _lib.call("emip_debug_set_head", variant)            # 0 row bands, 2 / 4 patch tilings
+    try:
+        y = ops.mlp_head(x.to(dt).to(dev), w1.to(dt).to(dev).contiguous(), b1.to(dev), wt, bd.to(dev))
+    finally:
+        _lib.call("emip_debug_set_head", 0)
     err = (y.float().cpu() - ref).abs().max().item()
     assert err < tol * max(1.0, ref.abs().max().item()), err
