@@ -629,3 +629,42 @@ class DropPathAddFn(Function):
         db = torch.empty_like(dy)
         ops.colscale_add(dy, dy, scale - 1.0, scale.shape[1], ctx.rps, db)        # dy + (s - 1) dy = s dy
         return dy, db, None, None
+
+
+class MemoryReadFn(Function):
+    """EMIP-long memory read (LTM.py:49-68): softmax over the T*n stored positions of K_mem^T k_q / sqrt(C), times V_mem.
+    q [S,n,C], keys / values [S,T*n,C] -> [S,n,C].  Backward: unfused formulation on the rectangular score matrix; only
+    the rows of keys / values that belong to the current frame carry gradient in train_long.py (the older frames were
+    detached), but all of them are returned -- autograd drops what nobody asked for."""
+
+    @staticmethod
+    def forward(ctx, q, keys, values):
+        S, n, C = q.shape
+        Lk = keys.shape[1]
+        out = torch.empty((S, n, C), dtype=q.dtype, device=q.device)
+        ops.attention(q, keys, values, out, batch=S, heads=1, nwin=1, Lq=n, Lk=Lk, D=C, DV=C, q_bs=n * C, k_bs=Lk * C,
+                      v_bs=Lk * C, o_bs=n * C, ldq=C, ldk=C, ldv=C, ldo=C, scale=C ** -0.5)
+        ctx.save_for_backward(q, keys, values)
+        return out
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v = ctx.saved_tensors
+        do = do.contiguous()
+        S, n, C = q.shape
+        Lk = k.shape[1]
+        Lp = _round_up(Lk, 8)
+        dt, dev = q.dtype, q.device
+        scale = C ** -0.5
+        Sm = torch.empty((S, n, Lp), dtype=dt, device=dev)
+        ops.gemm_batched(q, k, Sm, S, n, Lk, C, C, C, Lp, n * C, Lk * C, n * Lp)
+        P = ops.softmax_rows(Sm.view(S * n, Lp), Lk, scale, out=Sm.view(S * n, Lp))
+        dV = ops.gemm_tn_batched(P, do, S, n, Lp, C, Lp, C, n * Lp, n * C)                 # f32 [S,Lp,C]
+        dP = torch.empty((S, n, Lp), dtype=dt, device=dev)
+        ops.gemm_batched(do, v, dP, S, n, Lk, C, C, C, Lp, n * C, Lk * C, n * Lp)
+        dS = ops.softmax_bwd_rows(P, dP.view(S * n, Lp), Lk, scale, out=dP.view(S * n, Lp))
+        kT = ops.transpose_pad(k, Lp)                                                      # [S,C,Lp]
+        dq = torch.empty_like(q)
+        ops.gemm_batched(dS, kT, dq, S, n, C, Lp, Lp, Lp, C, n * Lp, C * Lp, n * C)
+        dK = ops.gemm_tn_batched(dS, q, S, n, Lp, C, Lp, C, n * Lp, n * C)                 # f32 [S,Lp,C]
+        return dq, _to_act(dK[:, :Lk].contiguous(), dt), _to_act(dV[:, :Lk].contiguous(), dt)

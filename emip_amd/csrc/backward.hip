@@ -195,6 +195,56 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows128_kernel(const T* __res
     }
 }
 
+// ---- long rows (the EMIP-long memory read: up to 5 x 1936 = 9680 keys): one workgroup per row, three passes ----------
+__device__ __forceinline__ float block_reduce_max(float v, float* sh) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    return v;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    v = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return v;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_long_kernel(const T* __restrict__ X, T* __restrict__ Y, long rows,
+                                                                int L, long ld, float scale) {
+    __shared__ float sh[4];
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const T* x = X + r * ld;
+        T* y = Y + r * ld;
+        float mx = -INFINITY;
+        for (int c = threadIdx.x; c < L; c += 256) mx = fmaxf(mx, to_f32<T>(x[c]) * scale);
+        mx = block_reduce_max(mx, sh);
+        float sum = 0.f;
+        for (int c = threadIdx.x; c < L; c += 256) sum += expf(to_f32<T>(x[c]) * scale - mx);
+        const float inv = 1.f / block_reduce_sum(sum, sh);
+        for (int c = threadIdx.x; c < ld; c += 256)
+            y[c] = from_f32<T>(c < L ? expf(to_f32<T>(x[c]) * scale - mx) * inv : 0.f);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_rows_long_kernel(const T* __restrict__ P, const T* __restrict__ DP,
+                                                                    T* __restrict__ DS, long rows, int L, long ld,
+                                                                    float scale) {
+    __shared__ float sh[4];
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const T* p = P + r * ld;
+        const T* dp = DP + r * ld;
+        float dot = 0.f;
+        for (int c = threadIdx.x; c < L; c += 256) dot += to_f32<T>(p[c]) * to_f32<T>(dp[c]);
+        dot = block_reduce_sum(dot, sh);
+        for (int c = threadIdx.x; c < ld; c += 256)
+            DS[r * ld + c] = from_f32<T>(c < L ? to_f32<T>(p[c]) * (to_f32<T>(dp[c]) - dot) * scale : 0.f);
+    }
+}
+
 // Y[z][c][r] = r < R ? X[z][r][c] : 0   for c < C, r < Rpad   (X rows of stride ldx, Y rows of stride Rpad)
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ X, long ldx, long bsx,
@@ -519,9 +569,14 @@ __global__ __launch_bounds__(256) void bilinear_planar_bwd_kernel(const float* _
 extern "C" int emip_softmax_rows(const void* X, void* Y, long rows, int L, long ld, float scale, const int* gid_q,
                                  const int* gid_k, long period, long nwin, int dtype, void* stream) {
     REQ_DT(dtype);
-    EMIP_REQUIRE(X && Y && rows > 0 && L > 0 && L <= 2048 && ld >= L && ld <= 2048);
+    EMIP_REQUIRE(X && Y && rows > 0 && L > 0 && L <= 65536 && ld >= L && ld <= 65536);
     EMIP_REQUIRE((gid_q == nullptr) == (gid_k == nullptr));
-    if (gid_q) EMIP_REQUIRE(period > 0 && nwin > 0);
+    if (gid_q) EMIP_REQUIRE(period > 0 && nwin > 0 && ld <= 2048);
+    if (ld > 2048) {        // long rows: one workgroup per row
+        DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_rows_long_kernel<T>, dim3((unsigned)(rows < 65535 ? rows : 65535)),
+                                             dim3(256), 0, (hipStream_t)stream, (const T*)X, (T*)Y, rows, L, ld, scale));
+        return emip_launch_status();
+    }
     if (!gid_q && ld == 128 && (((uintptr_t)X | (uintptr_t)Y) & 15) == 0) {
         DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_rows128_kernel<T>, dim3(grid_for(rows, 16)), dim3(256), 0,
                                              (hipStream_t)stream, (const T*)X, (T*)Y, rows, L, scale));
@@ -536,7 +591,13 @@ extern "C" int emip_softmax_rows(const void* X, void* Y, long rows, int L, long 
 extern "C" int emip_softmax_bwd_rows(const void* P, const void* DP, void* DS, long rows, int L, long ld, float scale,
                                      int dtype, void* stream) {
     REQ_DT(dtype);
-    EMIP_REQUIRE(P && DP && DS && rows > 0 && L > 0 && L <= 2048 && ld >= L && ld <= 2048);
+    EMIP_REQUIRE(P && DP && DS && rows > 0 && L > 0 && L <= 65536 && ld >= L && ld <= 65536);
+    if (ld > 2048) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_bwd_rows_long_kernel<T>,
+                                             dim3((unsigned)(rows < 65535 ? rows : 65535)), dim3(256), 0,
+                                             (hipStream_t)stream, (const T*)P, (const T*)DP, (T*)DS, rows, L, ld, scale));
+        return emip_launch_status();
+    }
     if (ld == 128 && (((uintptr_t)P | (uintptr_t)DP | (uintptr_t)DS) & 15) == 0) {
         DISPATCH_T(dtype, hipLaunchKernelGGL(softmax_bwd_rows128_kernel<T>, dim3(grid_for(rows, 16)), dim3(256), 0,
                                              (hipStream_t)stream, (const T*)P, (const T*)DP, (T*)DS, rows, L, scale));

@@ -170,7 +170,10 @@ class Block(EmipModule):
         if self.training and self.drop_path_rate > 0:
             # stochastic depth: the branch is computed without the fused residual, then scaled per sample
             if not torch.is_grad_enabled():
-                raise RuntimeError("train-mode DropPath runs on the autograd path: enable grad or call .eval()")
+                # train mode under torch.no_grad() (the frozen short-term part of train_long.py): same Functions, whose
+                # inputs do not require grad, so nothing is recorded
+                with torch.enable_grad():
+                    return self.run(x)
             rps = x.shape[1] * x.shape[2]
             a = self.attn.run(LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), None)
             x = DropPathAddFn.apply(x, a, self._drop_scale(x, "attn"), rps)

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
+from ...autograd import ConcatFn, ConvFn, MemoryReadFn
 from ...nn_base import EmipModule, f32, fold_bn, pack_conv
 from ..EMIP_short.create_backbone import DimensionalReduction, NeighborConnectionDecoder
 
@@ -33,6 +34,18 @@ class fusion(EmipModule):
                              lambda cw, cb, *_: (lambda wb: (pack_conv(wb[0], dt), wb[1]))(fold_bn(cw, cb, bn)))
         w3, b3 = self.packed("c3", (c3.weight, c3.bias), lambda a, b: (pack_conv(a, dt), f32(b)))
         x = ops.eltwise(fea, corr, 2)
+        if torch.is_grad_enabled():
+            # training step (train_long.py:37-58): batch-statistics BatchNorm, every op an autograd Function; fea and corr
+            # come out of the frozen short-term part and are constants
+            from ..EMIP_short.create_backbone import conv_bn_relu_autograd
+            y = conv_bn_relu_autograd(self, c0, bn, x, 3, 1, 1)
+            w3p, w3d = self.packed("c3t", (c3.weight,), lambda a: (
+                pack_conv(a, dt), pack_conv(a.detach().flip(2, 3).permute(1, 0, 2, 3), dt)))
+            return ConvFn.apply(y, c3.weight, c3.bias, w3p, w3d, 3, 1, 1, None)
+        if self.training:
+            from ..EMIP_short.create_backbone import conv_bn_train
+            x = conv_bn_train(self, c0, bn, x, 3, 1, 1)
+            return ops.conv2d(x, w3, 3, 3, 1, 1, bias=b3)
         x = ops.conv2d(x, w0, 3, 3, 1, 1, bias=b0, act=ops.ACT_RELU)
         return ops.conv2d(x, w3, 3, 3, 1, 1, bias=b3)
 
@@ -45,6 +58,12 @@ class KeyValue(EmipModule):
 
     def run(self, x, out_k=None, out_v=None):
         dt = self.cdtype
+        if torch.is_grad_enabled():
+            pk, pkd, pv, pvd = self.packed("kvt", (self.Key.weight, self.Value.weight), lambda a, c: (
+                pack_conv(a, dt), pack_conv(a.detach().flip(2, 3).permute(1, 0, 2, 3), dt),
+                pack_conv(c, dt), pack_conv(c.detach().flip(2, 3).permute(1, 0, 2, 3), dt)))
+            return (ConvFn.apply(x, self.Key.weight, self.Key.bias, pk, pkd, 3, 1, 1, None),
+                    ConvFn.apply(x, self.Value.weight, self.Value.bias, pv, pvd, 3, 1, 1, None))
         wk, bk, wv, bv = self.packed("kv", (self.Key.weight, self.Key.bias, self.Value.weight, self.Value.bias),
                                      lambda a, b, c, d: (pack_conv(a, dt), f32(b), pack_conv(c, dt), f32(d)))
         return (ops.conv2d(x, wk, 3, 3, 1, 1, bias=bk, out=out_k), ops.conv2d(x, wv, 3, 3, 1, 1, bias=bv, out=out_v))
@@ -74,6 +93,10 @@ class LTM(EmipModule):
         """fea0 [S,h,w,128]; keys/values [S,T,h*w,128] -> cat(mem, v_q) channels-last [S,h,w,256]"""
         S, h, w, C = fea0.shape
         T, n = keys.shape[1], h * w
+        if torch.is_grad_enabled():
+            kq, vq = self.KV_Q_r4.run(fea0)
+            mem = MemoryReadFn.apply(kq.view(S, n, C), keys.reshape(S, T * n, C), values.reshape(S, T * n, C))
+            return ConcatFn.apply(None, mem.view(S, h, w, C), vq)
         out = torch.empty((S, h, w, 2 * C), dtype=fea0.dtype, device=fea0.device)
         kq, _ = self.KV_Q_r4.run(fea0, out_v=out[..., C:])
         ops.attention(kq, keys, values, out, batch=S, heads=1, nwin=1, Lq=n, Lk=T * n, D=C, DV=C, q_bs=n * C,

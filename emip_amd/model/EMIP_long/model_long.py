@@ -46,6 +46,8 @@ class Model_long(EmipModule):
         return m[:, 0].permute(0, 2, 3, 4, 1).reshape(S, T, h * w, C).to(self.cdtype).contiguous()
 
     def _lookup(self, ref_k, ref_v):
+        if ref_k.requires_grad or ref_v.requires_grad:
+            raise RuntimeError("feed the memory back detached (train_long.py:52-53)")
         """Reuse the channels-last memory of the previous step when the caller feeds back what we returned
         (possibly .detach()-ed: same storage), instead of converting layouts every frame."""
         c = self._mem_cache
@@ -57,12 +59,13 @@ class Model_long(EmipModule):
 
     def forward_streams(self, frames0, frames1, index, memory_k, memory_v):
         """frames0/frames1: [S,3,H,W]; memory_k/v: [S,1,128,T,44,44] or None.  Returns (masks [S,1,H,W], keys, values)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("emip_amd Model_long: run forward under torch.no_grad() (inference build)")
+        if torch.is_grad_enabled() and not self.training and any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("emip_amd Model_long in eval mode: wrap inference in torch.no_grad()")
         st = self.short_term
         S = frames0.shape[0]
         if index == 0:
-            mask, _ = st.run(frames0, frames1)
+            with torch.no_grad():
+                mask, _ = st.run(frames0, frames1)
             return mask, None, None
         mk = mv = None
         if not (index == 1 or memory_k is None):
@@ -71,7 +74,8 @@ class Model_long(EmipModule):
         h = w = int(round(keys.shape[2] ** 0.5))
         ref_k, ref_v = self._mem_to_ref(keys, h, w), self._mem_to_ref(values, h, w)
         object.__setattr__(self, "_mem_cache", ((ref_k.data_ptr(), ref_k._version, tuple(ref_k.shape)),
-                                                (ref_v.data_ptr(), ref_v._version, tuple(ref_v.shape)), keys, values))
+                                                (ref_v.data_ptr(), ref_v._version, tuple(ref_v.shape)), keys.detach(),
+                                                values.detach()))
         return mask_long, ref_k, ref_v
 
     def step_cl(self, frames0, frames1, mem_k, mem_v):
@@ -80,12 +84,13 @@ class Model_long(EmipModule):
         With a full window the shapes are static, which is what emip_amd.graph.GraphedLong captures."""
         st = self.short_term
         S = frames0.shape[0]
-        st.run(frames0, frames1)
-        L = st.last
-        fea, cc = L["fea"], L["conv_corr"]
-        h, w = fea[0].shape[1:3]
-        f2_2 = st.dr2.run(fea[1][S:])
-        f2_3 = st.dr3.run(fea[2][S:])
+        with torch.no_grad():                  # model_long.py:70: the short-term part never carries gradient
+            st.run(frames0, frames1)
+            L = st.last
+            fea, cc = L["fea"], L["conv_corr"]
+            h, w = fea[0].shape[1:3]
+            f2_2 = st.dr2.run(fea[1][S:])
+            f2_3 = st.dr3.run(fea[2][S:])
         pk, pv = self.LTM.memorize_cl(fea[0][:S], cc)                  # [S,h,w,128] each
         pk, pv = pk.view(S, 1, h * w, -1), pv.view(S, 1, h * w, -1)
         if mem_k is None:

@@ -53,4 +53,32 @@ def train_step(model, optimizer, reducer, image1, image2, gts):
     return loss.detach(), loss_pred.detach(), loss_flow.detach()
 
 
-__all__ = ["freeze_like_reference", "trainable", "build_optimizer", "train_step", "GradReducer"]
+def freeze_short_term(model_long):
+    """train_long.py:404-406: everything under `short_term` is frozen"""
+    for name, para in model_long.named_parameters():
+        if "short_term" in name:
+            para.requires_grad_(False)
+    return model_long
+
+
+def train_long_video(model_long, optimizer, reducer, frames, masks):
+    """train_long.py:41-61: one optimizer step PER FRAME of a video clip, the memory fed back detached.
+    frames [N,3,H,W], masks [N,1,H,W] on the device.  Returns the summed loss of the clip (0-dim device tensor)."""
+    memory_k = memory_v = None
+    loss_iter = None
+    for index in range(1, len(frames)):
+        optimizer.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            preds, memory_k, memory_v = model_long(frames[index - 1], frames[index], index, memory_k, memory_v)
+            memory_k, memory_v = memory_k.detach(), memory_v.detach()
+            loss = hybrid_e_loss(preds, masks[index].unsqueeze(dim=0))
+            loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        optimizer.step()
+        loss_iter = loss.detach() if loss_iter is None else loss_iter + loss.detach()
+    return loss_iter
+
+
+__all__ = ["freeze_like_reference", "freeze_short_term", "trainable", "build_optimizer", "train_step",
+           "train_long_video", "GradReducer"]

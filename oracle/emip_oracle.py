@@ -397,12 +397,12 @@ def short_forward(image1, image2, sd, p="", training=False, drop_masks=None, cap
 # EMIP-long (model/EMIP_long)
 
 
-def ltm_memorize(fea0, corr, sd, p):
+def ltm_memorize(fea0, corr, sd, p, training=False):
     """LTM.memorize: fusion conv on fea+corr, then Key/Value convs.
     LTM.py:38-41,78-79,103-111.  Returns k,v [1,1,128,1,44,44]."""
     f = p + ".fusion.conv1_fusion"
     x = fea0 + corr
-    x = _conv(F.relu(_bn(_conv(x, sd, f + ".0", padding=1), sd, f + ".1")), sd, f + ".3", padding=1)
+    x = _conv(F.relu(_bn(_conv(x, sd, f + ".0", padding=1), sd, f + ".1", training)), sd, f + ".3", padding=1)
     k = _conv(x, sd, p + ".KV_M_r4.Key", padding=1)
     v = _conv(x, sd, p + ".KV_M_r4.Value", padding=1)
     return k[None, :, :, None], v[None, :, :, None]
@@ -422,15 +422,30 @@ def ltm_segment(fea0, keys, values, sd, p):
     return torch.cat([mem, vq], 1)
 
 
-def long_forward(frame0, frame1, index, memory_k, memory_v, sd):
-    """Model_long.forward.  model/EMIP_long/model_long.py:68-117."""
+def long_forward(frame0, frame1, index, memory_k, memory_v, sd, training=False, drop_masks=None):
+    """Model_long.forward.  model/EMIP_long/model_long.py:68-117.  training=True: train_long.py:37 puts the whole
+    model in train mode (batch-statistics BatchNorm, DropPath via drop_masks) while the short-term part runs under
+    torch.no_grad() (model_long.py:70) -- its results are constants of the step."""
     cap = {}
     st = "short_term."
-    mask, _, _ = short_forward(frame0[None], frame1[None], sd, st, capture=cap)
-    if index == 0:
-        return mask, None, None
-    f2_2 = dim_reduction(cap["pvt2"][1], sd, st + "dr2")
-    f2_3 = dim_reduction(cap["pvt2"][2], sd, st + "dr3")
+    with torch.no_grad():
+        mask, _, _ = short_forward(frame0[None], frame1[None], sd, st, training=training, drop_masks=drop_masks,
+                                   capture=cap)
+        if index == 0:
+            return mask, None, None
+        f2_2 = dim_reduction(cap["pvt2"][1], sd, st + "dr2", training)
+        f2_3 = dim_reduction(cap["pvt2"][2], sd, st + "dr3", training)
+    if training:
+        cap = {k: (tuple(t.detach() for t in v) if isinstance(v, (tuple, list)) else v.detach()) for k, v in cap.items()
+               if torch.is_tensor(v) or isinstance(v, (tuple, list))}
+        pk, pvv = ltm_memorize(cap["pvt1"][0], cap["conv_corr"], sd, "LTM", True)
+        keys = pk if index == 1 else torch.cat([memory_k, pk], 3)[:, :, :, -5:]
+        values = pvv if index == 1 else torch.cat([memory_v, pvv], 3)[:, :, :, -5:]
+        mem = ltm_segment(cap["pvt2"][0], keys, values, sd, "LTM")
+        mem = dim_reduction(mem, sd, "long_dr", True)
+        fl = injector_forward(cap["pvt2"][0], mem, sd, "injector1")
+        fl = dim_reduction(fl, sd, "dr1", True)
+        return ncd_forward(f2_3, f2_2, fl, sd, "decoder", True), keys, values
     pk, pvv = ltm_memorize(cap["pvt1"][0], cap["conv_corr"], sd, "LTM")
     if index == 1:
         keys, values = pk, pvv

@@ -36,13 +36,20 @@ def _data(rank):
     return im1.cuda(), im2.cuda(), synthetic_gt(1, seed=600 + rank).cuda()
 
 
+def _loss(net, im1, im2, gt):
+    """hybrid_e_loss + a smooth linear functional of the flow predictions: reaches every trainable parameter the real
+    objective reaches, without the piecewise photometric loss whose gradient jitters run to run"""
+    from emip_amd.loss.loss_pred import hybrid_e_loss
+    mask, fw, bw = net(im1, im2)
+    w = torch.linspace(-1, 1, 352 * 352, device=im1.device).view(1, 1, 352, 352) / (352 * 352)
+    return hybrid_e_loss(mask, gt) + sum((f * w).sum() + (b_ * w.flip(-1)).sum() for f, b_ in zip(fw, bw))
+
+
 def _worker(rank, port, out):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE="2")
     dist.init_process_group("gloo", rank=rank, world_size=2)
     from emip_amd.dp import GradReducer, broadcast_parameters
-    from emip_amd.loss.loss_flow import unFlowLoss
-    from emip_amd.loss.loss_pred import hybrid_e_loss
     from emip_amd.train import build_optimizer, trainable
     net = _build()
     broadcast_parameters(net)
@@ -50,10 +57,7 @@ def _worker(rank, port, out):
     red = GradReducer(trainable(net))
     im1, im2, gt = _data(rank)
     with torch.enable_grad():                     # train.py:43-60 with the reducer in DDP's place
-        mask, fw, bw = net(im1, im2)
-        loss = hybrid_e_loss(mask, gt) + unFlowLoss().compute_loss(
-            [torch.cat((fw[i], bw[i]), 1) for i in range(len(fw))], torch.cat((im1, im2), 1))[0]
-        loss.backward()
+        _loss(net, im1, im2, gt).backward()
     red.finish()
     p = dict(net.named_parameters())
     grads = {n: p[n].grad.detach().cpu().numpy() for n in NAMES}
@@ -79,9 +83,6 @@ def test_two_rank_training_step_keeps_replicas_identical():
     for n in NAMES:
         assert (got[0][n] == got[1][n]).all(), n
     # single process: the same two samples one after the other, gradients averaged by hand
-    from emip_amd.loss.loss_flow import unFlowLoss
-    from emip_amd.loss.loss_pred import hybrid_e_loss
-    from emip_amd.train import build_optimizer
     net = _build()
     params = [q_ for q_ in net.parameters() if q_.requires_grad]
     acc = None
@@ -90,10 +91,7 @@ def test_two_rank_training_step_keeps_replicas_identical():
         for q_ in params:
             q_.grad = None
         with torch.enable_grad():
-            mask, fw, bw = net(im1, im2)
-            loss = hybrid_e_loss(mask, gt) + unFlowLoss().compute_loss(
-                [torch.cat((fw[i], bw[i]), 1) for i in range(len(fw))], torch.cat((im1, im2), 1))[0]
-            loss.backward()
+            _loss(net, im1, im2, gt).backward()
         gs = [None if q_.grad is None else q_.grad.clone() for q_ in params]
         acc = gs if acc is None else [None if a is None else a + b for a, b in zip(acc, gs)]
         # BatchNorm running buffers advance per forward on every replica; parameters only change in step()
@@ -104,6 +102,4 @@ def test_two_rank_training_step_keeps_replicas_identical():
         ref = (acc[idx[id(p[n])]] * 0.5).cpu().numpy()
         err = abs(ref - grads[0][n]).max()
         scale = abs(ref).max() + 1e-12
-        # the photometric loss is piecewise and the f32 atomics jitter run to run (tests/test_train_gpu.py): the
-        # parameters fed through the flow loss repeat to a few per cent, the others to 1e-3
-        assert err <= 5e-2 * scale, (n, err, scale)
+        assert err <= 1e-2 * scale, (n, err, scale)        # f32 atomics jitter run to run; ReLU masks may flip

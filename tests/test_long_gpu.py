@@ -99,3 +99,76 @@ def test_graphed_steady_state_matches_eager(long_net):
             assert (out - ref).abs().max().item() < 1e-3
             gk, gv = runner.memory()
             assert (gk - mk).abs().max().item() < 1e-3 and (gv - mv).abs().max().item() < 1e-3
+
+
+def test_long_training_step_vs_reference_golden(model_args, long_sd, golden):
+    """one EMIP-long training step (train_long.py:37-58: train mode, short-term part frozen and under no_grad,
+    hybrid_e_loss, backward) against the fixture the reference itself produced: mask, loss, memory and the gradients of
+    the long-branch parameters"""
+    from emip_amd import nn_base
+    from emip_amd.filler import synthetic_gt
+    from emip_amd.loss.loss_pred import hybrid_e_loss
+    from emip_amd.model.EMIP_long.model_long import Model_long
+    nn_base.set_default_dtype(torch.float32)
+    g = golden("long_train.npz")
+    net = Model_long(model_args)
+    net.load_state_dict(long_sd)
+    net = net.to("cuda:0")
+    for name, para in net.named_parameters():              # train_long.py:404-406
+        if "short_term" in name:
+            para.requires_grad_(False)
+    net.train()
+    for m in net.modules():                                # the fixture was produced with DropPath off
+        if hasattr(m, "drop_path_rate"):
+            m.drop_path_rate = 0.0
+    seq = [synthetic_pair(1, seed=900, shift=(t - 2, 2 - t))[1][0].cuda() for t in range(3)]
+    gt = synthetic_gt(1, seed=901).cuda()
+    with torch.enable_grad():
+        _, mk, mv = net(seq[0], seq[1], 1, None, None)
+        mk, mv = mk.detach(), mv.detach()
+        mask, k2, v2 = net(seq[1], seq[2], 2, mk, mv)
+        loss = hybrid_e_loss(mask, gt)
+        loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-4
+    assert (mask.detach().cpu()[:, :, ::2, ::2] - torch.from_numpy(g["mask"])).abs().max().item() < 2e-3
+    assert k2.shape == (1, 1, 128, 2, 44, 44)
+    assert np.allclose(_stats(k2.cpu()), g["k_stats"], rtol=2e-3, atol=1e-3)
+    p = dict(net.named_parameters())
+    worst = 0.0
+    for i, n in enumerate(str(x) for x in g["names"]):
+        gr = p[n].grad
+        assert gr is not None, n
+        ref_head, ref_stats = g["g%d_head" % i], g["g%d_stats" % i]
+        err = np.abs(gr.detach().reshape(-1)[:64].cpu().numpy() - ref_head).max() / max(ref_stats[2], 1e-12)
+        l2 = abs(_stats(gr.cpu())[1] - ref_stats[1]) / max(ref_stats[1], 1e-12)
+        worst = max(worst, err, l2)
+        assert err < 2e-2 and l2 < 2e-2, (n, err, l2)
+    print("EMIP-long training step: worst relative gradient deviation vs the reference", worst)
+    assert not [n for n, q in p.items() if "short_term" in n and q.grad is not None]
+    have = {n for n, q in p.items() if q.requires_grad and q.grad is None}
+    assert have == {str(x) for x in g["no_grad"]}, sorted(have ^ {str(x) for x in g["no_grad"]})[:6]
+
+
+def test_train_long_video_runs_with_full_window(model_args, long_sd):
+    """emip_amd.train.train_long_video over a 7-frame clip in bf16: the window saturates at 5 frames (9680-key memory
+    read and its backward), long-branch parameters move, short-term ones do not"""
+    from emip_amd import nn_base
+    from emip_amd.filler import synthetic_gt
+    from emip_amd.model.EMIP_long.model_long import Model_long
+    from emip_amd.train import build_optimizer, freeze_short_term, train_long_video
+    nn_base.set_default_dtype(torch.bfloat16)
+    try:
+        net = Model_long(model_args)
+        net.load_state_dict(long_sd)
+        net = freeze_short_term(net.to("cuda:0")).train()
+        opt = build_optimizer(net, lr=1e-5, weight_decay=1e-7, clip=0.5)
+        frames = torch.stack(_seq(321)[:7])
+        masks = torch.cat([synthetic_gt(1, seed=40 + t) for t in range(7)]).cuda()
+        w_long = net.LTM.KV_Q_r4.Key.weight.detach().clone()
+        w_short = net.short_term.decoder.conv5.weight.detach().clone()
+        loss = train_long_video(net, opt, None, frames, masks)
+        assert torch.isfinite(loss).item() and 0 < loss.item() < 100
+        assert (net.LTM.KV_Q_r4.Key.weight.detach() - w_long).abs().max().item() > 0
+        assert torch.equal(net.short_term.decoder.conv5.weight.detach(), w_short)
+    finally:
+        nn_base.set_default_dtype(torch.float32)

@@ -119,3 +119,35 @@ def test_postprocess_restatement_known_answers():
     assert np.abs(out.astype(int) - want.astype(int)).max() <= 1 and out.min() == 0 and out.max() >= 254
     up = O.postprocess_mask(x, (40, 24))
     assert up.shape == (40, 24) and up[0, 0] == 0 and up[-1, -1] >= 254
+
+
+def test_long_training_step_vs_reference(golden, long_sd):
+    """oracle long_forward(training=True) + hybrid_e_loss + autograd against the reference's own train-mode step
+    (oracle/make_golden_long_train.py): mask, loss, memory statistics and long-branch gradients"""
+    import numpy as np
+    import torch
+    from emip_amd.filler import synthetic_gt, synthetic_pair
+    from oracle import emip_oracle as O
+    g = golden("long_train.npz")
+    names = [str(n) for n in g["names"]]
+    sd = {k: (v.clone().requires_grad_(True) if (v.is_floating_point() and not k.startswith("short_term.")) else v)
+          for k, v in long_sd.items()}
+    seq = [synthetic_pair(1, seed=900, shift=(t - 2, 2 - t))[1][0] for t in range(3)]
+    gt = synthetic_gt(1, seed=901)
+    _, mk, mv = O.long_forward(seq[0], seq[1], 1, None, None, sd, training=True)
+    mask, k2, v2 = O.long_forward(seq[1], seq[2], 2, mk.detach(), mv.detach(), sd, training=True)
+    loss = O.hybrid_e_loss(mask, gt)
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) < 1e-5
+    assert (mask.detach()[:, :, ::2, ::2] - torch.from_numpy(g["mask"])).abs().max().item() < 1e-4
+    assert int(g["T"]) == k2.shape[3] == 2
+
+    def st(t):
+        t = t.detach().double()
+        return np.array([t.mean().item(), t.pow(2).sum().sqrt().item(), t.abs().max().item()])
+    assert np.allclose(st(k2), g["k_stats"], rtol=1e-4, atol=1e-6)
+    for i, n in enumerate(names):
+        gr = sd[n].grad
+        assert gr is not None, n
+        assert np.allclose(st(gr), g["g%d_stats" % i], rtol=2e-3, atol=1e-7), n
+        assert np.allclose(gr.reshape(-1)[:64].numpy(), g["g%d_head" % i], rtol=2e-3, atol=1e-6 * abs(g["g%d_stats" % i][2]) + 1e-9), n
