@@ -318,3 +318,47 @@ def test_train_step_runs_and_updates(model_args, short_sd):
         assert torch.equal(net.GMFlow.upsampler[0].weight.detach(), w_fr)
     finally:
         nn_base.set_default_dtype(torch.float32)
+
+
+def test_training_step_gradients_vs_reference_golden(model_args, short_sd, golden):
+    """the HIP training step against gradients the REFERENCE itself produced (tests/golden/short_train_grads.npz,
+    oracle/make_golden_short_train.py: train mode, DropPath off, hybrid_e_loss + unFlowLoss)"""
+    import numpy as np
+    from emip_amd import nn_base
+    from emip_amd.filler import synthetic_gt
+    from emip_amd.loss.loss_flow import unFlowLoss
+    from emip_amd.loss.loss_pred import hybrid_e_loss
+    nn_base.set_default_dtype(torch.float32)
+    g = golden("short_train_grads.npz")
+    net = _short_net(model_args, short_sd)
+    for m in net.modules():
+        if hasattr(m, "drop_path_rate"):
+            m.drop_path_rate = 0.0
+    im1, im2 = synthetic_pair(1, seed=99)
+    gt = synthetic_gt(1, seed=99)
+    with torch.enable_grad():
+        mask, fw, bw = net(im1.cuda(), im2.cuda())
+        lp = hybrid_e_loss(mask, gt.cuda())
+        lf = unFlowLoss().compute_loss([torch.cat((fw[i], bw[i]), 1) for i in range(len(fw))],
+                                       torch.cat((im1, im2), 1).cuda())[0]
+        (lp + lf).backward()
+    assert abs(lp.item() - float(g["loss_pred"])) < 1e-3 and abs(lf.item() - float(g["loss_flow"])) < 1e-3
+    assert (mask.detach().cpu()[:, :, ::4, ::4] - torch.from_numpy(g["mask"])).abs().max().item() < 2e-3
+    p = dict(net.named_parameters())
+
+    def tol(n):
+        # the photometric loss is piecewise: parameters that only see it through the flows repeat to ~10 % between two
+        # f32 forwards that differ by 0.03 px (see test_full_training_step_gradients_vs_oracle); the rest is tight
+        if n.startswith("injector."):
+            return 0.3
+        if n == "conv_corr.0.weight" or "block1." in n or "block2." in n or "patch_embed1" in n:
+            return 0.06
+        return 1e-2
+    for i, n in enumerate(str(x) for x in g["names"]):
+        gr = p[n].grad
+        assert gr is not None, n
+        ref_stats, ref_head = g["g%d_stats" % i], g["g%d_head" % i]
+        err = np.abs(gr.detach().reshape(-1)[:64].cpu().numpy() - ref_head).max() / max(ref_stats[2], 1e-12)
+        l2 = abs(gr.double().pow(2).sum().sqrt().item() - ref_stats[1]) / max(ref_stats[1], 1e-12)
+        print(f"  {n}: head {err:.2e} l2 {l2:.2e}")
+        assert err < tol(n) and l2 < tol(n), (n, err, l2)
