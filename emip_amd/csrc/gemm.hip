@@ -260,6 +260,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             if (kt + 1 < nk) store_tile(cur ^ 1, ra, rw);
             __syncthreads();
         }
+    } else if (NBUF == 5) {
+        // one LDS buffer, THREE register stages: the global loads of K tiles kt+1 and kt+2 are in flight while tile kt is
+        // multiplied.  For grids of about one workgroup per CU (the 121-token spatial-reduction convs: 16-80 workgroups
+        // walking K = 1280-4096) nothing else hides the load latency; the staging registers are cheap at 64x64 tiles.
+        uint4 ra0[CA], rw0[CW], ra1[CA], rw1[CW], ra2[CA], rw2[CW];
+        load_tile(0, ra0, rw0);
+        if (nk > 1) load_tile(BK, ra1, rw1);
+        for (int kt = 0; kt < nk; kt += 3) {
+            if (kt + 2 < nk) load_tile((kt + 2) * BK, ra2, rw2);
+            store_tile(0, ra0, rw0);
+            __syncthreads();
+            compute_tile(0);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                if (kt + 3 < nk) load_tile((kt + 3) * BK, ra0, rw0);
+                store_tile(0, ra1, rw1);
+                __syncthreads();
+                compute_tile(0);
+                __syncthreads();
+            }
+            if (kt + 2 < nk) {
+                if (kt + 4 < nk) load_tile((kt + 4) * BK, ra1, rw1);
+                store_tile(0, ra2, rw2);
+                __syncthreads();
+                compute_tile(0);
+                __syncthreads();
+            }
+        }
     } else {
         // one LDS buffer, two barriers per K tile: half the LDS, more workgroups per CU
         uint4 ra[CA], rw[CW];
@@ -368,6 +396,7 @@ int g_gemm_nbuf = 1;  // debug/tuning knob (emip_debug_set)
 int g_gemm_tile = 0;  // 0 = heuristic, else BM*1000+BN
 int g_gemm_dbg = 0;
 int g_gemm_glds = 1;  // LDS-DMA main loop for dense GEMMs
+int g_gemm_deep = 512;    // 64x64 tiles: 3-stage register prefetch for grids of at most this many workgroups (0 = off)
 int g_gemm_share = 1; // concurrent streams sharing the GPU (tile choice assumes 256 / share CUs); measured: no gain
 
 template <typename T, int BM, int BN, bool CONV>
@@ -380,6 +409,13 @@ int launch(GemmArgs& a, int batch, hipStream_t s) {
         constexpr int BKE = 128 / sizeof(T);
         if (g_gemm_glds && a.K % BKE == 0 && a.K1 % BKE == 0) {
             hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 3>), grid, dim3(256), 2 * (BM + BN) * 128, s, a);
+            return emip_launch_status();
+        }
+    }
+    if constexpr (BM == 64 && BN == 64) {
+        // small grids with a long K walk: deep register prefetch (see NBUF == 5)
+        if (g_gemm_deep && (long)a.tiles_m * a.tiles_n * batch <= g_gemm_deep && a.K >= 8 * (int)(128 / sizeof(T))) {
+            hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 5>), grid, dim3(256), (BM + BN) * 128, s, a);
             return emip_launch_status();
         }
     }
@@ -492,6 +528,10 @@ extern "C" int emip_debug_set(int key, int value) {
     }
     if (key == 3) {
         g_gemm_glds = value ? 1 : 0;
+        return EMIP_OK;
+    }
+    if (key == 6 && value >= 0) {
+        g_gemm_deep = value;
         return EMIP_OK;
     }
     if (key == 4 && (value == 1 || value == 2 || value == 4 || value == 8)) {
