@@ -121,7 +121,7 @@ def cpu_baseline(sd):
     im1, im2 = synthetic_pair(1, seed=1234)
     with torch.no_grad():
         torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))   # the GPU box gives one GPU a 16-CPU share
-        O.short_forward(im1, im2, sd)                        # warm-up
+        ref_mask = O.short_forward(im1, im2, sd)[0]          # warm-up; also the reference mask of the parity figures
         t0 = time.time()
         n = 0
         while n < 3 or (time.time() - t0 < 12.0 and n < 12):
@@ -130,7 +130,34 @@ def cpu_baseline(sd):
         dt = time.time() - t0
     return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "%d fp32 batch-1 EMIP-short forwards of the CPU oracle (oracle/emip_oracle.py, PyTorch-CPU, "
-                      "%d threads, host has %d logical CPUs)" % (n, torch.get_num_threads(), os.cpu_count())}
+                      "%d threads, host has %d logical CPUs)" % (n, torch.get_num_threads(), os.cpu_count())}, ref_mask
+
+
+def parity_figures(net_bf16, margs, sd, ref_mask, dev):
+    """BASELINE.json's metric also names 'mask IoU vs ref': the benchmarked bf16 network and the f32 parity mode on the
+    same seeded pair the CPU reference just ran (threshold sigmoid >= 0.5, IoU = |A & B| / |A | B|, eval/metrics.py:488-492)"""
+    from emip_amd import nn_base
+    from emip_amd.filler import synthetic_pair
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    im1, im2 = synthetic_pair(1, seed=1234)
+    im1, im2 = im1.to(dev), im2.to(dev)
+    with torch.no_grad():
+        m16 = net_bf16(im1, im2)[0].float().cpu()
+        nn_base.set_default_dtype(torch.float32)
+        try:
+            net32 = CoUpdater(margs)
+            net32.load_state_dict(sd)
+            m32 = net32.to(dev).eval()(im1, im2)[0].cpu()
+        finally:
+            nn_base.set_default_dtype(torch.bfloat16)
+
+    def iou(a, b):
+        a, b = a > 0, b > 0
+        return float((a & b).sum().item() + 1e-9) / float((a | b).sum().item() + 1e-9)
+    return {"mask_iou_bf16_vs_cpu_ref": round(iou(m16, ref_mask), 5), "mask_iou_f32_vs_cpu_ref": round(iou(m32, ref_mask), 5),
+            "mask_logit_max_abs_err_f32_vs_cpu_ref": float("%.3g" % (m32 - ref_mask).abs().max().item()),
+            "mask_logit_max_abs_err_bf16_vs_cpu_ref": float("%.3g" % (m16 - ref_mask).abs().max().item()),
+            "pair": "synthetic seed 1234, batch 1"}
 
 
 def main_train(args):
@@ -410,7 +437,8 @@ def main():
                                                               if whole else None)})
         out["kernel_breakdown_ms"] = {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd)
+            out["cpu_baseline"], ref_mask = cpu_baseline(sd)
+            out["parity"] = parity_figures(net, margs, sd, ref_mask, dev)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
