@@ -37,6 +37,8 @@ struct GemmArgs {
     // batching over blockIdx.z
     long bsA, bsW, bsC, bsR;
     int tiles_m, tiles_n;
+    unsigned* zero_ptr;   // optional scratch the first workgroup clears (saves the consumer's zero-fill launch)
+    long zero_words;
     int dbg;   // experiment flags (emip_debug_set key 2): 1 = skip epilogue stores, 2 = skip global loads in the K loop
 };
 
@@ -81,6 +83,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
 
+    if (p.zero_ptr && blockIdx.x == 0 && blockIdx.z == 0) {
+        // statistics scratch of the normalisation that follows this conv: cleared here, accumulated into by the next
+        // kernel in stream order (which starts after this grid has drained)
+        for (long i = tid; i < p.zero_words; i += 256) p.zero_ptr[i] = 0u;
+    }
     const int ntile = p.tiles_m * p.tiles_n;
     const int swz = xcd_remap(blockIdx.x, ntile);
     const int tile_m = swz / p.tiles_n, tile_n = swz - tile_m * p.tiles_n;
@@ -484,8 +491,9 @@ extern "C" int emip_gemm(const void* A, const void* A2, const void* W, void* C, 
 
 extern "C" int emip_conv2d(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H,
                            int Wd, int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy,
-                           long ldr, int act, int dtype, void* stream) {
+                           long ldr, int act, void* zero_ptr, long zero_bytes, int dtype, void* stream) {
     EMIP_REQUIRE(X && W && Y && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0);
+    if (zero_ptr) EMIP_REQUIRE(zero_bytes > 0 && (zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0);
     EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
     EMIP_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     const int vec = dtype == EMIP_F32 ? 4 : 8;
@@ -501,6 +509,8 @@ extern "C" int emip_conv2d(const void* X, const void* W, void* Y, const float* b
     a.M = B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin; a.K1 = a.K;
     a.lda = ldx; a.ldw = a.K; a.ldc = ldy; a.ldr = ldr; a.act = act;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.zero_ptr = static_cast<unsigned*>(zero_ptr);
+    a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == EMIP_F32 ? dispatch<float, true>(a, 1, s) : dispatch<bf16_t, true>(a, 1, s);
 }

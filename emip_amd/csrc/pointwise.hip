@@ -22,8 +22,8 @@ inline int grid_for(long work_items, int threads) {
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
                                                         const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, long M, int C, float eps,
-                                                        int lpr_log2) {
+                                                        const float* __restrict__ beta, const T* R, long ldr, long M,
+                                                        int C, float eps, int lpr_log2) {
     const int LPR = 1 << lpr_log2;
     const int lane = threadIdx.x & 63;
     const int sub = lane & (LPR - 1);
@@ -71,6 +71,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X,
                 float o4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) o4[j] = (v[i][j] - mean) * rstd * gamma[vi * 4 + j] + beta[vi * 4 + j];
+                if (R) {                      // wave-uniform: fused residual add (R may alias Y)
+                    float r4[4];
+                    Vec4<T>::load(R + row * ldr + vi * 4, r4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o4[j] += r4[j];
+                }
                 Vec4<T>::store(Y + row * ldy + vi * 4, o4);
             }
         }
@@ -685,10 +691,11 @@ struct TypeOf { typedef T type; };
 extern "C" int emip_version(void) { return 100; }
 
 extern "C" int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
-                              long M, int C, float eps, int dtype, void* stream) {
+                              const void* R, long ldr, long M, int C, float eps, int dtype, void* stream) {
     REQ_DT(dtype);
     EMIP_REQUIRE(X && Y && gamma && beta && M > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
     EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
+    if (R) EMIP_REQUIRE((ldr & 3) == 0 && ldr >= C);
     const int nv = C >> 2;
     int lg = 0;
     while ((1 << lg) < nv && lg < 6) ++lg;
@@ -696,7 +703,7 @@ extern "C" int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const 
     const long waves = (M + rows_per_wave - 1) / rows_per_wave;
     const int grid = grid_for(waves, 4);
     DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)X, ldx, (T*)Y, ldy, gamma, beta, M, C, eps, lg));
+                                         (const T*)X, ldx, (T*)Y, ldy, gamma, beta, (const T*)R, ldr, M, C, eps, lg));
     return emip_launch_status();
 }
 
@@ -756,13 +763,13 @@ extern "C" int emip_dwconv3x3_gated(const void* X, long ldx, void* Y, long ldy, 
     return emip_launch_status();
 }
 
-extern "C" int emip_chan_stats(const void* X, long ldx, double* sums, long groups, long rows, int C, int dtype,
-                               void* stream) {
+extern "C" int emip_chan_stats(const void* X, long ldx, double* sums, long groups, long rows, int C, int prezeroed,
+                               int dtype, void* stream) {
     REQ_DT(dtype);
     EMIP_REQUIRE(X && sums && groups > 0 && groups < 65536 && rows > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
     EMIP_REQUIRE((ldx & 3) == 0 && ldx >= C);
     hipStream_t s = (hipStream_t)stream;
-    if (emip_zero_async(sums, sizeof(double) * 2 * groups * C, s) != EMIP_OK) return EMIP_E_LAUNCH;
+    if (!prezeroed && emip_zero_async(sums, sizeof(double) * 2 * groups * C, s) != EMIP_OK) return EMIP_E_LAUNCH;
     const int rpb = 512;
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)groups);
     DISPATCH_T(dtype, hipLaunchKernelGGL(chan_stats_kernel<T>, grid, dim3(256), 0, s, (const T*)X, ldx, sums, rows, C,

@@ -5,15 +5,20 @@ downsample.0}, conv2, plus the never-called adaptor parameters dwconv64/96/128, 
 which exist only as state_dict entries).  Each 3x3 conv is an implicit GEMM; InstanceNorm2d (affine=False, no
 running statistics) is a per-(image, channel) statistics pass plus one fused normalise/ReLU/residual pass.
 """
+import torch
 import torch.nn as nn
 
 from ..... import ops
 from .....nn_base import EmipModule, f32, pack_conv, pack_linear, to_cl, to_planar
 
 
-def _inorm(y, relu, res=None, relu_outer=False):
-    B = y.shape[0]
-    sums = ops.chan_stats(y, B)
+def _conv_inorm(x, w, k, stride, pad, relu, bias=None, res=None, relu_outer=False):
+    """conv + InstanceNorm2d (+ReLU, + residual): the conv's first workgroup clears the statistics scratch, so the pair of
+    normalisation kernels needs no zero-fill launch of its own"""
+    B, cout = x.shape[0], w.shape[0]
+    sums = torch.empty((B, cout, 2), dtype=torch.float64, device=x.device)
+    y = ops.conv2d(x, w, k, k, stride, pad, bias=bias, zero=sums)
+    ops.chan_stats(y, B, sums=sums)
     return ops.chan_norm_apply(y, sums, B, 1e-5, relu_inner=relu, relu_outer=relu_outer, res=res, out=y)
 
 
@@ -36,13 +41,12 @@ class ResidualBlock(EmipModule):
         dt = self.cdtype
         w1, w2 = self.packed("w", (self.conv1.weight, self.conv2.weight),
                              lambda a, b: (pack_conv(a, dt), pack_conv(b, dt)))
-        y = _inorm(ops.conv2d(x, w1, 3, 3, self.stride, 1), relu=True)
-        y = ops.conv2d(y, w2, 3, 3, 1, 1)
+        y = _conv_inorm(x, w1, 3, self.stride, 1, relu=True)
         if self.downsample is not None:
             wd, bd = self.packed("d", (self.downsample[0].weight, self.downsample[0].bias),
                                  lambda a, b: (pack_conv(a, dt), f32(b)))
-            x = _inorm(ops.conv2d(x, wd, 1, 1, self.stride, 0, bias=bd), relu=False)
-        return _inorm(y, relu=True, res=x, relu_outer=True)
+            x = _conv_inorm(x, wd, 1, self.stride, 0, relu=False, bias=bd)
+        return _conv_inorm(y, w2, 3, 1, 1, relu=True, res=x, relu_outer=True)
 
 
 class CNNEncoder(EmipModule):
@@ -77,7 +81,7 @@ class CNNEncoder(EmipModule):
         w1, w2, b2 = self.packed("w", (self.conv1.weight, self.conv2.weight, self.conv2.bias),
                                  lambda a, b, c: (pack_conv(a, dt, cin_pad=cin), pack_linear(b.reshape(b.shape[0], -1), dt),
                                                   f32(c)))
-        x = _inorm(ops.conv2d(img_cl, w1, 7, 7, 2, 3), relu=True)
+        x = _conv_inorm(img_cl, w1, 7, 2, 3, relu=True)
         for layer in (self.layer1, self.layer2, self.layer3):
             x = layer[1].run(layer[0].run(x))
         return ops.gemm(x, w2, bias=b2)

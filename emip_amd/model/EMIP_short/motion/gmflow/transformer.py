@@ -145,8 +145,7 @@ class FeatureTransformer(EmipModule):
             msg = _window_attention(qkv, qkv[..., C:], qkv[..., 2 * C:], B2, h, w, C, 3 * C, 3 * C, 3 * C, shift,
                                     attn_num_splits)
             msg = ops.gemm(msg, ws["merge"])
-            msg = ops.layernorm(msg, ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, out=msg)
-            ops.eltwise(c0, msg, 2, out=c0)
+            ops.layernorm(msg, ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, out=c0, res=c0)    # c0 += LN(msg)
             # ---- cross attention + FFN
             q = ops.gemm(c0, wc["q"])
             msg = _window_attention(q, kvx, kvx[..., C:], B2, h, w, C, C, 2 * C, 2 * C, shift, attn_num_splits)
@@ -154,8 +153,7 @@ class FeatureTransformer(EmipModule):
             msg = ops.layernorm(msg, wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps, out=msg)
             hid = ops.gemm(c0, wc["m0"], a2=msg, act=ops.ACT_GELU)
             msg = ops.gemm(hid, wc["m2"])
-            msg = ops.layernorm(msg, wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps, out=msg)
-            ops.eltwise(c0, msg, 2, out=c0)
+            ops.layernorm(msg, wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps, out=c0, res=c0)     # c0 += LN(msg)
         return c0
 
 

@@ -76,7 +76,7 @@ def gemm_batched(a, w, out, batch, M, N, K, lda, ldw, ldc, bsA, bsW, bsC):
     return out
 
 
-def conv2d(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None):
+def conv2d(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None, zero=None):
     """x [B,H,W,Cin] channels-last, w packed [Cout, kh*kw*Cin] -> [B,Ho,Wo,Cout]."""
     _dev(x)
     B, H, W, Cin = x.shape
@@ -94,19 +94,23 @@ def conv2d(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out
     if res is not None:
         Mr, Nr, ldr = rows(res)
         assert Mr == Mo and Nr == Cout
+    # zero: a scratch tensor the kernel's first workgroup clears (the statistics buffer of the normalisation that follows)
     _lib.call("emip_conv2d", _p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, ldx, Cout, kh, kw, stride, pad,
-              ldy, ldr, act, dt_code(x.dtype), _stream())
+              ldy, ldr, act, _p(zero), zero.numel() * zero.element_size() if zero is not None else 0,
+              dt_code(x.dtype), _stream())
     return out
 
 
-def layernorm(x, gamma, beta, eps, out=None):
+def layernorm(x, gamma, beta, eps, out=None, res=None):
+    """LN(x) [+ res]; out may alias x or res"""
     M, C, ldx = rows(x)
     if out is None:
         out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     Mo, Co, ldy = rows(out)
     assert Mo == M and Co == C
-    _lib.call("emip_layernorm", _p(x), ldx, _p(out), ldy, _p(gamma), _p(beta), M, C, float(eps), dt_code(x.dtype),
-              _stream())
+    ldr = rows(res)[2] if res is not None else 0
+    _lib.call("emip_layernorm", _p(x), ldx, _p(out), ldy, _p(gamma), _p(beta), _p(res), ldr, M, C, float(eps),
+              dt_code(x.dtype), _stream())
     return out
 
 
@@ -151,11 +155,15 @@ def dwconv3x3_gated(x, wt, cout_pad, bias=None):
     return out
 
 
-def chan_stats(x, groups):
+def chan_stats(x, groups, sums=None):
+    """sums f64 [groups, C, 2]; pass `sums` when the producing conv2d(..., zero=sums) already cleared it"""
     M, C, ldx = rows(x)
     assert M % groups == 0
-    sums = torch.empty((groups, C, 2), dtype=torch.float64, device=x.device)
-    _lib.call("emip_chan_stats", _p(x), ldx, _p(sums), groups, M // groups, C, dt_code(x.dtype), _stream())
+    pre = sums is not None
+    if sums is None:
+        sums = torch.empty((groups, C, 2), dtype=torch.float64, device=x.device)
+    assert sums.shape == (groups, C, 2) and sums.dtype == torch.float64 and sums.is_contiguous()
+    _lib.call("emip_chan_stats", _p(x), ldx, _p(sums), groups, M // groups, C, int(pre), dt_code(x.dtype), _stream())
     return sums
 
 

@@ -63,10 +63,12 @@ int emip_debug_set_tn(int target_workgroups);   /* 0 = heuristic split count of 
  *   gmflow/backbone.py:44-47,83,97 (CNN encoder); gmflow/gmflow.py:47-49 (upsampler);
  *   model/EMIP_short/model.py:59-62 (conv_corr; X is the raw correlation [B][src][tgt], which IS the
  *   NHWC view of matching.py:18-20's permuted tensor); create_backbone.py:22-36 (ConvBR, BN folded
- *   into W/bias by the host in eval mode); model/EMIP_long/LTM.py:30-41,74-79. */
+ *   into W/bias by the host in eval mode); model/EMIP_long/LTM.py:30-41,74-79.
+ * zero_ptr (may be NULL): zero_bytes of scratch cleared by the kernel's first workgroup -- the statistics buffer of the
+ * InstanceNorm / BatchNorm that follows, so that emip_chan_stats(prezeroed = 1) needs no separate zero-fill launch. */
 int emip_conv2d(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd, int Cin,
-                long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act, int dtype,
-                void* stream);
+                long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act, void* zero_ptr,
+                long zero_bytes, int dtype, void* stream);
 
 /* Fused attention  O = softmax(Q K^T * scale + mask) V  (online softmax, scores never stored unless S!=NULL).
  * Replaces: lib/pvt_v2.py:121-125 (SRA, D=DV=64, Lk=121); gmflow/transformer.py:46-105 (split-window
@@ -90,15 +92,18 @@ int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K, long ldk, 
 
 /* ---- normalisations ------------------------------------------------------------------------ */
 
-/* Row LayerNorm over C channels (biased variance).  nn.LayerNorm call sites lib/pvt_v2.py:137,144,189,78,302
- * (eps 1e-6 / 1e-5), gmflow/transformer.py:134,145, PromptInteract.py:346-349 (WithBias_LayerNorm). */
-int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta, long M, int C,
-                   float eps, int dtype, void* stream);
+/* Row LayerNorm over C channels (biased variance): Y = LN(X) [+ R].  nn.LayerNorm call sites lib/pvt_v2.py:137,144,189,
+ * 78,302 (eps 1e-6 / 1e-5), gmflow/transformer.py:134,145 (R = the residual stream of `source + message`, :196),
+ * PromptInteract.py:346-349 (WithBias_LayerNorm).  R may be NULL and may alias Y. */
+int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta, const void* R,
+                   long ldr, long M, int C, float eps, int dtype, void* stream);
 
-/* Per-(group, channel) sum / sum-of-squares over `rows` rows -> sums f64 [groups][C][2] (zeroed inside).
+/* Per-(group, channel) sum / sum-of-squares over `rows` rows -> sums f64 [groups][C][2] (zeroed inside unless
+ * prezeroed != 0: the producing emip_conv2d cleared it through its zero_ptr).
  * groups = images for nn.InstanceNorm2d (gmflow/backbone.py:40,50-53), 1 for train-mode BatchNorm2d
  * (create_backbone.py:28, model.py:60). */
-int emip_chan_stats(const void* X, long ldx, double* sums, long groups, long rows, int C, int dtype, void* stream);
+int emip_chan_stats(const void* X, long ldx, double* sums, long groups, long rows, int C, int prezeroed, int dtype,
+                    void* stream);
 
 /* y = [relu]( R + [relu]( (x-mean)*rstd [*gamma+beta] ) ) using emip_chan_stats output.
  * gmflow/backbone.py:61-69 (ResidualBlock tail) and train-mode ConvBR. */
