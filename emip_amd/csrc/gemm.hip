@@ -37,6 +37,13 @@ struct GemmArgs {
     // batching over blockIdx.z
     long bsA, bsW, bsC, bsR;
     int tiles_m, tiles_n;
+    // LayerNorm elimination: ln_stats [rows of A][2] = (sum x, sum x^2) over ln_C channels of every A
+    // row / input pixel -> the operand loader feeds (x - mean) * rstd to the MFMA (gamma / beta are folded into W / bias by
+    // the host); out_stats [M][2]: the epilogue accumulates the same sums of the rows it writes (zeroed by an earlier kernel)
+    const float* ln_stats;
+    float* out_stats;
+    int ln_C;
+    float ln_eps;
     unsigned* zero_ptr;   // optional scratch the first workgroup clears (saves the consumer's zero-fill launch)
     long zero_words;
     int dbg;   // experiment flags (emip_debug_set key 2): 1 = skip epilogue stores, 2 = skip global loads in the K loop
@@ -70,7 +77,15 @@ struct Mma<float> {
 // NBUF = 3: LDS-DMA variant (dense GEMM with K a multiple of the K tile): global_load_lds_dwordx4 writes the
 //           tiles straight into two LDS buffers (no staging VGPRs, no ds_write traffic -- the register-staged
 //           loop is bound by the ds_write_b128 rate); the XOR swizzle moves to the per-lane SOURCE address.
-template <typename T, int BM, int BN, bool CONV, int NBUF>
+template <typename T>
+__device__ __forceinline__ uint4 ln_apply(uint4 v, float mu, float rs) {
+    T* e = reinterpret_cast<T*>(&v);
+#pragma unroll
+    for (int j = 0; j < (int)(16 / sizeof(T)); ++j) e[j] = from_f32<T>((to_f32<T>(e[j]) - mu) * rs);
+    return v;
+}
+
+template <typename T, int BM, int BN, bool CONV, int NBUF, bool LNA = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int VEC = 16 / sizeof(T);   // elements per 16-B chunk
     constexpr int BK = 128 / sizeof(T);   // K elements per tile
@@ -135,10 +150,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     // Loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a load inside an
     // `if` makes hipcc branch around it and wait for it on the spot, which serialises the tile's loads.
+    // LNA: per-row (sum, sum of squares) of the A operand's source rows; the normalisation itself happens in store_tile, when
+    // the data has arrived, so that the global loads of a tile stay back to back
+    float2 ln_st[LNA ? CA : 1];
+    unsigned ln_ok = 0;
+    if (LNA && !CONV) {
+#pragma unroll
+        for (int i = 0; i < CA; ++i) ln_st[LNA ? i : 0] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * a_off[i]);
+    }
     auto load_tile = [&](int k0, uint4 (&ra)[CA], uint4 (&rw)[CW]) {
         const int kk = k0 + sc * VEC;
         const bool kok = kk < p.K;
         const int kkc = kok ? kk : 0;
+        if (LNA) ln_ok = 0;
         if (CONV) {
             const int tap = kkc / p.Cin;
             const int ci = kkc - tap * p.Cin;
@@ -148,8 +172,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
                 const bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
                 const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.Wd - 1);
-                const uint4 v = *reinterpret_cast<const uint4*>(A + (a_off[i] + (long)iyc * p.Wd + ixc) * p.lda + ci);
+                const long pix = a_off[i] + (long)iyc * p.Wd + ixc;
+                const uint4 v = *reinterpret_cast<const uint4*>(A + pix * p.lda + ci);
                 ra[i] = mask4(v, ok);
+                if (LNA) {
+                    ln_st[LNA ? i : 0] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * pix);
+                    ln_ok |= ok ? (1u << i) : 0u;
+                }
             }
         } else {
             const bool second = kkc >= p.K1;
@@ -160,6 +189,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < CA; ++i) {
                 const uint4 v = *reinterpret_cast<const uint4*>(base + a_off[i] * ld + kc);
                 ra[i] = mask4(v, kok && a_ok[i]);
+                if (LNA) ln_ok |= (kok && a_ok[i]) ? (1u << i) : 0u;
             }
         }
 #pragma unroll
@@ -172,7 +202,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         char* ta = smem + buf * TILE_BYTES;
         char* tw = ta + BM * 128;
 #pragma unroll
-        for (int i = 0; i < CA; ++i) *reinterpret_cast<uint4*>(ta + (srow + 32 * i) * 128 + swz_c) = ra[i];
+        for (int i = 0; i < CA; ++i) {
+            uint4 v = ra[i];
+            if (LNA) {
+                const float2 st = ln_st[LNA ? i : 0];
+                const float mu = st.x / (float)p.ln_C;
+                const float rs = rsqrtf(fmaxf(st.y / (float)p.ln_C - mu * mu, 0.f) + p.ln_eps);
+                v = mask4(ln_apply<T>(v, mu, rs), (ln_ok >> i) & 1u);      // padding / tail stays exactly zero
+            }
+            *reinterpret_cast<uint4*>(ta + (srow + 32 * i) * 128 + swz_c) = v;
+        }
 #pragma unroll
         for (int i = 0; i < CW; ++i) *reinterpret_cast<uint4*>(tw + (srow + 32 * i) * 128 + swz_c) = rw[i];
     };
@@ -365,6 +404,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             const int row = er0 + RPI * i;
             const int m = m0 + wm * WM + 16 * b + row;
             const int n = nb + cg * VEC;
+            float st1 = 0.f, st2 = 0.f;
             if (m < p.M && n < p.N) {
                 float v[VEC];
 #pragma unroll
@@ -383,6 +423,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) o[j] = from_f32<T>(v[j]);
                     *reinterpret_cast<uint4*>(C + (long)m * p.ldc + n) = ov;
+                    if (p.out_stats) {       // statistics of the STORED (rounded) values, like a LayerNorm that reads them back
+#pragma unroll
+                        for (int j = 0; j < VEC; ++j) {
+                            const float q = to_f32<T>(o[j]);
+                            st1 += q;
+                            st2 += q * q;
+                        }
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < VEC; ++j) {
@@ -392,6 +440,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                             C[(long)m * p.ldc + n + j] = from_f32<T>(o);
                         }
                     }
+                }
+            }
+            if (p.out_stats) {
+                // the CG lanes that hold one row's column groups are adjacent: reduce, then one atomic pair per row and
+                // 64-column wave block (every lane takes part in the shuffles, rows >= M contribute zeros)
+#pragma unroll
+                for (int o = CG >> 1; o > 0; o >>= 1) {
+                    st1 += __shfl_xor(st1, o);
+                    st2 += __shfl_xor(st2, o);
+                }
+                if (cg == 0 && m < p.M) {
+                    atomicAdd(p.out_stats + 2 * ((long)z * p.M + m), st1);
+                    atomicAdd(p.out_stats + 2 * ((long)z * p.M + m) + 1, st2);
                 }
             }
         }
@@ -412,6 +473,10 @@ int launch(GemmArgs& a, int batch, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.dbg = g_gemm_dbg;
     dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
+    if (a.ln_stats) {          // normalising operand loader: the register-staged loop (the LDS-DMA path cannot touch the data)
+        hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 1, true>), grid, dim3(256), (BM + BN) * 128, s, a);
+        return emip_launch_status();
+    }
     if constexpr (!CONV) {
         constexpr int BKE = 128 / sizeof(T);
         if (g_gemm_glds && a.K % BKE == 0 && a.K1 % BKE == 0) {
@@ -463,9 +528,33 @@ int dispatch(GemmArgs& a, int batch, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int emip_gemm_ln(const void*, const void*, const void*, void*, const float*, const void*, int, int, int, int, long,
+                            long, long, long, long, int, int, long, long, long, long, const float*, int, float, float*, void*,
+                            long, int, void*);
+extern "C" int emip_conv2d_ln(const void*, const void*, void*, const float*, const void*, int, int, int, int, long, int, int, int,
+                              int, int, long, long, int, void*, long, const float*, float, float*, int, void*);
+
+static int check_ln(const GemmArgs& a, int batch, bool fast_epilogue) {
+    if (a.ln_stats) EMIP_REQUIRE(a.ln_C > 0 && a.ln_eps > 0.f && a.A2 == nullptr && batch == 1 &&
+                                 (reinterpret_cast<uintptr_t>(a.ln_stats) & 7) == 0);
+    if (a.out_stats) EMIP_REQUIRE(fast_epilogue && (reinterpret_cast<uintptr_t>(a.out_stats) & 3) == 0);
+    return EMIP_OK;
+}
+
 extern "C" int emip_gemm(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R,
                          int M, int N, int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act,
                          int batch, long bsA, long bsW, long bsC, long bsR, int dtype, void* stream) {
+    return emip_gemm_ln(A, A2, W, C, bias, R, M, N, K, K1, lda, lda2, ldw, ldc, ldr, act, batch, bsA, bsW, bsC, bsR,
+                        nullptr, 0, 0.f, nullptr, nullptr, 0, dtype, stream);
+}
+
+// emip_gemm plus the LayerNorm-elimination hooks: ln_stats [M][2] (sum, sum of squares over ln_C = K channels of every A
+// row): the loader feeds (x - mean) * rstd; out_stats [M][2]: row sums of the stored output, accumulated with atomics
+// (cleared beforehand, e.g. through an earlier launch's zero_ptr); zero_ptr / zero_bytes: scratch this launch clears.
+extern "C" int emip_gemm_ln(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R,
+                            int M, int N, int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act,
+                            int batch, long bsA, long bsW, long bsC, long bsR, const float* ln_stats, int ln_C,
+                            float ln_eps, float* out_stats, void* zero_ptr, long zero_bytes, int dtype, void* stream) {
     EMIP_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && batch > 0);
     EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
     const int vec = dtype == EMIP_F32 ? 4 : 8;
@@ -485,6 +574,15 @@ extern "C" int emip_gemm(const void* A, const void* A2, const void* W, void* C, 
     a.M = M; a.N = N; a.K = K; a.K1 = K1;
     a.lda = lda; a.lda2 = lda2; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.act = act;
     a.bsA = bsA; a.bsW = bsW; a.bsC = bsC; a.bsR = bsR;
+    a.ln_stats = ln_stats; a.ln_C = ln_C; a.ln_eps = ln_eps; a.out_stats = out_stats;
+    if (zero_ptr) EMIP_REQUIRE(zero_bytes > 0 && (zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0);
+    a.zero_ptr = static_cast<unsigned*>(zero_ptr);
+    a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
+    {
+        const bool fast = (ldc % vec) == 0 && aligned16(C) && N % vec == 0 &&
+                          (R == nullptr || ((ldr % vec) == 0 && aligned16(R)));
+        if (check_ln(a, batch, fast) != EMIP_OK) return EMIP_E_INVALID;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == EMIP_F32 ? dispatch<float, false>(a, batch, s) : dispatch<bf16_t, false>(a, batch, s);
 }
@@ -492,6 +590,17 @@ extern "C" int emip_gemm(const void* A, const void* A2, const void* W, void* C, 
 extern "C" int emip_conv2d(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H,
                            int Wd, int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy,
                            long ldr, int act, void* zero_ptr, long zero_bytes, int dtype, void* stream) {
+    return emip_conv2d_ln(X, W, Y, bias, R, B, H, Wd, Cin, ldx, Cout, KH, KW, stride, pad, ldy, ldr, act, zero_ptr,
+                          zero_bytes, nullptr, 0.f, nullptr, dtype, stream);
+}
+
+// emip_conv2d plus the LayerNorm-elimination hooks: ln_stats [B*H*W][2] (sum, sum of squares over the Cin channels of
+// every INPUT pixel): the im2col loader feeds (x - mean) * rstd (zero padding stays zero); out_stats [B*Ho*Wo][2]: row sums
+// of the stored output pixels, accumulated with atomics.
+extern "C" int emip_conv2d_ln(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H,
+                              int Wd, int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy,
+                              long ldr, int act, void* zero_ptr, long zero_bytes, const float* ln_stats, float ln_eps,
+                              float* out_stats, int dtype, void* stream) {
     EMIP_REQUIRE(X && W && Y && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0);
     if (zero_ptr) EMIP_REQUIRE(zero_bytes > 0 && (zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0);
     EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
@@ -511,6 +620,12 @@ extern "C" int emip_conv2d(const void* X, const void* W, void* Y, const float* b
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
     a.zero_ptr = static_cast<unsigned*>(zero_ptr);
     a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
+    a.ln_stats = ln_stats; a.ln_C = Cin; a.ln_eps = ln_eps; a.out_stats = out_stats;
+    {
+        const bool fast = (ldy % vec) == 0 && aligned16(Y) && Cout % vec == 0 &&
+                          (R == nullptr || ((ldr % vec) == 0 && aligned16(R)));
+        if (check_ln(a, 1, fast) != EMIP_OK) return EMIP_E_INVALID;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == EMIP_F32 ? dispatch<float, true>(a, 1, s) : dispatch<bf16_t, true>(a, 1, s);
 }

@@ -22,8 +22,9 @@ inline int grid_for(long work_items, int threads) {
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy,
                                                         const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, const T* R, long ldr, long M,
-                                                        int C, float eps, int lpr_log2) {
+                                                        const float* __restrict__ beta, const T* R, long ldr,
+                                                        float* __restrict__ out_stats, long M, int C, float eps,
+                                                        int lpr_log2) {
     const int LPR = 1 << lpr_log2;
     const int lane = threadIdx.x & 63;
     const int sub = lane & (LPR - 1);
@@ -64,6 +65,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X,
         }
         for (int o = LPR >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
         const float rstd = rsqrtf(q / (float)C + eps);
+        float os1 = 0.f, os2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int vi = sub + i * LPR;
@@ -78,6 +80,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X,
                     for (int j = 0; j < 4; ++j) o4[j] += r4[j];
                 }
                 Vec4<T>::store(Y + row * ldy + vi * 4, o4);
+                if (out_stats) {              // sums of the STORED (rounded) row: input of a LayerNorm folded into its consumer
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float q = to_f32<T>(from_f32<T>(o4[j]));
+                        os1 += q;
+                        os2 += q * q;
+                    }
+                }
+            }
+        }
+        if (out_stats) {                      // wave-uniform
+            for (int o = LPR >> 1; o > 0; o >>= 1) {
+                os1 += __shfl_xor(os1, o);
+                os2 += __shfl_xor(os2, o);
+            }
+            if (ok && sub == 0) {
+                out_stats[2 * row] = os1;
+                out_stats[2 * row + 1] = os2;
             }
         }
     }
@@ -691,7 +711,8 @@ struct TypeOf { typedef T type; };
 extern "C" int emip_version(void) { return 100; }
 
 extern "C" int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta,
-                              const void* R, long ldr, long M, int C, float eps, int dtype, void* stream) {
+                              const void* R, long ldr, float* out_stats, long M, int C, float eps, int dtype,
+                              void* stream) {
     REQ_DT(dtype);
     EMIP_REQUIRE(X && Y && gamma && beta && M > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
     EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
@@ -703,7 +724,8 @@ extern "C" int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const 
     const long waves = (M + rows_per_wave - 1) / rows_per_wave;
     const int grid = grid_for(waves, 4);
     DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                                         (const T*)X, ldx, (T*)Y, ldy, gamma, beta, (const T*)R, ldr, M, C, eps, lg));
+                                         (const T*)X, ldx, (T*)Y, ldy, gamma, beta, (const T*)R, ldr, out_stats, M, C, eps,
+                                         lg));
     return emip_launch_status();
 }
 

@@ -21,6 +21,13 @@ from ..nn_base import EmipModule, f32, pack_conv, pack_dw, pack_linear, to_cl, t
 # so the two-kernel path stays the default.
 FUSED_MLP_TAIL = False
 
+# LayerNorm elimination on the inference path: the three LayerNorms of a block (norm1, norm2 and the one
+# behind the spatial-reduction conv) are not launched at all.  The producer of the residual stream (proj / fc2 GEMM, the sr
+# conv, the patch-embed LayerNorm) accumulates per-row (sum, sum of squares) in its epilogue, gamma is folded into the
+# consumer's weights and beta into its bias when the weights are packed, and the consumer's operand loader feeds
+# (x - mean) * rstd to the MFMA.
+FUSED_LN = True
+
 
 def _lin_packs(w, dt):
     """forward pack [N,K] and input-gradient pack [K,N] of a Linear weight"""
@@ -166,6 +173,65 @@ class Block(EmipModule):
             s = torch.floor(keep + torch.rand(B, device=x.device)) / keep
         return s.view(B, 1).expand(B, C).contiguous()
 
+    def _folded(self):
+        """packed weights with the block's LayerNorm affines folded in: y = LN(x) W^T + b = xhat (W*gamma)^T + (b + W beta)"""
+        dt, a, m = self.cdtype, self.attn, self.mlp
+        sr = a.sr_ratio
+
+        def build(g1, b1, g2, b2, wq, bq, wkv, bkv, wp, bp, w1, bb1, wd, bd, w2, bb2, *srp):
+            f = lambda t: t.detach().float()
+            g1, b1, g2, b2 = f(g1), f(b1), f(g2), f(b2)
+            out = dict(q=(f(wq) * g1).to(dt).contiguous(), bq=(f(bq) + f(wq) @ b1).contiguous(),
+                       p=pack_linear(wp, dt), bp=f32(bp),
+                       w1=(f(w1) * g2).to(dt).contiguous(), b1=(f(bb1) + f(w1) @ b2).contiguous(),
+                       wd=pack_dw(wd), bd=f32(bd), w2=pack_linear(w2, dt), b2=f32(bb2))
+            if sr > 1:
+                wsr, bsr, gs, bs = (f(t) for t in srp)
+                out.update(sr=pack_conv(wsr * g1.view(1, -1, 1, 1), dt),
+                           bsr=(bsr + (wsr * b1.view(1, -1, 1, 1)).sum((1, 2, 3))).contiguous(),
+                           kv=(f(wkv) * gs).to(dt).contiguous(), bkv=(f(bkv) + f(wkv) @ bs).contiguous())
+            else:
+                out.update(kv=(f(wkv) * g1).to(dt).contiguous(), bkv=(f(bkv) + f(wkv) @ b1).contiguous())
+            return out
+        params = (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, a.q.weight, a.q.bias,
+                  a.kv.weight, a.kv.bias, a.proj.weight, a.proj.bias, m.fc1.weight, m.fc1.bias,
+                  m.dwconv.dwconv.weight, m.dwconv.dwconv.bias, m.fc2.weight, m.fc2.bias)
+        if sr > 1:
+            params += (a.sr.weight, a.sr.bias, a.norm.weight, a.norm.bias)
+        return self.packed("fln", params, build)
+
+    def run_fused(self, x, stats):
+        """Inference block without LayerNorm launches.  x [B,H,W,C] (updated in place), stats f32 [B*H*W, 2] = (sum, sum of
+        squares) of its rows -> (x, stats of the new rows)."""
+        a = self.attn
+        dt, C, heads, sr = self.cdtype, a.dim, a.num_heads, a.sr_ratio
+        B, H, W, _ = x.shape
+        N = H * W
+        M = B * N
+        w = self._folded()
+        Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
+        buf = torch.empty(2 * (Ms + 2 * M), dtype=torch.float32, device=x.device)
+        st_sr, st1, st2 = buf[:2 * Ms], buf[2 * Ms:2 * Ms + 2 * M], buf[2 * Ms + 2 * M:]
+        # the first launch of the block clears the statistics the sr conv and the proj GEMM will accumulate into
+        q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, zero=buf[:2 * Ms + 2 * M])
+        if sr > 1:
+            s = ops.conv2d(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps,
+                           out_stats=st_sr)
+            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps)
+        else:
+            s = x
+            kv = ops.gemm(x, w["kv"], bias=w["bkv"], ln_stats=stats, ln_eps=self.norm1.eps)
+        Lk = s.shape[1] * s.shape[2]
+        att = torch.empty((B, H, W, C), dtype=dt, device=x.device)
+        ops.attention(q, kv, kv[..., C:], att, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
+                      k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
+                      k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
+        ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)                          # x += proj(attn)
+        t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, zero=st2)
+        t = ops.dwconv3x3(t, w["wd"], w["bd"], act=ops.ACT_GELU)
+        ops.gemm(t, w["w2"], bias=w["b2"], res=x, out=x, out_stats=st2)                           # x += mlp(...)
+        return x, st2
+
     def run(self, x):
         if self.training and self.drop_path_rate > 0:
             # stochastic depth: the branch is computed without the fused residual, then scaled per sample
@@ -199,7 +265,7 @@ class OverlapPatchEmbed(EmipModule):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
         self.norm = nn.LayerNorm(embed_dim)
 
-    def run(self, x):
+    def run(self, x, out_stats=None):
         dt = self.cdtype
         cin = x.shape[-1]  # the image arrives with its 3 channels zero-padded to 8
         if torch.is_grad_enabled():
@@ -211,7 +277,7 @@ class OverlapPatchEmbed(EmipModule):
         w, b, g, be = self.packed("pe", (self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias),
                                   lambda a, bb, c, d: (pack_conv(a, dt, cin_pad=cin), f32(bb), f32(c), f32(d)))
         y = ops.conv2d(x, w, self.patch_size, self.patch_size, self.stride, self.patch_size // 2, bias=b)
-        return ops.layernorm(y, g, be, self.norm.eps, out=y)
+        return ops.layernorm(y, g, be, self.norm.eps, out=y, out_stats=out_stats)
 
 
 class PyramidVisionTransformerV2(EmipModule):
@@ -238,9 +304,21 @@ class PyramidVisionTransformerV2(EmipModule):
         """x: channels-last image [B,H,W,8] -> list of the 4 stage outputs, channels-last."""
         outs = []
         for i in range(self.num_stages):
-            x = getattr(self, f"patch_embed{i + 1}").run(x)
-            for blk in getattr(self, f"block{i + 1}"):
-                x = blk.run(x)
+            pe = getattr(self, f"patch_embed{i + 1}")
+            blocks = getattr(self, f"block{i + 1}")
+            if FUSED_LN and not torch.is_grad_enabled() and not (self.training and any(b.drop_path_rate > 0 for b in blocks)):
+                # no LayerNorm launches inside the blocks: row statistics travel with the residual stream
+                st = pe.stride
+                Ho, Wo = (x.shape[1] + 2 * (pe.patch_size // 2) - pe.patch_size) // st + 1, \
+                         (x.shape[2] + 2 * (pe.patch_size // 2) - pe.patch_size) // st + 1
+                stats = torch.empty(2 * x.shape[0] * Ho * Wo, dtype=torch.float32, device=x.device)
+                x = pe.run(x, out_stats=stats)
+                for blk in blocks:
+                    x, stats = blk.run_fused(x, stats)
+            else:
+                x = pe.run(x)
+                for blk in blocks:
+                    x = blk.run(x)
             norm = getattr(self, f"norm{i + 1}")
             if torch.is_grad_enabled():
                 x = LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)

@@ -43,8 +43,15 @@ def rows(t):
     return m, t.shape[-1], ld
 
 
-def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None):
-    """out[m, n] = act(a[m, :] . w[n, :] (+ a2 . w[n, K1:]) + bias[n]) + res[m, n]"""
+def _nbytes(t):
+    return t.numel() * t.element_size() if t is not None else 0
+
+
+def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=None, ln_eps=0.0, out_stats=None,
+         zero=None):
+    """out[m, n] = act(a[m, :] . w[n, :] (+ a2 . w[n, K1:]) + bias[n]) + res[m, n]
+    ln_stats f32 [M,2]: normalise the rows of a on the fly ((x - mean) * rstd; gamma / beta folded into w / bias);
+    out_stats f32 [M,2]: accumulate (sum, sum of squares) of the stored rows; zero: scratch tensor this launch clears."""
     M, K1, lda = rows(a)
     N, K = w.shape
     lda2 = 0
@@ -63,8 +70,15 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None):
         assert Mr == M and Nr == N and res.dtype == a.dtype
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == N
-    _lib.call("emip_gemm", _p(a), _p(a2), _p(w), _p(out), _p(bias), _p(res), M, N, K, K1, lda, lda2, K, ldc, ldr, act,
-              1, 0, 0, 0, 0, dt_code(a.dtype), _stream())
+    if ln_stats is None and out_stats is None and zero is None:
+        _lib.call("emip_gemm", _p(a), _p(a2), _p(w), _p(out), _p(bias), _p(res), M, N, K, K1, lda, lda2, K, ldc, ldr,
+                  act, 1, 0, 0, 0, 0, dt_code(a.dtype), _stream())
+        return out
+    for t in (ln_stats, out_stats):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 2 * M)
+    _lib.call("emip_gemm_ln", _p(a), _p(a2), _p(w), _p(out), _p(bias), _p(res), M, N, K, K1, lda, lda2, K, ldc, ldr, act,
+              1, 0, 0, 0, 0, _p(ln_stats), K, float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), dt_code(a.dtype),
+              _stream())
     return out
 
 
@@ -76,7 +90,8 @@ def gemm_batched(a, w, out, batch, M, N, K, lda, ldw, ldc, bsA, bsW, bsC):
     return out
 
 
-def conv2d(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None, zero=None):
+def conv2d(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None, zero=None, ln_stats=None,
+           ln_eps=0.0, out_stats=None):
     """x [B,H,W,Cin] channels-last, w packed [Cout, kh*kw*Cin] -> [B,Ho,Wo,Cout]."""
     _dev(x)
     B, H, W, Cin = x.shape
@@ -95,22 +110,28 @@ def conv2d(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out
         Mr, Nr, ldr = rows(res)
         assert Mr == Mo and Nr == Cout
     # zero: a scratch tensor the kernel's first workgroup clears (the statistics buffer of the normalisation that follows)
-    _lib.call("emip_conv2d", _p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, ldx, Cout, kh, kw, stride, pad,
-              ldy, ldr, act, _p(zero), zero.numel() * zero.element_size() if zero is not None else 0,
-              dt_code(x.dtype), _stream())
+    if ln_stats is None and out_stats is None:
+        _lib.call("emip_conv2d", _p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, ldx, Cout, kh, kw, stride, pad,
+                  ldy, ldr, act, _p(zero), _nbytes(zero), dt_code(x.dtype), _stream())
+        return out
+    assert ln_stats is None or (ln_stats.dtype == torch.float32 and ln_stats.numel() == 2 * B * H * W)
+    assert out_stats is None or (out_stats.dtype == torch.float32 and out_stats.numel() == 2 * Mo)
+    _lib.call("emip_conv2d_ln", _p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, ldx, Cout, kh, kw, stride, pad,
+              ldy, ldr, act, _p(zero), _nbytes(zero), _p(ln_stats), float(ln_eps), _p(out_stats), dt_code(x.dtype),
+              _stream())
     return out
 
 
-def layernorm(x, gamma, beta, eps, out=None, res=None):
-    """LN(x) [+ res]; out may alias x or res"""
+def layernorm(x, gamma, beta, eps, out=None, res=None, out_stats=None):
+    """LN(x) [+ res]; out may alias x or res.  out_stats f32 [M,2]: (sum, sum of squares) of the stored rows"""
     M, C, ldx = rows(x)
     if out is None:
         out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     Mo, Co, ldy = rows(out)
     assert Mo == M and Co == C
     ldr = rows(res)[2] if res is not None else 0
-    _lib.call("emip_layernorm", _p(x), ldx, _p(out), ldy, _p(gamma), _p(beta), _p(res), ldr, M, C, float(eps),
-              dt_code(x.dtype), _stream())
+    _lib.call("emip_layernorm", _p(x), ldx, _p(out), ldy, _p(gamma), _p(beta), _p(res), ldr, _p(out_stats), M, C,
+              float(eps), dt_code(x.dtype), _stream())
     return out
 
 

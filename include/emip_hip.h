@@ -50,6 +50,20 @@ int emip_gemm(const void* A, const void* A2, const void* W, void* C, const float
               int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, int batch, long bsA, long bsW,
               long bsC, long bsR, int dtype, void* stream);
 
+/* emip_gemm with the LayerNorm-elimination hooks (lib/pvt_v2.py:165-167: x + attn(norm1(x)), x + mlp(norm2(x)); :108-110:
+ * kv(norm(sr(x)))).  The LayerNorm in front of a Linear / conv is folded away: gamma into the weights and beta into the
+ * bias at pack time (y = LN(x) W^T + b = ((x - mean) rstd) (W * gamma)^T + (b + W beta)), the per-row mean / rstd from
+ *   ln_stats  f32 [M][2] = (sum x, sum x^2) over the ln_C = K channels of every A row: the operand loader feeds
+ *             (x - mean) * rstd (biased variance, eps = ln_eps) to the MFMA;
+ *   out_stats f32 [M][2]: (sum, sum of squares) of the rows this launch stores, accumulated with atomics -- the ln_stats
+ *             of the next consumer; it must be zero beforehand, e.g. through an earlier launch's
+ *   zero_ptr / zero_bytes: scratch the first workgroup of this launch clears.
+ * Every hook may be NULL; emip_gemm is this function with all of them NULL. */
+int emip_gemm_ln(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M, int N,
+                 int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, int batch, long bsA, long bsW,
+                 long bsC, long bsR, const float* ln_stats, int ln_C, float ln_eps, float* out_stats, void* zero_ptr,
+                 long zero_bytes, int dtype, void* stream);
+
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
 int emip_gemm_tile(long M, long N, long batch, long K);
 
@@ -69,6 +83,12 @@ int emip_debug_set_tn(int target_workgroups);   /* 0 = heuristic split count of 
 int emip_conv2d(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd, int Cin,
                 long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act, void* zero_ptr,
                 long zero_bytes, int dtype, void* stream);
+
+/* emip_conv2d with the same hooks: ln_stats f32 [B*H*W][2] over the Cin channels of every INPUT pixel (zero padding stays
+ * zero), out_stats f32 [B*Ho*Wo][2] of the stored output pixels. */
+int emip_conv2d_ln(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd, int Cin,
+                   long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act, void* zero_ptr,
+                   long zero_bytes, const float* ln_stats, float ln_eps, float* out_stats, int dtype, void* stream);
 
 /* Fused attention  O = softmax(Q K^T * scale + mask) V  (online softmax, scores never stored unless S!=NULL).
  * Replaces: lib/pvt_v2.py:121-125 (SRA, D=DV=64, Lk=121); gmflow/transformer.py:46-105 (split-window
@@ -96,7 +116,9 @@ int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K, long ldk, 
  * 78,302 (eps 1e-6 / 1e-5), gmflow/transformer.py:134,145 (R = the residual stream of `source + message`, :196),
  * PromptInteract.py:346-349 (WithBias_LayerNorm).  R may be NULL and may alias Y. */
 int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const float* gamma, const float* beta, const void* R,
-                   long ldr, long M, int C, float eps, int dtype, void* stream);
+                   long ldr, float* out_stats, long M, int C, float eps, int dtype, void* stream);
+/* out_stats (may be NULL): f32 [M][2] = (sum, sum of squares) of every stored output row -- the input of a following
+ * LayerNorm that is folded into its consumer (emip_gemm_ln / emip_conv2d_ln). */
 
 /* Per-(group, channel) sum / sum-of-squares over `rows` rows -> sums f64 [groups][C][2] (zeroed inside unless
  * prezeroed != 0: the producing emip_conv2d cleared it through its zero_ptr).

@@ -381,3 +381,62 @@ def test_mlp_head_matches_unfused(dt, tol, B, H, W, C, ratio, variant):
         _lib.call("emip_debug_set_head", 0)
     err = (y.float().cpu() - ref).abs().max().item()
     assert err < tol * max(1.0, ref.abs().max().item()), err
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("M,N,K", [(3872, 320, 320), (968, 640, 320), (500, 64, 64), (7744, 512, 128)])
+def test_gemm_with_folded_layernorm_and_row_statistics(dt, tol, M, N, K):
+    """emip_gemm_ln: LN folded into the consumer (loader normalisation + gamma/beta in the weights) == LN then Linear;
+    producer row statistics == sums of the stored rows; LayerNorm's own out_stats likewise"""
+    from emip_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    x = (torch.randn(M, K, generator=g) * 1.5 + 0.7).to(dt)
+    gamma, beta = 1 + 0.1 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = 0.1 * torch.randn(N, generator=g)
+    res = torch.randn(M, N, generator=g).to(dt)
+    ref = torch.nn.functional.layer_norm(x.float(), (K,), gamma, beta, 1e-6) @ w.t() + b + res.float()
+    dev = "cuda:0"
+    xs = x.to(dev)
+    stats = torch.stack([xs.float().sum(1), (xs.float() ** 2).sum(1)], 1).contiguous()
+    wf = (w * gamma).to(dt).to(dev).contiguous()                 # gamma folded into the weights
+    bf = (b + w @ beta).to(dev)                                  # beta folded into the bias
+    out_stats = torch.zeros(M, 2, device=dev)
+    y = ops.gemm(xs, wf, bias=bf, res=res.to(dev), ln_stats=stats, ln_eps=1e-6, out_stats=out_stats)
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), err
+    want = torch.stack([y.float().sum(1), (y.float() ** 2).sum(1)], 1)
+    assert ((out_stats - want).abs() / (want.abs() + 1.0)).max().item() < 1e-3
+    # the scratch-clearing hook: a following launch zeroes a buffer while doing its own work
+    scratch = torch.ones(37, device=dev)
+    ops.gemm(xs, wf, bias=bf, zero=scratch)
+    assert scratch.abs().max().item() == 0
+    ls = torch.empty(M, 2, device=dev)
+    z = ops.layernorm(xs, gamma.to(dev), beta.to(dev), 1e-6, out_stats=ls)
+    wantl = torch.stack([z.float().sum(1), (z.float() ** 2).sum(1)], 1)
+    assert ((ls - wantl).abs() / (wantl.abs() + 1.0)).max().item() < 1e-3
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,H,C,k", [(2, 88, 64, 8), (3, 44, 128, 4), (2, 22, 320, 2)])
+def test_sr_conv_with_folded_layernorm(dt, tol, B, H, C, k):
+    """emip_conv2d_ln on the spatial-reduction conv (kernel = stride): per-INPUT-pixel normalisation in the im2col loader"""
+    from emip_amd import ops
+    g = torch.Generator().manual_seed(B + H)
+    x = (torch.randn(B, H, H, C, generator=g) + 0.3).to(dt)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w = torch.randn(C, C, k, k, generator=g) / (C * k * k) ** 0.5
+    b = 0.1 * torch.randn(C, generator=g)
+    xn = torch.nn.functional.layer_norm(x.float(), (C,), gamma, beta, 1e-6)
+    ref = torch.nn.functional.conv2d(xn.permute(0, 3, 1, 2), w, b, stride=k).permute(0, 2, 3, 1)
+    dev = "cuda:0"
+    xs = x.to(dev)
+    stats = torch.stack([xs.float().sum(-1), (xs.float() ** 2).sum(-1)], -1).view(-1, 2).contiguous()
+    wf = (w * gamma.view(1, C, 1, 1)).permute(0, 2, 3, 1).reshape(C, -1).to(dt).to(dev).contiguous()
+    bf = (b + (w * beta.view(1, C, 1, 1)).sum((1, 2, 3))).to(dev)
+    out_stats = torch.zeros(B * (H // k) ** 2, 2, device=dev)
+    y = ops.conv2d(xs, wf, k, k, k, 0, bias=bf, ln_stats=stats, ln_eps=1e-6, out_stats=out_stats)
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), err
+    want = torch.stack([y.float().sum(-1), (y.float() ** 2).sum(-1)], -1).view(-1, 2)
+    assert ((out_stats - want).abs() / (want.abs() + 1.0)).max().item() < 1e-3
