@@ -38,18 +38,21 @@ def _algo_flops(name, a):
         if a[4]:                                            # raw scores (the correlation volume) written out
             byt += 2.0 * z * Lq * Lk
         return 2.0 * z * Lq * Lk * (D + dv), ("attn", D, DV, bkv), byt
-    if name == "emip_gemm":
+    if name in ("emip_gemm", "emip_gemm_ln"):
         M, N, K, batch = a[6], a[7], a[8], a[16]
-        lds_dma = (K % 64 == 0) and (a[9] % 64 == 0)         # bf16: dense GEMMs with whole K tiles use the LDS-DMA loop
+        ln = name == "emip_gemm_ln" and a[21] is not None     # normalising loader: the register-staged loop
+        lds_dma = (K % 64 == 0) and (a[9] % 64 == 0) and not ln   # bf16: dense GEMMs with whole K tiles use LDS-DMA
         K = {344: 340}.get(K, K)
         byt = 2.0 * batch * (M * K + N * K + M * N * (2 if a[5] else 1))
-        return 2.0 * M * N * K * batch, (M, N, batch, False, 3 if lds_dma else 1, a[8]), byt
-    if name == "emip_conv2d":
+        return 2.0 * M * N * K * batch, (M, N, batch, False, ("1,ln" if ln else (3 if lds_dma else 1)), a[8]), byt
+    if name in ("emip_conv2d", "emip_conv2d_ln"):
         B, H, W, Cin, Cout, KH, KW, s, p = a[5], a[6], a[7], a[8], a[10], a[11], a[12], a[13], a[14]
         Ho, Wo = (H + 2 * p - KH) // s + 1, (W + 2 * p - KW) // s + 1
         cin = {8: 3, 136: 130}.get(Cin, Cin)
         byt = 2.0 * (B * H * W * cin + Cout * KH * KW * cin + B * Ho * Wo * Cout * (2 if a[4] else 1))
-        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin, (B * Ho * Wo, Cout, 1, True, 1, KH * KW * Cin), byt
+        ln = name == "emip_conv2d_ln" and a[20] is not None
+        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin, (B * Ho * Wo, Cout, 1, True, "1,ln" if ln else 1,
+                                                          KH * KW * Cin), byt
     return 0.0, None, 0.0
 
 
@@ -84,7 +87,7 @@ def kernel_breakdown(net, im1, im2, splits=1):
             key = "attn_kernel<bf16,%d,%d,%d>" % tile[1:]
         elif tile is not None:
             t = lib.emip_gemm_tile(tile[0], tile[1], tile[2], tile[5])
-            key = "gemm_kernel<bf16,%d,%d,%s,%d>" % (t // 1000, t % 1000, "conv" if tile[3] else "dense", tile[4])
+            key = "gemm_kernel<bf16,%d,%d,%s,%s>" % (t // 1000, t % 1000, "conv" if tile[3] else "dense", tile[4])
         d = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
         d[0] += ms
         d[1] += fl
@@ -106,7 +109,8 @@ def rocprof_avg(key):
         return None
     f = m.group(2).split(",")
     if m.group(1) == "gemm":
-        pat = "gemm_kernelIDF16bLi%sELi%sELb%dELi%sEE" % (f[0], f[1], 1 if f[2] == "conv" else 0, f[3])
+        pat = "gemm_kernelIDF16bLi%sELi%sELb%dELi%sELb%dEE" % (f[0], f[1], 1 if f[2] == "conv" else 0, f[3],
+                                                              1 if len(f) > 4 and f[4] == "ln" else 0)
     else:
         pat = "attn_kernelIDF16bLi%sELi%sELi%sEE" % (f[0], f[1], f[2])
     for r in csv.DictReader(open(path)):

@@ -152,17 +152,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     // `if` makes hipcc branch around it and wait for it on the spot, which serialises the tile's loads.
     // LNA: per-row (sum, sum of squares) of the A operand's source rows; the normalisation itself happens in store_tile, when
     // the data has arrived, so that the global loads of a tile stay back to back
-    float2 ln_st[LNA ? CA : 1];
-    unsigned ln_ok = 0;
+    struct LnStage {
+        float2 st[LNA ? CA : 1];
+        unsigned ok;
+    };
+    float2 ln_row[LNA ? CA : 1];          // dense GEMM: the statistics of this thread's rows never change
     if (LNA && !CONV) {
 #pragma unroll
-        for (int i = 0; i < CA; ++i) ln_st[LNA ? i : 0] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * a_off[i]);
+        for (int i = 0; i < CA; ++i) ln_row[LNA ? i : 0] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * a_off[i]);
     }
-    auto load_tile = [&](int k0, uint4 (&ra)[CA], uint4 (&rw)[CW]) {
+    LnStage ln0, ln1, ln2;                // one per register stage (only ln0 is live outside the 3-stage loop)
+    (void)ln1; (void)ln2;
+    auto load_tile_ln = [&](int k0, uint4 (&ra)[CA], uint4 (&rw)[CW], LnStage& ln) {
         const int kk = k0 + sc * VEC;
         const bool kok = kk < p.K;
         const int kkc = kok ? kk : 0;
-        if (LNA) ln_ok = 0;
+        if (LNA) ln.ok = 0;
         if (CONV) {
             const int tap = kkc / p.Cin;
             const int ci = kkc - tap * p.Cin;
@@ -176,8 +181,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 const uint4 v = *reinterpret_cast<const uint4*>(A + pix * p.lda + ci);
                 ra[i] = mask4(v, ok);
                 if (LNA) {
-                    ln_st[LNA ? i : 0] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * pix);
-                    ln_ok |= ok ? (1u << i) : 0u;
+                    ln.st[LNA ? i : 0] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * pix);
+                    ln.ok |= ok ? (1u << i) : 0u;
                 }
             }
         } else {
@@ -189,7 +194,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < CA; ++i) {
                 const uint4 v = *reinterpret_cast<const uint4*>(base + a_off[i] * ld + kc);
                 ra[i] = mask4(v, kok && a_ok[i]);
-                if (LNA) ln_ok |= (kok && a_ok[i]) ? (1u << i) : 0u;
+                if (LNA) {
+                    ln.st[LNA ? i : 0] = ln_row[LNA ? i : 0];
+                    ln.ok |= (kok && a_ok[i]) ? (1u << i) : 0u;
+                }
             }
         }
 #pragma unroll
@@ -198,23 +206,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
             rw[i] = mask4(v, kok && w_ok[i]);
         }
     };
-    auto store_tile = [&](int buf, const uint4 (&ra)[CA], const uint4 (&rw)[CW]) {
+    auto load_tile = [&](int k0, uint4 (&ra)[CA], uint4 (&rw)[CW]) { load_tile_ln(k0, ra, rw, ln0); };
+    auto store_tile_ln = [&](int buf, const uint4 (&ra)[CA], const uint4 (&rw)[CW], const LnStage& ln) {
         char* ta = smem + buf * TILE_BYTES;
         char* tw = ta + BM * 128;
 #pragma unroll
         for (int i = 0; i < CA; ++i) {
             uint4 v = ra[i];
             if (LNA) {
-                const float2 st = ln_st[LNA ? i : 0];
+                const float2 st = ln.st[LNA ? i : 0];
                 const float mu = st.x / (float)p.ln_C;
                 const float rs = rsqrtf(fmaxf(st.y / (float)p.ln_C - mu * mu, 0.f) + p.ln_eps);
-                v = mask4(ln_apply<T>(v, mu, rs), (ln_ok >> i) & 1u);      // padding / tail stays exactly zero
+                v = mask4(ln_apply<T>(v, mu, rs), (ln.ok >> i) & 1u);      // padding / tail stays exactly zero
             }
             *reinterpret_cast<uint4*>(ta + (srow + 32 * i) * 128 + swz_c) = v;
         }
 #pragma unroll
         for (int i = 0; i < CW; ++i) *reinterpret_cast<uint4*>(tw + (srow + 32 * i) * 128 + swz_c) = rw[i];
     };
+    auto store_tile = [&](int buf, const uint4 (&ra)[CA], const uint4 (&rw)[CW]) { store_tile_ln(buf, ra, rw, ln0); };
 
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -311,24 +321,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         // multiplied.  For grids of about one workgroup per CU (the 121-token spatial-reduction convs: 16-80 workgroups
         // walking K = 1280-4096) nothing else hides the load latency; the staging registers are cheap at 64x64 tiles.
         uint4 ra0[CA], rw0[CW], ra1[CA], rw1[CW], ra2[CA], rw2[CW];
-        load_tile(0, ra0, rw0);
-        if (nk > 1) load_tile(BK, ra1, rw1);
+        load_tile_ln(0, ra0, rw0, ln0);
+        if (nk > 1) load_tile_ln(BK, ra1, rw1, ln1);
         for (int kt = 0; kt < nk; kt += 3) {
-            if (kt + 2 < nk) load_tile((kt + 2) * BK, ra2, rw2);
-            store_tile(0, ra0, rw0);
+            if (kt + 2 < nk) load_tile_ln((kt + 2) * BK, ra2, rw2, ln2);
+            store_tile_ln(0, ra0, rw0, ln0);
             __syncthreads();
             compute_tile(0);
             __syncthreads();
             if (kt + 1 < nk) {
-                if (kt + 3 < nk) load_tile((kt + 3) * BK, ra0, rw0);
-                store_tile(0, ra1, rw1);
+                if (kt + 3 < nk) load_tile_ln((kt + 3) * BK, ra0, rw0, ln0);
+                store_tile_ln(0, ra1, rw1, ln1);
                 __syncthreads();
                 compute_tile(0);
                 __syncthreads();
             }
             if (kt + 2 < nk) {
-                if (kt + 4 < nk) load_tile((kt + 4) * BK, ra1, rw1);
-                store_tile(0, ra2, rw2);
+                if (kt + 4 < nk) load_tile_ln((kt + 4) * BK, ra1, rw1, ln1);
+                store_tile_ln(0, ra2, rw2, ln2);
                 __syncthreads();
                 compute_tile(0);
                 __syncthreads();
@@ -473,7 +483,13 @@ int launch(GemmArgs& a, int batch, hipStream_t s) {
     a.tiles_n = (a.N + BN - 1) / BN;
     a.dbg = g_gemm_dbg;
     dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
-    if (a.ln_stats) {          // normalising operand loader: the register-staged loop (the LDS-DMA path cannot touch the data)
+    if (a.ln_stats) {          // normalising operand loader: the register-staged loops (the LDS-DMA path cannot touch the data)
+        if constexpr (BM == 64 && BN == 64) {
+            if (g_gemm_deep && (long)a.tiles_m * a.tiles_n * batch <= g_gemm_deep && a.K >= 8 * (int)(128 / sizeof(T))) {
+                hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 5, true>), grid, dim3(256), (BM + BN) * 128, s, a);
+                return emip_launch_status();
+            }
+        }
         hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 1, true>), grid, dim3(256), (BM + BN) * 128, s, a);
         return emip_launch_status();
     }

@@ -15,10 +15,11 @@ import sys
 
 
 def bench_key(name):
-    m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELb([01])ELi(\d+)EE", name)
+    m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])EE", name)
     if m:
-        return "gemm_kernel<%s,%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
-                                                "conv" if m.group(4) == "1" else "dense", m.group(5))
+        return "gemm_kernel<%s,%s,%s,%s,%s%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
+                                                  "conv" if m.group(4) == "1" else "dense", m.group(5),
+                                                  ",ln" if m.group(6) == "1" else "")
     m = re.search(r"attn_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EE", name)
     if m:
         return "attn_kernel<%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
