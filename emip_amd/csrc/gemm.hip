@@ -44,6 +44,12 @@ struct GemmArgs {
     float* out_stats;
     int ln_C;
     float ln_eps;
+    // split-K (small-M, long-K launches): blockIdx.y owns a range of K tiles and adds its partial tile into acc_out (f32
+    // [M][ldacc], zero beforehand) with atomics; bias is added by split 0; the row cast / statistics happen in
+    // emip_rows_finalize
+    float* acc_out;
+    long ldacc;
+    int ksplit;
     unsigned* zero_ptr;   // optional scratch the first workgroup clears (saves the consumer's zero-fill launch)
     long zero_words;
     int dbg;   // experiment flags (emip_debug_set key 2): 1 = skip epilogue stores, 2 = skip global loads in the K loop
@@ -98,10 +104,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
 
-    if (p.zero_ptr && blockIdx.x == 0 && blockIdx.z == 0) {
-        // statistics scratch of the normalisation that follows this conv: cleared here, accumulated into by the next
-        // kernel in stream order (which starts after this grid has drained)
-        for (long i = tid; i < p.zero_words; i += 256) p.zero_ptr[i] = 0u;
+    if (p.zero_ptr && blockIdx.z == 0 && blockIdx.y == 0) {
+        // scratch of LATER kernels in stream order (statistics, split-K accumulators): cleared here by all workgroups
+        for (long i = (long)blockIdx.x * 256 + tid; i < p.zero_words; i += (long)gridDim.x * 256) p.zero_ptr[i] = 0u;
     }
     const int ntile = p.tiles_m * p.tiles_n;
     const int swz = xcd_remap(blockIdx.x, ntile);
@@ -255,7 +260,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
     };
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nk_all = (p.K + BK - 1) / BK;
+    // split-K: this workgroup's range of K tiles (register-staged loops only)
+    const int kt_per = p.ksplit > 1 ? (nk_all + p.ksplit - 1) / p.ksplit : nk_all;
+    const int kt_lo = p.ksplit > 1 ? (int)blockIdx.y * kt_per : 0;
+    const int nk = min(nk_all, kt_lo + kt_per);
     if (NBUF == 3) {
         // One wave instruction moves 64 x 16 B = 8 tile rows (LDS destination = wave-uniform base + lane*16).
         // Wave w stages rows [w*BM/4, (w+1)*BM/4) of the A tile and [w*BN/4, ...) of the W tile.
@@ -321,9 +330,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         // multiplied.  For grids of about one workgroup per CU (the 121-token spatial-reduction convs: 16-80 workgroups
         // walking K = 1280-4096) nothing else hides the load latency; the staging registers are cheap at 64x64 tiles.
         uint4 ra0[CA], rw0[CW], ra1[CA], rw1[CW], ra2[CA], rw2[CW];
-        load_tile_ln(0, ra0, rw0, ln0);
-        if (nk > 1) load_tile_ln(BK, ra1, rw1, ln1);
-        for (int kt = 0; kt < nk; kt += 3) {
+        if (kt_lo < nk) load_tile_ln(kt_lo * BK, ra0, rw0, ln0);
+        if (kt_lo + 1 < nk) load_tile_ln((kt_lo + 1) * BK, ra1, rw1, ln1);
+        for (int kt = kt_lo; kt < nk; kt += 3) {
             if (kt + 2 < nk) load_tile_ln((kt + 2) * BK, ra2, rw2, ln2);
             store_tile_ln(0, ra0, rw0, ln0);
             __syncthreads();
@@ -347,10 +356,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     } else {
         // one LDS buffer, two barriers per K tile: half the LDS, more workgroups per CU
         uint4 ra[CA], rw[CW];
-        load_tile(0, ra, rw);
+        load_tile(kt_lo * BK, ra, rw);
         store_tile(0, ra, rw);
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = kt_lo; kt < nk; ++kt) {
             if (kt + 1 < nk && !(p.dbg & 2)) load_tile((kt + 1) * BK, ra, rw);
             compute_tile(0);
             __syncthreads();
@@ -360,6 +369,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 
     if ((p.dbg & 1) && acc[0][0][0] != 123456.f) return;   // experiment: no epilogue (the test keeps acc live)
+    if (p.acc_out) {
+        // split-K partial tile: lane holds channels n .. n+3 of row m (swapped operands), straight to f32 atomics
+        const bool first = blockIdx.y == 0;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = n0 + wn * (BN / 2) + 16 * a + 4 * fq;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m0 + wm * (BM / 2) + 16 * b + fr;
+                if (m < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (n + j < p.N) {
+                            const float v = acc[a][b][j] + ((first && p.bias) ? p.bias[n + j] : 0.f);
+                            atomicAdd(p.acc_out + (long)m * p.ldacc + n + j, v);
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
     T* C = reinterpret_cast<T*>(p.C) + z * p.bsC;   // may alias R (in-place residual update)
     const T* R = p.R ? reinterpret_cast<const T*>(p.R) + z * p.bsR : nullptr;
     constexpr int WM = BM / 2, WN = BN / 2, EP_LD = WN + 4;
@@ -482,7 +513,15 @@ int launch(GemmArgs& a, int batch, hipStream_t s) {
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     a.dbg = g_gemm_dbg;
-    dim3 grid(a.tiles_m * a.tiles_n, 1, batch);
+    dim3 grid(a.tiles_m * a.tiles_n, a.ksplit > 1 ? a.ksplit : 1, batch);
+    if (a.ksplit > 1 && !a.ln_stats) {       // split-K lives in the register-staged loops
+        if constexpr (BM == 64 && BN == 64) {
+            hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 5>), grid, dim3(256), (BM + BN) * 128, s, a);
+        } else {
+            hipLaunchKernelGGL((gemm_kernel<T, BM, BN, CONV, 1>), grid, dim3(256), (BM + BN) * 128, s, a);
+        }
+        return emip_launch_status();
+    }
     if (a.ln_stats) {          // normalising operand loader: the register-staged loops (the LDS-DMA path cannot touch the data)
         if constexpr (BM == 64 && BN == 64) {
             if (g_gemm_deep && (long)a.tiles_m * a.tiles_n * batch <= g_gemm_deep && a.K >= 8 * (int)(128 / sizeof(T))) {
@@ -549,6 +588,9 @@ extern "C" int emip_gemm_ln(const void*, const void*, const void*, void*, const 
                             long, int, void*);
 extern "C" int emip_conv2d_ln(const void*, const void*, void*, const float*, const void*, int, int, int, int, long, int, int, int,
                               int, int, long, long, int, void*, long, const float*, float, float*, int, void*);
+extern "C" int emip_conv2d_splitk(const void*, const void*, void*, const float*, const void*, int, int, int, int, long, int, int,
+                                  int, int, int, long, long, int, void*, long, const float*, float, float*, float*, long, int,
+                                  int, void*);
 
 static int check_ln(const GemmArgs& a, int batch, bool fast_epilogue) {
     if (a.ln_stats) EMIP_REQUIRE(a.ln_C > 0 && a.ln_eps > 0.f && a.A2 == nullptr && batch == 1 &&
@@ -617,7 +659,23 @@ extern "C" int emip_conv2d_ln(const void* X, const void* W, void* Y, const float
                               int Wd, int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy,
                               long ldr, int act, void* zero_ptr, long zero_bytes, const float* ln_stats, float ln_eps,
                               float* out_stats, int dtype, void* stream) {
-    EMIP_REQUIRE(X && W && Y && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0);
+    return emip_conv2d_splitk(X, W, Y, bias, R, B, H, Wd, Cin, ldx, Cout, KH, KW, stride, pad, ldy, ldr, act, zero_ptr,
+                              zero_bytes, ln_stats, ln_eps, out_stats, nullptr, 0, 1, dtype, stream);
+}
+
+// emip_conv2d_ln with split-K for small-M / long-K launches (the 121-token spatial-reduction convs): ksplit > 1 workgroups
+// share every output tile, each walks 1/ksplit of the K tiles and adds its partial sums (bias with split 0) into
+// acc_out f32 [B*Ho*Wo][ldacc] (zero beforehand) with atomics; Y, R, act and out_stats are then unused -- the cast to the
+// storage type and the row statistics come from emip_rows_finalize.
+extern "C" int emip_conv2d_splitk(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H,
+                                  int Wd, int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy,
+                                  long ldr, int act, void* zero_ptr, long zero_bytes, const float* ln_stats, float ln_eps,
+                                  float* out_stats, float* acc_out, long ldacc, int ksplit, int dtype, void* stream) {
+    EMIP_REQUIRE(X && W && (Y || acc_out) && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0);
+    EMIP_REQUIRE(ksplit >= 1 && ksplit <= 64);
+    if (ksplit > 1) EMIP_REQUIRE(acc_out && ldacc >= Cout && R == nullptr && act == EMIP_ACT_NONE && out_stats == nullptr);
+    else EMIP_REQUIRE(Y != nullptr);
+    if (!Y) Y = acc_out;            // split-K: Y is not written, the checks below only look at its alignment
     if (zero_ptr) EMIP_REQUIRE(zero_bytes > 0 && (zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0);
     EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
     EMIP_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0);
@@ -637,6 +695,7 @@ extern "C" int emip_conv2d_ln(const void* X, const void* W, void* Y, const float
     a.zero_ptr = static_cast<unsigned*>(zero_ptr);
     a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
     a.ln_stats = ln_stats; a.ln_C = Cin; a.ln_eps = ln_eps; a.out_stats = out_stats;
+    a.acc_out = ksplit > 1 ? acc_out : nullptr; a.ldacc = ldacc; a.ksplit = ksplit;
     {
         const bool fast = (ldy % vec) == 0 && aligned16(Y) && Cout % vec == 0 &&
                           (R == nullptr || ((ldr % vec) == 0 && aligned16(R)));

@@ -104,6 +104,50 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ X,
 }
 
 // ----------------------------------------------------------------------------
+// Rows of an f32 accumulation buffer (split-K partial sums, complete) -> storage type, plus the (sum, sum of squares) of
+// the stored rows for a LayerNorm folded into the consumer.  Same row / lane layout as layernorm_kernel.
+template <typename T>
+__global__ __launch_bounds__(256) void rows_finalize_kernel(const float* __restrict__ A, long lda, T* __restrict__ Y,
+                                                            long ldy, float* __restrict__ out_stats, long M, int C,
+                                                            int lpr_log2) {
+    const int LPR = 1 << lpr_log2;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1);
+    const int rows_per_wave = 64 >> lpr_log2;
+    const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * 4;
+    const int nv = C >> 2;
+    for (long row0 = wave_global * rows_per_wave; row0 < M; row0 += nwaves * rows_per_wave) {
+        const long row = row0 + (lane >> lpr_log2);
+        const bool ok = row < M;
+        float s1 = 0.f, s2 = 0.f;
+        for (int vi = sub; vi < nv; vi += LPR) {
+            if (ok) {
+                const float4 t = *reinterpret_cast<const float4*>(A + row * lda + vi * 4);
+                float v[4] = {t.x, t.y, t.z, t.w};
+                Vec4<T>::store(Y + row * ldy + vi * 4, v);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float q = to_f32<T>(from_f32<T>(v[j]));
+                    s1 += q;
+                    s2 += q * q;
+                }
+            }
+        }
+        if (out_stats) {
+            for (int o = LPR >> 1; o > 0; o >>= 1) {
+                s1 += __shfl_xor(s1, o);
+                s2 += __shfl_xor(s2, o);
+            }
+            if (ok && sub == 0) {
+                out_stats[2 * row] = s1;
+                out_stats[2 * row + 1] = s2;
+            }
+        }
+    }
+}
+
+// ----------------------------------------------------------------------------
 // LayerNorm backward (rows of C channels).  mean / rstd are recomputed from x (cheaper than saving them):
 //   xh = (x - mean) * rstd,  g = dy * gamma,  dx = rstd * (g - mean_c(g) - xh * mean_c(g * xh))
 //   dgamma[c] += sum_rows dy * xh,  dbeta[c] += sum_rows dy      (f32 atomics, one add per channel per workgroup)
@@ -726,6 +770,22 @@ extern "C" int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const 
     DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_kernel<T>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                                          (const T*)X, ldx, (T*)Y, ldy, gamma, beta, (const T*)R, ldr, out_stats, M, C, eps,
                                          lg));
+    return emip_launch_status();
+}
+
+// A f32 [M][lda] (complete split-K sums) -> Y [M][ldy] in the storage type; out_stats (may be NULL) f32 [M][2].
+extern "C" int emip_rows_finalize(const float* A, long lda, void* Y, long ldy, float* out_stats, long M, int C, int dtype,
+                                  void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(A && Y && M > 0 && C >= 4 && C <= 4096 && (C & 3) == 0 && (lda & 3) == 0 && (ldy & 3) == 0 && lda >= C &&
+                 ldy >= C && aligned16(A));
+    const int nv = C >> 2;
+    int lg = 0;
+    while ((1 << lg) < nv && lg < 6) ++lg;
+    const int rows_per_wave = 64 >> lg;
+    const long waves = (M + rows_per_wave - 1) / rows_per_wave;
+    DISPATCH_T(dtype, hipLaunchKernelGGL(rows_finalize_kernel<T>, dim3(grid_for(waves, 4)), dim3(256), 0,
+                                         (hipStream_t)stream, A, lda, (T*)Y, ldy, out_stats, M, C, lg));
     return emip_launch_status();
 }
 

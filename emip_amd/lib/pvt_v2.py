@@ -27,6 +27,10 @@ FUSED_MLP_TAIL = False
 # consumer's weights and beta into its bias when the weights are packed, and the consumer's operand loader feeds
 # (x - mean) * rstd to the MFMA.
 FUSED_LN = True
+# Split-K for the 121-token spatial-reduction convs (emip_conv2d_splitk + emip_rows_finalize): parity-tested, but the f32
+# atomics, the 1.2 MB accumulator to clear and the extra launch cost more than the shorter K walk saves end to end
+# (948 -> 886 pairs/s), so it stays off.
+SPLITK_SR = False
 
 
 def _lin_packs(w, dt):
@@ -210,13 +214,25 @@ class Block(EmipModule):
         M = B * N
         w = self._folded()
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
-        buf = torch.empty(2 * (Ms + 2 * M), dtype=torch.float32, device=x.device)
-        st_sr, st1, st2 = buf[:2 * Ms], buf[2 * Ms:2 * Ms + 2 * M], buf[2 * Ms + 2 * M:]
-        # the first launch of the block clears the statistics the sr conv and the proj GEMM will accumulate into
-        q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, zero=buf[:2 * Ms + 2 * M])
+        # scratch of the block, one allocation: [split-K accumulator of the sr conv | its row stats | stats of x1 | of x2]
+        o = Ms * C if (sr > 1 and SPLITK_SR) else 0
+        buf = torch.empty(o + 2 * (Ms + 2 * M), dtype=torch.float32, device=x.device)
+        acc_sr = buf[:o].view(Ms, C) if o else None
+        st_sr, st1, st2 = buf[o:o + 2 * Ms], buf[o + 2 * Ms:o + 2 * Ms + 2 * M], buf[o + 2 * Ms + 2 * M:]
+        # the first launch of the block clears what the sr conv and the proj GEMM will accumulate into
+        q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, zero=buf[:o + 2 * Ms + 2 * M])
         if sr > 1:
-            s = ops.conv2d(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps,
-                           out_stats=st_sr)
+            # 121 output tokens per image against K = sr*sr*C: split K over workgroups (about 256 in total), f32 atomics
+            tiles = ((Ms + 63) // 64) * ((C + 63) // 64)
+            nk = sr * sr * C // (64 if dt == torch.bfloat16 else 32)
+            ksplit = max(1, min(nk // 2, (256 + tiles - 1) // tiles, 64)) if SPLITK_SR else 1
+            if ksplit > 1:
+                ops.conv2d_splitk(x, w["sr"], sr, sr, sr, 0, w["bsr"], acc_sr, ksplit, ln_stats=stats,
+                                  ln_eps=self.norm1.eps)
+                s = ops.rows_finalize(acc_sr, dt, (B, H // sr, W // sr, C), out_stats=st_sr)
+            else:            # enough output tiles to fill the chip on their own
+                s = ops.conv2d(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps,
+                               out_stats=st_sr)
             kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps)
         else:
             s = x

@@ -90,6 +90,27 @@ def gemm_batched(a, w, out, batch, M, N, K, lda, ldw, ldc, bsA, bsW, bsC):
     return out
 
 
+def conv2d_splitk(x, w, kh, kw, stride, pad, bias, acc, ksplit, ln_stats=None, ln_eps=0.0, zero=None):
+    """split-K conv: partial sums (bias included once) are ADDED into acc f32 [B*Ho*Wo, Cout] (zero beforehand)"""
+    _dev(x)
+    B, H, W, Cin = x.shape
+    ldx = x.stride(2)
+    Cout = w.shape[0]
+    assert acc.dtype == torch.float32 and acc.is_contiguous() and acc.shape[-1] == Cout and ksplit > 1
+    _lib.call("emip_conv2d_splitk", _p(x), _p(w), None, _p(bias), None, B, H, W, Cin, ldx, Cout, kh, kw, stride, pad,
+              Cout, 0, ACT_NONE, _p(zero), _nbytes(zero), _p(ln_stats), float(ln_eps), None, _p(acc), Cout, int(ksplit),
+              dt_code(x.dtype), _stream())
+    return acc
+
+
+def rows_finalize(acc, dtype, shape, out_stats=None):
+    """complete f32 rows [M, C] -> tensor of `shape` (last dim C) in `dtype`, + (sum, sum of squares) of the stored rows"""
+    M, C = acc.shape
+    y = torch.empty(shape, dtype=dtype, device=acc.device)
+    _lib.call("emip_rows_finalize", _p(acc), C, _p(y), C, _p(out_stats), M, C, dt_code(dtype), _stream())
+    return y
+
+
 def conv2d(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None, zero=None, ln_stats=None,
            ln_eps=0.0, out_stats=None):
     """x [B,H,W,Cin] channels-last, w packed [Cout, kh*kw*Cin] -> [B,Ho,Wo,Cout]."""

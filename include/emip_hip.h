@@ -90,6 +90,17 @@ int emip_conv2d_ln(const void* X, const void* W, void* Y, const float* bias, con
                    long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act, void* zero_ptr,
                    long zero_bytes, const float* ln_stats, float ln_eps, float* out_stats, int dtype, void* stream);
 
+/* Split-K variant for small-M / long-K convs (the 121-token spatial-reduction convs of lib/pvt_v2.py:75,107: 16-80 output
+ * tiles walking K = 1280-4096): ksplit workgroups share an output tile, each takes 1/ksplit of the K tiles and adds its
+ * partial sums (bias with split 0) into acc_out f32 [B*Ho*Wo][ldacc] (zero beforehand) with atomics; Y / R / act /
+ * out_stats are unused then.  emip_rows_finalize casts the complete rows to the storage type and takes their statistics. */
+int emip_conv2d_splitk(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd,
+                       int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act,
+                       void* zero_ptr, long zero_bytes, const float* ln_stats, float ln_eps, float* out_stats,
+                       float* acc_out, long ldacc, int ksplit, int dtype, void* stream);
+int emip_rows_finalize(const float* A, long lda, void* Y, long ldy, float* out_stats, long M, int C, int dtype,
+                       void* stream);
+
 /* Fused attention  O = softmax(Q K^T * scale + mask) V  (online softmax, scores never stored unless S!=NULL).
  * Replaces: lib/pvt_v2.py:121-125 (SRA, D=DV=64, Lk=121); gmflow/transformer.py:46-105 (split-window
  *   attention; q_rows/k_rows [nwin][L] int32 tables fold torch.roll + split_feature + merge_splits into

@@ -440,3 +440,31 @@ def test_sr_conv_with_folded_layernorm(dt, tol, B, H, C, k):
     assert err < tol * max(1.0, ref.abs().max().item()), err
     want = torch.stack([y.float().sum(-1), (y.float() ** 2).sum(-1)], -1).view(-1, 2)
     assert ((out_stats - want).abs() / (want.abs() + 1.0)).max().item() < 1e-3
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,H,C,k,ks", [(2, 88, 64, 8, 16), (3, 44, 128, 4, 8), (2, 22, 320, 2, 4), (1, 22, 320, 2, 7)])
+def test_sr_conv_splitk_and_finalize(dt, tol, B, H, C, k, ks):
+    """split-K spatial-reduction conv (f32 atomics, LayerNorm folded into the loader) + emip_rows_finalize == LN -> conv"""
+    from emip_amd import ops
+    g = torch.Generator().manual_seed(B * 7 + H)
+    x = (torch.randn(B, H, H, C, generator=g) + 0.3).to(dt)
+    gamma, beta = 1 + 0.1 * torch.randn(C, generator=g), 0.1 * torch.randn(C, generator=g)
+    w = torch.randn(C, C, k, k, generator=g) / (C * k * k) ** 0.5
+    b = 0.1 * torch.randn(C, generator=g)
+    xn = torch.nn.functional.layer_norm(x.float(), (C,), gamma, beta, 1e-6)
+    ref = torch.nn.functional.conv2d(xn.permute(0, 3, 1, 2), w, b, stride=k).permute(0, 2, 3, 1)
+    dev = "cuda:0"
+    xs = x.to(dev)
+    stats = torch.stack([xs.float().sum(-1), (xs.float() ** 2).sum(-1)], -1).view(-1, 2).contiguous()
+    wf = (w * gamma.view(1, C, 1, 1)).permute(0, 2, 3, 1).reshape(C, -1).to(dt).to(dev).contiguous()
+    bf = (b + (w * beta.view(1, C, 1, 1)).sum((1, 2, 3))).to(dev)
+    Ms = B * (H // k) ** 2
+    acc = torch.zeros(Ms, C, device=dev)
+    ops.conv2d_splitk(xs, wf, k, k, k, 0, bf, acc, ks, ln_stats=stats, ln_eps=1e-6)
+    st = torch.empty(Ms, 2, device=dev)
+    y = ops.rows_finalize(acc, dt, (B, H // k, H // k, C), out_stats=st)
+    err = (y.float().cpu() - ref).abs().max().item()
+    assert err < tol * max(1.0, ref.abs().max().item()), err
+    want = torch.stack([y.float().sum(-1), (y.float() ** 2).sum(-1)], -1).view(-1, 2)
+    assert ((st - want).abs() / (want.abs() + 1.0)).max().item() < 1e-3
