@@ -50,7 +50,8 @@ def test_argument_checks_refuse_before_launch():
     from emip_amd import _lib
     lib = _lib.load()
     assert lib.emip_gemm(None, None, None, None, None, None, 1, 1, 8, 8, 8, 0, 8, 1, 0, 0, 1, 0, 0, 0, 0, 0, None) == -1
-    assert lib.emip_layernorm(None, 4, None, 4, None, None, None, 0, 1, 4, 1e-5, 0, None) == -1
+    assert lib.emip_layernorm(None, 4, None, 4, None, None, None, 0, None, 1, 4, 1e-5, 0, None) == -1
+    assert lib.emip_rows_finalize(None, 4, None, 4, None, 1, 4, 0, None) == -1
     assert lib.emip_conv2d(None, None, None, None, None, 1, 8, 8, 8, 8, 8, 3, 3, 1, 1, 8, 0, 0, None, 0, 0, None) == -1
     assert lib.emip_preprocess_rgb(None, 0, 0, 1, 8, 8, None, None, 3, None, None, 3, None, None, None, 4, 4, None, None,
                                    None) == -1
