@@ -91,8 +91,10 @@ __device__ __forceinline__ uint4 ln_apply(uint4 v, float mu, float rs) {
     return v;
 }
 
-template <typename T, int BM, int BN, bool CONV, int NBUF, bool LNA = false>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+// The kernel body is a device function over an explicit block id so that one launch can host several problems
+// (gemm_pair_kernel below): bx = tile index, by = split-K index, bz = batch index, gx = number of tile blocks.
+template <typename T, int BM, int BN, bool CONV, int NBUF, bool LNA>
+__device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const int by, const int bz, const int gx) {
     constexpr int VEC = 16 / sizeof(T);   // elements per 16-B chunk
     constexpr int BK = 128 / sizeof(T);   // K elements per tile
     constexpr int TM = BM / 32, TN = BN / 32;  // 16x16 sub-tiles per wave
@@ -104,15 +106,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave & 1, wn = wave >> 1;
 
-    if (p.zero_ptr && blockIdx.z == 0 && blockIdx.y == 0) {
+    if (p.zero_ptr && bz == 0 && by == 0) {
         // scratch of LATER kernels in stream order (statistics, split-K accumulators): cleared here by all workgroups
-        for (long i = (long)blockIdx.x * 256 + tid; i < p.zero_words; i += (long)gridDim.x * 256) p.zero_ptr[i] = 0u;
+        for (long i = (long)bx * 256 + tid; i < p.zero_words; i += (long)gx * 256) p.zero_ptr[i] = 0u;
     }
     const int ntile = p.tiles_m * p.tiles_n;
-    const int swz = xcd_remap(blockIdx.x, ntile);
+    const int swz = xcd_remap(bx, ntile);
     const int tile_m = swz / p.tiles_n, tile_n = swz - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const long z = blockIdx.z;
+    const long z = bz;
 
     const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + z * p.bsA;
     const T* __restrict__ A2 = p.A2 ? reinterpret_cast<const T*>(p.A2) + z * p.bsA : nullptr;
@@ -263,7 +265,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int nk_all = (p.K + BK - 1) / BK;
     // split-K: this workgroup's range of K tiles (register-staged loops only)
     const int kt_per = p.ksplit > 1 ? (nk_all + p.ksplit - 1) / p.ksplit : nk_all;
-    const int kt_lo = p.ksplit > 1 ? (int)blockIdx.y * kt_per : 0;
+    const int kt_lo = p.ksplit > 1 ? by * kt_per : 0;
     const int nk = min(nk_all, kt_lo + kt_per);
     if (NBUF == 3) {
         // One wave instruction moves 64 x 16 B = 8 tile rows (LDS destination = wave-uniform base + lane*16).
@@ -371,7 +373,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     if ((p.dbg & 1) && acc[0][0][0] != 123456.f) return;   // experiment: no epilogue (the test keeps acc live)
     if (p.acc_out) {
         // split-K partial tile: lane holds channels n .. n+3 of row m (swapped operands), straight to f32 atomics
-        const bool first = blockIdx.y == 0;
+        const bool first = by == 0;
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
             const int n = n0 + wn * (BN / 2) + 16 * a + 4 * fq;
@@ -499,6 +501,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+template <typename T, int BM, int BN, bool CONV, int NBUF, bool LNA = false>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    gemm_body<T, BM, BN, CONV, NBUF, LNA>(p, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.x);
+}
+
+// Two implicit-GEMM problems in ONE launch (64x64 tiles, normalising loader): the first `na` workgroups work on `a`, the
+// rest on `b`.  Built for the PVT block, where the q projection (a 1x1 conv over the tokens) and the spatial-reduction conv
+// read the same normalised tokens and are independent: the sr conv is 16-80 workgroups walking a long K, alone it leaves the
+// chip idle for its whole duration, next to the q tiles it is hidden.  Neither problem may clear scratch the other one
+// accumulates into (the statistics scratch of a stage is cleared by the stage's patch-embed conv).
+template <typename T, int NBUF>
+__global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmArgs a, const GemmArgs b, const int na) {
+    if ((int)blockIdx.x < na) gemm_body<T, 64, 64, true, NBUF, true>(a, blockIdx.x, 0, 0, na);
+    else gemm_body<T, 64, 64, true, NBUF, true>(b, (int)blockIdx.x - na, 0, 0, (int)gridDim.x - na);
 }
 
 int g_gemm_nbuf = 1;  // debug/tuning knob (emip_debug_set)
@@ -703,6 +721,53 @@ extern "C" int emip_conv2d_splitk(const void* X, const void* W, void* Y, const f
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     return dtype == EMIP_F32 ? dispatch<float, true>(a, 1, s) : dispatch<bf16_t, true>(a, 1, s);
+}
+
+// ---- two convs in one launch -------------------------------------------------------------------------------------------
+struct emip_conv_desc_t {      // mirrors emip_conv_desc of include/emip_hip.h
+    const void* X; const void* W; void* Y; const float* bias; const void* R;
+    int B, H, Wd, Cin; long ldx; int Cout, KH, KW, stride, pad; long ldy, ldr; int act;
+    const float* ln_stats; float ln_eps; float* out_stats;
+};
+
+static int fill_pair_args(const emip_conv_desc_t& d, int dtype, GemmArgs& a) {
+    EMIP_REQUIRE(d.X && d.W && d.Y && d.ln_stats && d.B > 0 && d.H > 0 && d.Wd > 0 && d.Cin > 0 && d.Cout > 0);
+    EMIP_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.pad >= 0 && d.ln_eps > 0.f);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(d.Cin % vec == 0 && d.ldx % vec == 0 && d.ldx >= d.Cin && d.ldy >= d.Cout && d.Cout % vec == 0);
+    EMIP_REQUIRE(aligned16(d.X) && aligned16(d.W) && aligned16(d.Y) && d.ldy % vec == 0);
+    EMIP_REQUIRE((reinterpret_cast<uintptr_t>(d.ln_stats) & 7) == 0);
+    if (d.R) EMIP_REQUIRE(d.ldr >= d.Cout && d.ldr % vec == 0 && aligned16(d.R));
+    if (d.out_stats) EMIP_REQUIRE((reinterpret_cast<uintptr_t>(d.out_stats) & 3) == 0);
+    EMIP_REQUIRE(d.act >= EMIP_ACT_NONE && d.act <= EMIP_ACT_GELU);
+    const int Ho = (d.H + 2 * d.pad - d.KH) / d.stride + 1, Wo = (d.Wd + 2 * d.pad - d.KW) / d.stride + 1;
+    EMIP_REQUIRE(Ho > 0 && Wo > 0 && (long)d.B * Ho * Wo < 2147483647L && (long)d.KH * d.KW * d.Cin < 2147483647L);
+    a = GemmArgs{};
+    a.A = d.X; a.W = d.W; a.C = d.Y; a.bias = d.bias; a.R = d.R;
+    a.M = d.B * Ho * Wo; a.N = d.Cout; a.K = d.KH * d.KW * d.Cin; a.K1 = a.K;
+    a.lda = d.ldx; a.ldw = a.K; a.ldc = d.ldy; a.ldr = d.ldr; a.act = d.act;
+    a.H = d.H; a.Wd = d.Wd; a.Cin = d.Cin; a.Ho = Ho; a.Wo = Wo; a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad;
+    a.ln_stats = d.ln_stats; a.ln_C = d.Cin; a.ln_eps = d.ln_eps; a.out_stats = d.out_stats;
+    a.ksplit = 1;
+    a.tiles_m = (a.M + 63) / 64;
+    a.tiles_n = (a.N + 63) / 64;
+    a.dbg = 0;
+    return EMIP_OK;
+}
+
+// Two NHWC convs (either may be a 1x1 conv, i.e. a Linear over the tokens) with the normalising loader, in ONE launch.
+extern "C" int emip_conv2d_pair(const void* da, const void* db, int dtype, void* stream) {
+    EMIP_REQUIRE(da && db && (dtype == EMIP_F32 || dtype == EMIP_BF16));
+    GemmArgs a, b;
+    if (fill_pair_args(*static_cast<const emip_conv_desc_t*>(da), dtype, a) != EMIP_OK) return EMIP_E_INVALID;
+    if (fill_pair_args(*static_cast<const emip_conv_desc_t*>(db), dtype, b) != EMIP_OK) return EMIP_E_INVALID;
+    const int na = a.tiles_m * a.tiles_n, nb = b.tiles_m * b.tiles_n;
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EMIP_F32)
+        hipLaunchKernelGGL((gemm_pair_kernel<float, 5>), dim3(na + nb), dim3(256), 128 * 128, s, a, b, na);
+    else
+        hipLaunchKernelGGL((gemm_pair_kernel<bf16_t, 5>), dim3(na + nb), dim3(256), 128 * 128, s, a, b, na);
+    return emip_launch_status();
 }
 
 // the block tile the dispatcher picks for an (M, N, batch) problem, as BM*1000 + BN (introspection for bench.py)

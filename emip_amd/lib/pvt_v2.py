@@ -31,6 +31,8 @@ FUSED_LN = True
 # atomics, the 1.2 MB accumulator to clear and the extra launch cost more than the shorter K walk saves end to end
 # (948 -> 886 pairs/s), so it stays off.
 SPLITK_SR = False
+# q projection + spatial-reduction conv of a block hosted by one launch (emip_conv2d_pair)
+PAIR_Q_SR = True
 
 
 def _lin_packs(w, dt):
@@ -204,9 +206,16 @@ class Block(EmipModule):
             params += (a.sr.weight, a.sr.bias, a.norm.weight, a.norm.bias)
         return self.packed("fln", params, build)
 
-    def run_fused(self, x, stats):
+    @staticmethod
+    def scratch_floats(B, H, W, C, sr):
+        """f32 words of statistics scratch one block needs: [sr-conv rows | x1 rows | x2 rows] x 2 (+ split-K accumulator)"""
+        M = B * H * W
+        Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
+        return (Ms * C if (sr > 1 and SPLITK_SR) else 0) + 2 * (Ms + 2 * M)
+
+    def run_fused(self, x, stats, buf):
         """Inference block without LayerNorm launches.  x [B,H,W,C] (updated in place), stats f32 [B*H*W, 2] = (sum, sum of
-        squares) of its rows -> (x, stats of the new rows)."""
+        squares) of its rows, buf: this block's slice of the stage's ZEROED scratch -> (x, stats of the new rows)."""
         a = self.attn
         dt, C, heads, sr = self.cdtype, a.dim, a.num_heads, a.sr_ratio
         B, H, W, _ = x.shape
@@ -216,12 +225,20 @@ class Block(EmipModule):
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
         # scratch of the block, one allocation: [split-K accumulator of the sr conv | its row stats | stats of x1 | of x2]
         o = Ms * C if (sr > 1 and SPLITK_SR) else 0
-        buf = torch.empty(o + 2 * (Ms + 2 * M), dtype=torch.float32, device=x.device)
         acc_sr = buf[:o].view(Ms, C) if o else None
         st_sr, st1, st2 = buf[o:o + 2 * Ms], buf[o + 2 * Ms:o + 2 * Ms + 2 * M], buf[o + 2 * Ms + 2 * M:]
-        # the first launch of the block clears what the sr conv and the proj GEMM will accumulate into
-        q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, zero=buf[:o + 2 * Ms + 2 * M])
-        if sr > 1:
+        if sr > 1 and PAIR_Q_SR and not SPLITK_SR:
+            # q projection (as a 1x1 conv over the tokens) and the spatial-reduction conv in ONE launch
+            q = torch.empty((B, H, W, C), dtype=dt, device=x.device)
+            s = torch.empty((B, H // sr, W // sr, C), dtype=dt, device=x.device)
+            ops.conv2d_pair(ops.conv_desc(x, w["q"], 1, 1, 0, w["bq"], q, stats, self.norm1.eps),
+                            ops.conv_desc(x, w["sr"], sr, sr, 0, w["bsr"], s, stats, self.norm1.eps, out_stats=st_sr), dt)
+            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps)
+        else:
+            q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps)
+        if sr > 1 and PAIR_Q_SR and not SPLITK_SR:
+            pass
+        elif sr > 1:
             # 121 output tokens per image against K = sr*sr*C: split K over workgroups (about 256 in total), f32 atomics
             tiles = ((Ms + 63) // 64) * ((C + 63) // 64)
             nk = sr * sr * C // (64 if dt == torch.bfloat16 else 32)
@@ -243,7 +260,7 @@ class Block(EmipModule):
                       k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
                       k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
         ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)                          # x += proj(attn)
-        t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, zero=st2)
+        t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps)
         t = ops.dwconv3x3(t, w["wd"], w["bd"], act=ops.ACT_GELU)
         ops.gemm(t, w["w2"], bias=w["b2"], res=x, out=x, out_stats=st2)                           # x += mlp(...)
         return x, st2
@@ -281,7 +298,7 @@ class OverlapPatchEmbed(EmipModule):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=stride, padding=patch_size // 2)
         self.norm = nn.LayerNorm(embed_dim)
 
-    def run(self, x, out_stats=None):
+    def run(self, x, out_stats=None, zero=None):
         dt = self.cdtype
         cin = x.shape[-1]  # the image arrives with its 3 channels zero-padded to 8
         if torch.is_grad_enabled():
@@ -292,7 +309,7 @@ class OverlapPatchEmbed(EmipModule):
             return LayerNormFn.apply(y, self.norm.weight, self.norm.bias, self.norm.eps)
         w, b, g, be = self.packed("pe", (self.proj.weight, self.proj.bias, self.norm.weight, self.norm.bias),
                                   lambda a, bb, c, d: (pack_conv(a, dt, cin_pad=cin), f32(bb), f32(c), f32(d)))
-        y = ops.conv2d(x, w, self.patch_size, self.patch_size, self.stride, self.patch_size // 2, bias=b)
+        y = ops.conv2d(x, w, self.patch_size, self.patch_size, self.stride, self.patch_size // 2, bias=b, zero=zero)
         return ops.layernorm(y, g, be, self.norm.eps, out=y, out_stats=out_stats)
 
 
@@ -328,9 +345,13 @@ class PyramidVisionTransformerV2(EmipModule):
                 Ho, Wo = (x.shape[1] + 2 * (pe.patch_size // 2) - pe.patch_size) // st + 1, \
                          (x.shape[2] + 2 * (pe.patch_size // 2) - pe.patch_size) // st + 1
                 stats = torch.empty(2 * x.shape[0] * Ho * Wo, dtype=torch.float32, device=x.device)
-                x = pe.run(x, out_stats=stats)
-                for blk in blocks:
-                    x, stats = blk.run_fused(x, stats)
+                # statistics scratch of the whole stage: one allocation, cleared by the patch-embed conv's workgroups
+                a0 = blocks[0].attn
+                per = Block.scratch_floats(x.shape[0], Ho, Wo, a0.dim, a0.sr_ratio)
+                scratch = torch.empty((len(blocks), per), dtype=torch.float32, device=x.device)
+                x = pe.run(x, out_stats=stats, zero=scratch)
+                for j, blk in enumerate(blocks):
+                    x, stats = blk.run_fused(x, stats, scratch[j])
             else:
                 x = pe.run(x)
                 for blk in blocks:

@@ -111,6 +111,30 @@ def rows_finalize(acc, dtype, shape, out_stats=None):
     return y
 
 
+import ctypes as _ct
+
+
+class ConvDesc(_ct.Structure):
+    """emip_conv_desc of include/emip_hip.h"""
+    _fields_ = [("X", _ct.c_void_p), ("W", _ct.c_void_p), ("Y", _ct.c_void_p), ("bias", _ct.c_void_p), ("R", _ct.c_void_p),
+                ("B", _ct.c_int), ("H", _ct.c_int), ("Wd", _ct.c_int), ("Cin", _ct.c_int), ("ldx", _ct.c_long),
+                ("Cout", _ct.c_int), ("KH", _ct.c_int), ("KW", _ct.c_int), ("stride", _ct.c_int), ("pad", _ct.c_int),
+                ("ldy", _ct.c_long), ("ldr", _ct.c_long), ("act", _ct.c_int), ("ln_stats", _ct.c_void_p),
+                ("ln_eps", _ct.c_float), ("out_stats", _ct.c_void_p)]
+
+
+def conv_desc(x, w, k, stride, pad, bias, out, ln_stats, ln_eps, out_stats=None, res=None, act=ACT_NONE):
+    B, H, W, Cin = x.shape
+    assert w.shape[1] == k * k * Cin and w.is_contiguous() and w.dtype == x.dtype and ln_stats.dtype == torch.float32
+    return ConvDesc(_p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, x.stride(2), w.shape[0], k, k, stride, pad,
+                    rows(out)[2], rows(res)[2] if res is not None else 0, act, _p(ln_stats), float(ln_eps), _p(out_stats))
+
+
+def conv2d_pair(da, db, dtype):
+    """two convs (ConvDesc) with the normalising loader in one launch"""
+    _lib.call("emip_conv2d_pair", _ct.addressof(da), _ct.addressof(db), dt_code(dtype), _stream())
+
+
 def conv2d(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None, zero=None, ln_stats=None,
            ln_eps=0.0, out_stats=None):
     """x [B,H,W,Cin] channels-last, w packed [Cout, kh*kw*Cin] -> [B,Ho,Wo,Cout]."""

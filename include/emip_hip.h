@@ -101,6 +101,17 @@ int emip_conv2d_splitk(const void* X, const void* W, void* Y, const float* bias,
 int emip_rows_finalize(const float* A, long lda, void* Y, long ldy, float* out_stats, long M, int C, int dtype,
                        void* stream);
 
+/* Two convs with the normalising loader in ONE launch (64x64 tiles; a 1x1 conv is a Linear over the tokens).  In the PVT
+ * block the q projection and the spatial-reduction conv read the same normalised tokens and are independent
+ * (lib/pvt_v2.py:103-110): the sr conv alone is 16-80 workgroups walking a long K, beside the q tiles it is hidden.
+ * Neither problem may clear or produce what the other one consumes. */
+typedef struct emip_conv_desc {
+    const void* X; const void* W; void* Y; const float* bias; const void* R;
+    int B, H, Wd, Cin; long ldx; int Cout, KH, KW, stride, pad; long ldy, ldr; int act;
+    const float* ln_stats; float ln_eps; float* out_stats;
+} emip_conv_desc;
+int emip_conv2d_pair(const void* desc_a, const void* desc_b, int dtype, void* stream);   /* -> const emip_conv_desc* */
+
 /* Fused attention  O = softmax(Q K^T * scale + mask) V  (online softmax, scores never stored unless S!=NULL).
  * Replaces: lib/pvt_v2.py:121-125 (SRA, D=DV=64, Lk=121); gmflow/transformer.py:46-105 (split-window
  *   attention; q_rows/k_rows [nwin][L] int32 tables fold torch.roll + split_feature + merge_splits into
