@@ -152,6 +152,8 @@ class SraAttentionFn(Function):
 
     @staticmethod
     def backward(ctx, do):
+        """all heads in one launch per step (two-level batch: image, head); dK / dV are accumulated straight into the f32
+        gradient of the kv projection output"""
         q, kv = ctx.saved_tensors
         heads, scale = ctx.cfg
         do = do.contiguous()
@@ -160,24 +162,26 @@ class SraAttentionFn(Function):
         Lp = 128
         assert Lk <= Lp
         dt, dev = q.dtype, q.device
+        Z = B * heads
+        k_, v_ = kv, kv[..., C:]                                  # head h: columns 64 h .. of k, C + 64 h .. of v
+        S = torch.empty((B, heads, N, Lp), dtype=dt, device=dev)
+        ops.gemm_heads(q, k_, S, Z, heads, N, Lk, 64, C, 2 * C, Lp, N * C, 64, Lk * 2 * C, 64, heads * N * Lp, N * Lp)
+        P = ops.softmax_rows(S.view(Z * N, Lp), Lk, scale, out=S.view(Z * N, Lp))
+        dkv32 = torch.zeros((B, Lp, 2 * C), dtype=torch.float32, device=dev)
+        ops.gemm_tn_heads(P, do, dkv32[..., C:], Z, heads, N, Lp, 64, Lp, C, 2 * C, heads * N * Lp, N * Lp, N * C, 64,
+                          Lp * 2 * C, 64)                                                         # dV
+        dP = torch.empty((B, heads, N, Lp), dtype=dt, device=dev)
+        ops.gemm_heads(do, v_, dP, Z, heads, N, Lk, 64, C, 2 * C, Lp, N * C, 64, Lk * 2 * C, 64, heads * N * Lp, N * Lp)
+        dS = ops.softmax_bwd_rows(P, dP.view(Z * N, Lp), Lk, scale, out=dP.view(Z * N, Lp))
+        kT = ops.transpose_pad_heads(kv, Z, heads, Lk, 64, Lp, 2 * C, Lk * 2 * C, 64)               # [Z,64,Lp]
         dq = torch.empty_like(q)
-        dkv_pad = torch.zeros((B, Lp, 2 * C), dtype=dt, device=dev)
-        S = torch.empty((B, N, Lp), dtype=dt, device=dev)
-        dP = torch.empty((B, N, Lp), dtype=dt, device=dev)
-        for h in range(heads):
-            qh, kh, vh, doh = q[..., 64 * h:], kv[..., 64 * h:], kv[..., C + 64 * h:], do[..., 64 * h:]
-            ops.gemm_batched(qh, kh, S, B, N, Lk, 64, C, 2 * C, Lp, N * C, Lk * 2 * C, N * Lp)
-            P = ops.softmax_rows(S.view(B * N, Lp), Lk, scale, out=S.view(B * N, Lp)).view(B, N, Lp)
-            dV = ops.gemm_tn_batched(P, doh, B, N, Lp, 64, Lp, C, N * Lp, N * C)              # f32 [B,Lp,64]
-            ops.gemm_batched(doh, vh, dP, B, N, Lk, 64, C, 2 * C, Lp, N * C, Lk * 2 * C, N * Lp)
-            dS = ops.softmax_bwd_rows(P.view(B * N, Lp), dP.view(B * N, Lp), Lk, scale, out=dP.view(B * N, Lp))
-            dS = dS.view(B, N, Lp)
-            khT = ops.transpose_pad(kv[:, :, 64 * h:64 * h + 64], Lp)                        # [B,64,Lp]
-            ops.gemm_batched(dS, khT, dq[..., 64 * h:], B, N, 64, Lp, Lp, Lp, C, N * Lp, 64 * Lp, N * C)
-            dK = ops.gemm_tn_batched(dS, qh, B, N, Lp, 64, Lp, C, N * Lp, N * C)             # f32 [B,Lp,64]
-            ops.copy_cols(dK.view(B * Lp, 64), 0, 64, dkv_pad.view(B * Lp, 2 * C), 64 * h)
-            ops.copy_cols(dV.view(B * Lp, 64), 0, 64, dkv_pad.view(B * Lp, 2 * C), C + 64 * h)
-        return dq, dkv_pad[:, :Lk].contiguous(), None, None
+        ops.gemm_heads(dS, kT, dq, Z, heads, N, 64, Lp, Lp, Lp, C, heads * N * Lp, N * Lp, heads * 64 * Lp, 64 * Lp,
+                       N * C, 64)
+        ops.gemm_tn_heads(dS, q, dkv32, Z, heads, N, Lp, 64, Lp, C, 2 * C, heads * N * Lp, N * Lp, N * C, 64, Lp * 2 * C,
+                          64)                                                                      # dK
+        dkv = torch.empty((B, Lp, 2 * C), dtype=dt, device=dev)
+        ops.copy_cols(dkv32.view(B * Lp, 2 * C), 0, 2 * C, dkv.view(B * Lp, 2 * C), 0)
+        return dq, dkv[:, :Lk].contiguous(), None, None
 
 
 class BNReluFn(Function):

@@ -248,10 +248,12 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_long_kernel(const T* __r
 // Y[z][c][r] = r < R ? X[z][r][c] : 0   for c < C, r < Rpad   (X rows of stride ldx, Y rows of stride Rpad)
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_pad_kernel(const T* __restrict__ X, long ldx, long bsx,
-                                                            T* __restrict__ Y, long bsy, int R, int C, int Rpad) {
+                                                            T* __restrict__ Y, long bsy, int R, int C, int Rpad,
+                                                            int heads, long hsx) {
     __shared__ float tile[32][33];
     const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const long z = blockIdx.z;
+    X += heads > 1 ? (z / heads) * bsx + (z % heads) * hsx - z * bsx : 0;      // input of (b, h): b * bsx + h * hsx
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
         const int r = r0 + i, c = c0 + tx;
@@ -615,7 +617,19 @@ extern "C" int emip_transpose_pad(const void* X, long ldx, long bsx, void* Y, lo
     dim3 grid((Rpad + 31) / 32, (C + 31) / 32, batch);
     EMIP_REQUIRE(grid.y < 65536);
     DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_pad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)X,
-                                         ldx, bsx, (T*)Y, bsy, R, C, Rpad));
+                                         ldx, bsx, (T*)Y, bsy, R, C, Rpad, 1, 0L));
+    return emip_launch_status();
+}
+
+// batch = B * heads slices: input of (b, h) at b * bsx + h * hsx (C columns each), output [batch][C][Rpad] contiguous
+extern "C" int emip_transpose_pad_heads(const void* X, long ldx, long bsx, long hsx, void* Y, int batch, int heads, int R,
+                                        int C, int Rpad, int dtype, void* stream) {
+    REQ_DT(dtype);
+    EMIP_REQUIRE(X && Y && batch > 0 && batch < 65536 && heads >= 1 && batch % heads == 0 && R > 0 && C > 0 && Rpad >= R);
+    dim3 grid((Rpad + 31) / 32, (C + 31) / 32, batch);
+    EMIP_REQUIRE(grid.y < 65536);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(transpose_pad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)X,
+                                         ldx, bsx, (T*)Y, (long)C * Rpad, R, C, Rpad, heads, hsx));
     return emip_launch_status();
 }
 

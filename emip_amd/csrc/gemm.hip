@@ -34,8 +34,11 @@ struct GemmArgs {
     int act;
     // conv view of A
     int H, Wd, Cin, Ho, Wo, KH, KW, stride, pad;
-    // batching over blockIdx.z
+    // batching over blockIdx.z; with heads > 1 the batch index z = zb * heads + zh and an operand sits at zb * bs + zh * hs
+    // (per-head column slices of [B][tokens][heads*64] tensors)
     long bsA, bsW, bsC, bsR;
+    long hsA, hsW, hsC;
+    int heads;
     int tiles_m, tiles_n;
     // LayerNorm elimination: ln_stats [rows of A][2] = (sum x, sum x^2) over ln_C channels of every A
     // row / input pixel -> the operand loader feeds (x - mean) * rstd to the MFMA (gamma / beta are folded into W / bias by
@@ -116,9 +119,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const long z = bz;
 
-    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + z * p.bsA;
+    const long zb = p.heads > 1 ? z / p.heads : z, zh = p.heads > 1 ? z - zb * p.heads : 0;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + zb * p.bsA + zh * p.hsA;
     const T* __restrict__ A2 = p.A2 ? reinterpret_cast<const T*>(p.A2) + z * p.bsA : nullptr;
-    const T* __restrict__ Wp = reinterpret_cast<const T*>(p.W) + z * p.bsW;
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(p.W) + zb * p.bsW + zh * p.hsW;
 
     // ---- staging bookkeeping: thread owns chunk column sc of rows srow + 32*i
     const int sc = tid & 7;
@@ -393,7 +397,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
         }
         return;
     }
-    T* C = reinterpret_cast<T*>(p.C) + z * p.bsC;   // may alias R (in-place residual update)
+    T* C = reinterpret_cast<T*>(p.C) + zb * p.bsC + zh * p.hsC;   // may alias R (in-place residual update)
     const T* R = p.R ? reinterpret_cast<const T*>(p.R) + z * p.bsR : nullptr;
     constexpr int WM = BM / 2, WN = BN / 2, EP_LD = WN + 4;
     constexpr int CG = WN / VEC;        // 16-B column groups per row of the wave block
@@ -610,6 +614,10 @@ extern "C" int emip_conv2d_splitk(const void*, const void*, void*, const float*,
                                   int, int, int, long, long, int, void*, long, const float*, float, float*, float*, long, int,
                                   int, void*);
 
+// head strides handed from emip_gemm_heads to the shared entry body below (host-side, set and cleared around the call)
+static thread_local long t_hsA = 0, t_hsW = 0, t_hsC = 0;
+static thread_local int t_heads = 1;
+
 static int check_ln(const GemmArgs& a, int batch, bool fast_epilogue) {
     if (a.ln_stats) EMIP_REQUIRE(a.ln_C > 0 && a.ln_eps > 0.f && a.A2 == nullptr && batch == 1 &&
                                  (reinterpret_cast<uintptr_t>(a.ln_stats) & 7) == 0);
@@ -622,6 +630,19 @@ extern "C" int emip_gemm(const void* A, const void* A2, const void* W, void* C, 
                          int batch, long bsA, long bsW, long bsC, long bsR, int dtype, void* stream) {
     return emip_gemm_ln(A, A2, W, C, bias, R, M, N, K, K1, lda, lda2, ldw, ldc, ldr, act, batch, bsA, bsW, bsC, bsR,
                         nullptr, 0, 0.f, nullptr, nullptr, 0, dtype, stream);
+}
+
+// Strided-batched GEMM with a second (head) level: batch = B * heads, operand of (b, h) at b * bs + h * hs.  The per-head
+// products of the attention backward (lib/pvt_v2.py:113-121) in one launch instead of one per head.
+extern "C" int emip_gemm_heads(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc,
+                               int batch, int heads, long bsA, long hsA, long bsW, long hsW, long bsC, long hsC, int dtype,
+                               void* stream) {
+    EMIP_REQUIRE(heads >= 1 && batch >= heads);
+    t_heads = heads; t_hsA = hsA; t_hsW = hsW; t_hsC = hsC;
+    const int rc = emip_gemm_ln(A, nullptr, W, C, nullptr, nullptr, M, N, K, K, lda, 0, ldw, ldc, 0, EMIP_ACT_NONE, batch,
+                                bsA, bsW, bsC, 0, nullptr, 0, 0.f, nullptr, nullptr, 0, dtype, stream);
+    t_heads = 1; t_hsA = t_hsW = t_hsC = 0;
+    return rc;
 }
 
 // emip_gemm plus the LayerNorm-elimination hooks: ln_stats [M][2] (sum, sum of squares over ln_C = K channels of every A
@@ -650,6 +671,8 @@ extern "C" int emip_gemm_ln(const void* A, const void* A2, const void* W, void* 
     a.M = M; a.N = N; a.K = K; a.K1 = K1;
     a.lda = lda; a.lda2 = lda2; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.act = act;
     a.bsA = bsA; a.bsW = bsW; a.bsC = bsC; a.bsR = bsR;
+    a.heads = t_heads; a.hsA = t_hsA; a.hsW = t_hsW; a.hsC = t_hsC;
+    if (t_heads > 1) EMIP_REQUIRE(A2 == nullptr && R == nullptr && batch % t_heads == 0 && t_hsA % vec == 0 && t_hsW % vec == 0);
     a.ln_stats = ln_stats; a.ln_C = ln_C; a.ln_eps = ln_eps; a.out_stats = out_stats;
     if (zero_ptr) EMIP_REQUIRE(zero_bytes > 0 && (zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0);
     a.zero_ptr = static_cast<unsigned*>(zero_ptr);
@@ -714,6 +737,7 @@ extern "C" int emip_conv2d_splitk(const void* X, const void* W, void* Y, const f
     a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
     a.ln_stats = ln_stats; a.ln_C = Cin; a.ln_eps = ln_eps; a.out_stats = out_stats;
     a.acc_out = ksplit > 1 ? acc_out : nullptr; a.ldacc = ldacc; a.ksplit = ksplit;
+    a.heads = 1;
     {
         const bool fast = (ldy % vec) == 0 && aligned16(Y) && Cout % vec == 0 &&
                           (R == nullptr || ((ldr % vec) == 0 && aligned16(R)));
@@ -749,6 +773,7 @@ static int fill_pair_args(const emip_conv_desc_t& d, int dtype, GemmArgs& a) {
     a.H = d.H; a.Wd = d.Wd; a.Cin = d.Cin; a.Ho = Ho; a.Wo = Wo; a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad;
     a.ln_stats = d.ln_stats; a.ln_C = d.Cin; a.ln_eps = d.ln_eps; a.out_stats = d.out_stats;
     a.ksplit = 1;
+    a.heads = 1;
     a.tiles_m = (a.M + 63) / 64;
     a.tiles_n = (a.N + 63) / 64;
     a.dbg = 0;

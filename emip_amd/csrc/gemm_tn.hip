@@ -25,8 +25,11 @@ struct TnArgs {
     int tiles_n, tiles_k;
     // CONV: B[m][k] is the im2col view of an NHWC tensor X (m = output pixel, k = (ky, kx, ci), ci fastest)
     int H, Wd, Cin, Ho, Wo, KW, stride, pad;
-    // batching over blockIdx.z (element strides)
+    // batching over blockIdx.z (element strides); heads > 1: z = zb * heads + zh, operand at zb * bs + zh * hs
     long bsA, bsB, bsC;
+    long hsA, hsB, hsC;
+    int heads;
+    int prezeroed;
 };
 
 __device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -50,9 +53,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
     const int n0 = tile_n * 128, k0 = tile_k * 128;
     const long m_lo = (long)blockIdx.y * p.m_per_split;
     const long m_hi = min(p.M, m_lo + p.m_per_split);
-    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + (long)blockIdx.z * p.bsA;
-    const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B) + (long)blockIdx.z * p.bsB;
-    float* __restrict__ Cp = p.C + (long)blockIdx.z * p.bsC;
+    const long zz = blockIdx.z;
+    const long zb = p.heads > 1 ? zz / p.heads : zz, zh = p.heads > 1 ? zz - zb * p.heads : 0;
+    const T* __restrict__ A = reinterpret_cast<const T*>(p.A) + zb * p.bsA + zh * p.hsA;
+    const T* __restrict__ Bp = reinterpret_cast<const T*>(p.B) + zb * p.bsB + zh * p.hsB;
+    float* __restrict__ Cp = p.C + zb * p.bsC + zh * p.hsC;
 
     uint4 ra[NS], rb[NS];
     auto load_stage = [&](long m0) {
@@ -162,7 +167,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
     }
 
     // lane holds C[n = .. + 4q + reg][k = .. + i16]
-    const bool atomic = gridDim.y > 1;
+    const bool atomic = gridDim.y > 1 || p.prezeroed;
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -202,7 +207,7 @@ int launch_tn(TnArgs& a, int batch, int dtype, hipStream_t s) {
     if (splits > 65535) splits = 65535;
     a.m_per_split = ((a.M + splits - 1) / splits + bms - 1) / bms * bms;
     splits = (a.M + a.m_per_split - 1) / a.m_per_split;
-    if (splits > 1) {   // partial tiles are combined with atomics: clear the output first (dense rows only)
+    if (splits > 1 && !a.prezeroed) {   // partial tiles are combined with atomics: clear the output first (dense rows only)
         if (a.ldc != a.K || (batch > 1 && a.bsC != (long)a.N * a.K)) return EMIP_E_INVALID;
         if (emip_zero_async(a.C, sizeof(float) * (size_t)a.N * a.K * batch, s) != EMIP_OK) return EMIP_E_LAUNCH;
     }
@@ -223,6 +228,24 @@ extern "C" int emip_gemm_tn(const void* A, const void* B, float* C, long M, int 
     TnArgs a{};
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.bsA = bsA; a.bsB = bsB; a.bsC = bsC;
+    a.heads = 1;
+    return launch_tn<false>(a, batch, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
+// Two-level batch (batch = B * heads, operand of (b, h) at b * bs + h * hs) and an output that may be a column slice of a
+// wider PRE-ZEROED f32 buffer (ldc > K): results are ADDED with atomics.  dK / dV of all attention heads in one launch,
+// written straight into the [B][keys][2C] gradient of the kv projection.
+extern "C" int emip_gemm_tn_heads(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb,
+                                  long ldc, int batch, int heads, long bsA, long hsA, long bsB, long hsB, long bsC,
+                                  long hsC, int dtype, void* stream) {
+    EMIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536 && heads >= 1 && batch % heads == 0);
+    EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= N && ldb >= K && ldc >= K);
+    EMIP_REQUIRE(bsA % vec == 0 && bsB % vec == 0 && hsA % vec == 0 && hsB % vec == 0 && aligned16(A) && aligned16(B));
+    TnArgs a{};
+    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.bsA = bsA; a.bsB = bsB; a.bsC = bsC; a.hsA = hsA; a.hsB = hsB; a.hsC = hsC; a.heads = heads; a.prezeroed = 1;
     return launch_tn<false>(a, batch, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -241,5 +264,6 @@ extern "C" int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B
     a.A = dY; a.B = X; a.C = dW; a.M = (long)B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin;
     a.lda = lddy; a.ldb = ldx; a.ldc = a.K;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.heads = 1;
     return launch_tn<true>(a, 1, dtype, reinterpret_cast<hipStream_t>(stream));
 }

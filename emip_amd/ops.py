@@ -695,3 +695,29 @@ def mlp_head(x, w1, b1, wt, bdw, out=None):
     _lib.call("emip_mlp_head", _p(x), ldx, _p(w1), _p(b1), _p(wt), _p(bdw), _p(out), ldg, B, H, W, C, Ch,
               dt_code(x.dtype), _stream())
     return out
+
+
+def gemm_heads(a, w, out, batch, heads, M, N, K, lda, ldw, ldc, bsA, hsA, bsW, hsW, bsC, hsC):
+    """per (b, h): out = a w^T on raw views; operand of (b, h) at b * bs + h * hs (batch = B * heads)"""
+    _dev(a)
+    _lib.call("emip_gemm_heads", _p(a), _p(w), _p(out), M, N, K, lda, ldw, ldc, batch, heads, bsA, hsA, bsW, hsW, bsC, hsC,
+              dt_code(a.dtype), _stream())
+    return out
+
+
+def gemm_tn_heads(a, b, out, batch, heads, M, N, K, lda, ldb, ldc, bsA, hsA, bsB, hsB, bsC, hsC):
+    """per (b, h): out[n, k] += sum_m a[m, n] b[m, k] into the PRE-ZEROED f32 `out` (may be a column slice, ldc > K)"""
+    _dev(a)
+    assert out.dtype == torch.float32
+    _lib.call("emip_gemm_tn_heads", _p(a), _p(b), _p(out), M, N, K, lda, ldb, ldc, batch, heads, bsA, hsA, bsB, hsB, bsC,
+              hsC, dt_code(a.dtype), _stream())
+    return out
+
+
+def transpose_pad_heads(x, batch, heads, R, C, Rpad, ldx, bsx, hsx):
+    """slices (b, h) of x (R rows of C columns at b * bsx + h * hsx) -> [batch, C, Rpad], zero padded"""
+    _dev(x)
+    y = torch.empty((batch, C, Rpad), dtype=x.dtype, device=x.device)
+    _lib.call("emip_transpose_pad_heads", _p(x), ldx, bsx, hsx, _p(y), batch, heads, R, C, Rpad, dt_code(x.dtype),
+              _stream())
+    return y

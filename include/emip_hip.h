@@ -251,6 +251,17 @@ int emip_softmax_rows(const void* X, void* Y, long rows, int L, long ld, float s
 int emip_softmax_bwd_rows(const void* P, const void* DP, void* DS, long rows, int L, long ld, float scale, int dtype,
                           void* stream);
 
+/* Per-head products of the attention backward in ONE launch each (lib/pvt_v2.py:113-121: heads are 64-column slices of
+ * [B][tokens][C] tensors): batch = B * heads, the operand of (b, h) sits at b * bs + h * hs.  emip_gemm_tn_heads ADDS its
+ * results with atomics into a PRE-ZEROED f32 output that may be a column slice of a wider buffer (ldc > K). */
+int emip_gemm_heads(const void* A, const void* W, void* C, int M, int N, int K, long lda, long ldw, long ldc, int batch,
+                    int heads, long bsA, long hsA, long bsW, long hsW, long bsC, long hsC, int dtype, void* stream);
+int emip_gemm_tn_heads(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc,
+                       int batch, int heads, long bsA, long hsA, long bsB, long hsB, long bsC, long hsC, int dtype,
+                       void* stream);
+int emip_transpose_pad_heads(const void* X, long ldx, long bsx, long hsx, void* Y, int batch, int heads, int R, int C,
+                             int Rpad, int dtype, void* stream);
+
 /* Y[z][c][r] = r < R ? X[z][r][c] : 0 (r < Rpad): the K^T operand of dQ = dS K. */
 int emip_transpose_pad(const void* X, long ldx, long bsx, void* Y, long bsy, int batch, int R, int C, int Rpad,
                        int dtype, void* stream);
