@@ -46,12 +46,19 @@ class LinearFn(Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
         dx = ops.gemm(dy, ctx.wpt) if ctx.needs_input_grad[0] else None
-        dw = None
+        dw = db = None
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             n = weight.shape[0]
             kw = weight.numel() // n                      # x may carry zero-padded columns beyond the weight's K
-            dw = ops.gemm_tn(dy, x)[:n, :kw].contiguous().view_as(weight)
-        db = colsum_f32(dy)[:weight.shape[0]].contiguous() if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            if want_db:                                    # bias gradient from the dY tiles the weight-gradient GEMM stages
+                dwf, dbf = ops.gemm_tn(dy, x, with_colsum=True)
+                db = dbf[:n].contiguous()
+            else:
+                dwf = ops.gemm_tn(dy, x)
+            dw = dwf[:n, :kw].contiguous().view_as(weight)
+        elif want_db:
+            db = colsum_f32(dy)[:weight.shape[0]].contiguous()
         dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres, None, None, None
 

@@ -12,6 +12,9 @@
 // transposed read touches land in distinct bank groups.
 #include "common.h"
 
+extern "C" int emip_gemm_tn_bias(const void*, const void*, float*, float*, long, int, int, long, long, long, int, long, long,
+                                 long, int, void*);
+
 namespace {
 
 struct TnArgs {
@@ -30,6 +33,7 @@ struct TnArgs {
     long hsA, hsB, hsC;
     int heads;
     int prezeroed;
+    float* db;     // optional: column sums of A (the bias gradient sum_m dY[m][n]), accumulated with atomics (zero beforehand)
 };
 
 __device__ __forceinline__ int tn_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
@@ -60,6 +64,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
     float* __restrict__ Cp = p.C + zb * p.bsC + zh * p.hsC;
 
     uint4 ra[NS], rb[NS];
+    // bias gradient: a thread always stages the same 16-byte column chunk of A (256 % CPR == 0), so it can keep the column
+    // sums of everything it stages; only the k-tile-0 workgroups do it, so that every element of A is counted once
+    constexpr int VEC = 16 / ES;
+    const bool do_db = p.db != nullptr && tile_k == 0;
+    float cs[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) cs[j] = 0.f;
     auto load_stage = [&](long m0) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
@@ -87,6 +98,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
         }
     };
     auto store_stage = [&]() {
+        if (do_db) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const T* e = reinterpret_cast<const T*>(&ra[i]);
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) cs[j] += to_f32<T>(e[j]);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
             const int id = tid + 256 * i;
@@ -166,6 +185,20 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
         }
     }
 
+    if (do_db) {      // workgroup-uniform
+        __syncthreads();                                   // the staging tiles are free now
+        float* red = reinterpret_cast<float*>(smem);        // [256 / CPR][CPR * VEC]
+        const int c = tid % CPR, g = tid / CPR;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) red[g * (CPR * VEC) + c * VEC + j] = cs[j];
+        __syncthreads();
+        if (tid < CPR * VEC) {
+            float t = 0.f;
+            for (int gg = 0; gg < 256 / CPR; ++gg) t += red[gg * (CPR * VEC) + tid];
+            const int n = n0 + tid;
+            if (n < p.N) atomicAdd(p.db + (long)blockIdx.z * p.N + n, t);
+        }
+    }
     // lane holds C[n = .. + 4q + reg][k = .. + i16]
     const bool atomic = gridDim.y > 1 || p.prezeroed;
 #pragma unroll
@@ -220,6 +253,13 @@ int launch_tn(TnArgs& a, int batch, int dtype, hipStream_t s) {
 
 extern "C" int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc,
                             int batch, long bsA, long bsB, long bsC, int dtype, void* stream) {
+    return emip_gemm_tn_bias(A, B, C, nullptr, M, N, K, lda, ldb, ldc, batch, bsA, bsB, bsC, dtype, stream);
+}
+
+// emip_gemm_tn that also accumulates db[n] += sum_m A[m][n] (the bias gradient of the same Linear; db f32 [batch][N], zero
+// beforehand): the dY tile is already being staged, so the separate column-sum pass over dY disappears.
+extern "C" int emip_gemm_tn_bias(const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda,
+                                 long ldb, long ldc, int batch, long bsA, long bsB, long bsC, int dtype, void* stream) {
     EMIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536);
     EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
     const int vec = dtype == EMIP_F32 ? 4 : 8;
@@ -229,6 +269,7 @@ extern "C" int emip_gemm_tn(const void* A, const void* B, float* C, long M, int 
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.bsA = bsA; a.bsB = bsB; a.bsC = bsC;
     a.heads = 1;
+    a.db = db;
     return launch_tn<false>(a, batch, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -373,14 +373,20 @@ def photometric_loss(im, rec, mask, out, weight=1.0, accumulate=False):
     return out
 
 
-def gemm_tn(a, b):
-    """c[n, k] = sum_m a[m, n] * b[m, k]  (weight gradient: a = dY, b = X) -> f32 [N, K]"""
+def gemm_tn(a, b, with_colsum=False):
+    """c[n, k] = sum_m a[m, n] * b[m, k]  (weight gradient: a = dY, b = X) -> f32 [N, K]
+    with_colsum: also return sum_m a[m, n] (the bias gradient) from the same launch"""
     M, N, lda = rows(a)
     Mb, K, ldb = rows(b)
     assert M == Mb and a.dtype == b.dtype
     c = torch.empty((N, K), dtype=torch.float32, device=a.device)
-    _lib.call("emip_gemm_tn", _p(a), _p(b), _p(c), M, N, K, lda, ldb, K, 1, 0, 0, 0, dt_code(a.dtype), _stream())
-    return c
+    if not with_colsum:
+        _lib.call("emip_gemm_tn", _p(a), _p(b), _p(c), M, N, K, lda, ldb, K, 1, 0, 0, 0, dt_code(a.dtype), _stream())
+        return c
+    db = torch.zeros(N, dtype=torch.float32, device=a.device)
+    _lib.call("emip_gemm_tn_bias", _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, 1, 0, 0, 0, dt_code(a.dtype),
+              _stream())
+    return c, db
 
 
 def gemm_tn_batched(a, b, batch, M, N, K, lda, ldb, bsA, bsB):

@@ -230,6 +230,11 @@ int emip_photometric_loss(const float* im, const float* rec, const float* mask, 
 int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc, int batch,
                  long bsA, long bsB, long bsC, int dtype, void* stream);
 
+/* emip_gemm_tn that also accumulates the bias gradient db[n] += sum_m A[m][n] (f32 [batch][N], zero beforehand) from the dY
+ * tiles it stages anyway. */
+int emip_gemm_tn_bias(const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda, long ldb, long ldc,
+                      int batch, long bsA, long bsB, long bsC, int dtype, void* stream);
+
 /* Weight gradient of an NHWC conv, packed like the forward weights: dW[co][ky][kx][ci] (f32) =
  * sum over output pixels of dY[pix][co] * X[pix shifted by the tap][ci]  (zero padding honoured). */
 int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout,
