@@ -117,8 +117,10 @@ class DwConvFn(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, wt, wt_flip, gelu):
-        z = ops.dwconv3x3(x, wt, bias)
-        y = ops.dwconv3x3(x, wt, bias, act=ops.ACT_GELU) if gelu else z
+        if gelu:
+            y, z = ops.dwconv3x3_dual(x, wt, bias, ops.ACT_GELU)      # one pass: GELU output + pre-activation for backward
+        else:
+            y = z = ops.dwconv3x3(x, wt, bias)
         ctx.save_for_backward(x, z if gelu else x, weight)
         ctx.cfg = (wt_flip, gelu, bias is not None)
         return y

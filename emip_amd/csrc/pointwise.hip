@@ -5,6 +5,9 @@
 // touches whole contiguous rows).
 #include "common.h"
 
+extern "C" int emip_dwconv3x3_dual(const void*, long, void*, long, void*, long, const float*, const float*, int, int, int, int,
+                                   int, int, void*);
+
 namespace {
 
 constexpr int kMaxBlocks = 256 * 16;  // memory-bound grids: cap and grid-stride
@@ -335,7 +338,7 @@ template <typename T, int XT>
 __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y,
                                                              long ldy, const float* __restrict__ Wt,
                                                              const float* __restrict__ bias, int B, int H, int Wd,
-                                                             int C, int act) {
+                                                             int C, int act, T* __restrict__ Z, long ldz) {
     constexpr int NV = 16 / sizeof(T);
     const int ncg = C / NV;
     const int nxg = (Wd + XT - 1) / XT;
@@ -400,6 +403,19 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const T* __restrict
 #pragma unroll
                         for (int j = 0; j < NV; ++j) acc[o][j] = fmaf(v[j], w[kx][j], acc[o][j]);
                     }
+                }
+            }
+        }
+        if (Z) {                         // pre-activation copy for the backward pass (training): same launch, one more store
+#pragma unroll
+            for (int o = 0; o < XT; ++o) {
+                const int x = x0 + o;
+                if (x < Wd) {
+                    uint4 zv;
+                    T* zp = reinterpret_cast<T*>(&zv);
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) zp[j] = from_f32<T>(acc[o][j]);
+                    *reinterpret_cast<uint4*>(Z + ((b * H + y) * (long)Wd + x) * ldz + c) = zv;
                 }
             }
         }
@@ -814,17 +830,25 @@ extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long 
 
 extern "C" int emip_dwconv3x3(const void* X, long ldx, void* Y, long ldy, const float* Wt, const float* bias, int B,
                               int H, int Wd, int C, int act, int dtype, void* stream) {
+    return emip_dwconv3x3_dual(X, ldx, Y, ldy, nullptr, 0, Wt, bias, B, H, Wd, C, act, dtype, stream);
+}
+
+// emip_dwconv3x3 that also stores the pre-activation values Z (what the GELU backward needs) from the same pass
+extern "C" int emip_dwconv3x3_dual(const void* X, long ldx, void* Y, long ldy, void* Z, long ldz, const float* Wt,
+                                   const float* bias, int B, int H, int Wd, int C, int act, int dtype, void* stream) {
     REQ_DT(dtype);
     EMIP_REQUIRE(X && Y && Wt && B > 0 && H > 0 && Wd > 0 && C >= 4 && (C & 3) == 0);
     EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
     const int nv = dtype == EMIP_F32 ? 4 : 8;
     if (C % nv == 0 && ldx % nv == 0 && ldy % nv == 0 && aligned16(X) && aligned16(Y)) {
         const long total = (long)B * H * ((Wd + 3) / 4) * (C / nv);
+        if (Z) EMIP_REQUIRE(ldz % nv == 0 && ldz >= C && aligned16(Z));
         DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_rows_kernel<T, 4>), dim3(grid_for(total, 256)), dim3(256), 0,
                                              (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, Wt, bias, B, H, Wd, C,
-                                             act));
+                                             act, (T*)Z, ldz));
         return emip_launch_status();
     }
+    EMIP_REQUIRE(Z == nullptr);          // the dual store lives in the vectorised kernel only
     const long total = (long)B * H * Wd * (C >> 2);
     DISPATCH_T(dtype, hipLaunchKernelGGL((dwconv3x3_kernel<T, false>), dim3(grid_for(total, 256)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, Wt, bias, B, H, Wd, C, C,

@@ -212,6 +212,17 @@ def dwconv3x3(x, wt, bias=None, act=ACT_NONE, out=None):
     return out
 
 
+def dwconv3x3_dual(x, wt, bias, act):
+    """-> (act(dwconv(x)), dwconv(x)): activation output and pre-activation values from one pass"""
+    B, H, W, C = x.shape
+    M, _, ldx = rows(x)
+    y = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    z = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    _lib.call("emip_dwconv3x3_dual", _p(x), ldx, _p(y), C, _p(z), C, _p(wt), _p(bias), B, H, W, C, act,
+              dt_code(x.dtype), _stream())
+    return y, z
+
+
 def dwconv3x3_gated(x, wt, cout_pad, bias=None):
     B, H, W, C2 = x.shape
     _, _, ldx = rows(x)

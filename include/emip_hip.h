@@ -161,6 +161,9 @@ int emip_chan_norm_apply(const void* X, long ldx, void* Y, long ldy, const void*
  * PromptInteract.py:402-404 (q_dwconv, kv_dwconv). */
 int emip_dwconv3x3(const void* X, long ldx, void* Y, long ldy, const float* Wt, const float* bias, int B, int H,
                    int Wd, int C, int act, int dtype, void* stream);
+/* same, also storing the pre-activation values Z (input of the GELU backward) from the same pass */
+int emip_dwconv3x3_dual(const void* X, long ldx, void* Y, long ldy, void* Z, long ldz, const float* Wt, const float* bias,
+                        int B, int H, int Wd, int C, int act, int dtype, void* stream);
 
 /* Gated depthwise: X has C2 = 2*Ch channels, Y[c] = gelu(dw(X)[c]) * dw(X)[Ch+c], zero for Ch <= c < Cout_pad.
  * PromptInteract.py:380-384 (GDFN). */
