@@ -79,7 +79,7 @@ def test_layernorm_backward(dtype, M, C):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_layernorm_backward_many_rows_partial_accumulators(dtype):
-    """the autograd path spreads dgamma / dbeta over 32 partial accumulators for >= 8192 rows"""
+    """many-row LayerNorm backward through the autograd entry, and the kernel's partial-accumulator mode (nparts = 32)"""
     from emip_amd import ops
     M, C = 30976, 320
     x, xf = prep(rnd(M, C, seed=11) * 2 + 0.3, dtype)
@@ -91,6 +91,14 @@ def test_layernorm_backward_many_rows_partial_accumulators(dtype):
     dx, dg, db = ops.layernorm_bwd_fresh(x, dy, g.cuda(), 1e-6)
     tol = 2e-4 if dtype == torch.float32 else 2e-2
     assert rel(dx, xr.grad) < tol and rel(dg, gr.grad) < tol and rel(db, br.grad) < tol
+    from emip_amd import _lib
+    acc = torch.zeros(32, 2, C, device="cuda:0")
+    dx2 = torch.empty_like(x)
+    _lib.call("emip_layernorm_bwd", x.data_ptr(), C, dy.data_ptr(), C, dx2.data_ptr(), C, g.cuda().data_ptr(),
+              acc.data_ptr(), acc[0, 1].data_ptr(), 32, 2 * C, M, C, 1e-6, 0 if dtype == torch.float32 else 1,
+              torch.cuda.current_stream().cuda_stream)
+    s = acc.sum(0)
+    assert rel(dx2, xr.grad) < tol and rel(s[0], gr.grad) < tol and rel(s[1], br.grad) < tol
 
 
 def _pack_conv_w(w):  # [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin]
