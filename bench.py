@@ -319,6 +319,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=4, help="sub-batches replayed concurrently on separate HIP streams")
     args = ap.parse_args()
+    if os.environ.get("EMIP_KV_SPLIT"):
+        from emip_amd import ops
+        ops.KV_SPLIT = os.environ["EMIP_KV_SPLIT"] != "0"
     if args.workload == "train":
         return main_train(args)
     if args.workload == "long":

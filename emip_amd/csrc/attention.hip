@@ -20,6 +20,10 @@
 // ds_read_b128; the bf16 V tile is swizzled for conflict-free transposed reads.
 #include "common.h"
 
+extern "C" int emip_attention_splitkv(const void*, const void*, const void*, void*, void*, int, int, int, int, int, int, int, long,
+                                      long, long, long, long, long, long, long, long, long, long, long, long, long, const int*,
+                                      const int*, const int*, const int*, float, int, int, float*, int, void*);
+
 namespace {
 
 struct AttnArgs {
@@ -38,6 +42,11 @@ struct AttnArgs {
     const int* k_gid;
     float scale;
     int o_f32;
+    // KV split (long key sets on small grids): blockIdx.y = head * ksplit + split, every split walks 1/ksplit of the key
+    // tiles and leaves (unnormalised O, running max, running sum) in ws [z][head][split][Lq][DV + 2] (f32); attn_merge_kernel
+    // combines the splits and writes O
+    int ksplit;
+    float* ws;
 };
 
 template <int RB>
@@ -76,7 +85,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     const int z = blockIdx.z;
     const int win = z % p.nwin;
     const long batch = z / p.nwin;
-    const int head = blockIdx.y;
+    const int head = p.ksplit > 1 ? (int)blockIdx.y / p.ksplit : (int)blockIdx.y;
+    const int split = p.ksplit > 1 ? (int)blockIdx.y - head * p.ksplit : 0;
 
     const T* __restrict__ Qp = reinterpret_cast<const T*>(p.Q) + batch * p.q_bs + head * p.q_hs;
     const T* __restrict__ Kp = reinterpret_cast<const T*>(p.K) + batch * p.k_bs + head * p.k_hs;
@@ -153,11 +163,16 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
     T* __restrict__ Sp = p.S ? reinterpret_cast<T*>(p.S) + (long)z * p.s_bs + (long)head * 0 : nullptr;
 
-    const int ntile = (p.Lk + BKV - 1) / BKV;
-    load_tile(0);
-    store_tile(0);
+    const int ntile_all = (p.Lk + BKV - 1) / BKV;
+    const int tps = p.ksplit > 1 ? (ntile_all + p.ksplit - 1) / p.ksplit : ntile_all;
+    const int t_lo = split * tps;
+    const int ntile = min(ntile_all, t_lo + tps);          // this workgroup walks tiles [t_lo, ntile)
+    if (t_lo < ntile) {
+        load_tile(t_lo);
+        store_tile(t_lo & 1);
+    }
     __syncthreads();
-    for (int t = 0; t < ntile; ++t) {
+    for (int t = t_lo; t < ntile; ++t) {
         const int cur = t & 1;
         if (t + 1 < ntile) load_tile(t + 1);
         const char* kt_ = smem + cur * STAGE_BYTES;
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
         // ---- raw scores out (the correlation volume), masks, online softmax
         float tmax = -INFINITY;
-        const bool last_partial = (t == ntile - 1) && (p.Lk % BKV != 0);
+        const bool last_partial = (t == ntile_all - 1) && (p.Lk % BKV != 0);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -294,6 +309,27 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
     // ---- epilogue
     const float l_tot = l_run + __shfl_xor(l_run, 32);
+    if (p.ksplit > 1) {
+        // partial result of this key range: unnormalised O (f32), running max (log2 units) and running sum
+        if (q_ok) {
+            float* wp = p.ws + ((((long)z * p.heads + head) * p.ksplit + split) * p.Lq + q) * (DV + 2);
+#pragma unroll
+            for (int d = 0; d < NDT; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float v4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = oacc[d][4 * g + j];
+                    *reinterpret_cast<float2*>(wp + 32 * d + 8 * g + 4 * h) = make_float2(v4[0], v4[1]);
+                    *reinterpret_cast<float2*>(wp + 32 * d + 8 * g + 4 * h + 2) = make_float2(v4[2], v4[3]);
+                }
+            if (h == 0) {
+                wp[DV] = m_run;
+                wp[DV + 1] = l_tot;
+            }
+        }
+        return;
+    }
     const float inv = 1.0f / l_tot;
     if (q_ok) {
         const long orow = q_row;
@@ -323,6 +359,43 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     }
 }
 
+// combine the key-range partials: O = sum_s O_s 2^(m_s - M) / sum_s l_s 2^(m_s - M)
+template <typename T, int DV>
+__global__ __launch_bounds__(256) void attn_merge_kernel(const AttnArgs p, int zcount) {
+    const long total = (long)zcount * p.heads * p.Lq * (DV / 4);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(idx % (DV / 4));
+        long r = idx / (DV / 4);
+        const int q = (int)(r % p.Lq);
+        r /= p.Lq;
+        const int head = (int)(r % p.heads);
+        const long z = r / p.heads;
+        const float* wp = p.ws + (((z * p.heads + head) * p.ksplit) * (long)p.Lq + q) * (DV + 2);
+        const long sstride = (long)p.Lq * (DV + 2);
+        float M = -INFINITY;
+        for (int s = 0; s < p.ksplit; ++s) M = fmaxf(M, wp[s * sstride + DV]);
+        float L = 0.f, o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.ksplit; ++s) {
+            const float m = wp[s * sstride + DV];
+            const float f = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - M);      // an empty key range contributes nothing
+            L += wp[s * sstride + DV + 1] * f;
+            const float4 v = *reinterpret_cast<const float4*>(wp + s * sstride + 4 * c4);
+            o[0] += v.x * f; o[1] += v.y * f; o[2] += v.z * f; o[3] += v.w * f;
+        }
+        const float inv = 1.f / L;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] *= inv;
+        const int win = (int)(z % p.nwin);
+        const long batch = z / p.nwin;
+        const long orow = p.q_rows ? p.q_rows[(long)win * p.Lq + q] : q;
+        if (p.o_f32) {
+            Vec4<float>::store(reinterpret_cast<float*>(p.O) + batch * p.o_bs + head * p.o_hs + orow * p.ldo + 4 * c4, o);
+        } else {
+            Vec4<T>::store(reinterpret_cast<T*>(p.O) + batch * p.o_bs + head * p.o_hs + orow * p.ldo + 4 * c4, o);
+        }
+    }
+}
+
 template <typename T, int D, int DV, int BKV>
 int launch_bkv(const AttnArgs& a, int batch, hipStream_t s) {
     constexpr int ES = sizeof(T);
@@ -336,8 +409,14 @@ int launch_bkv(const AttnArgs& a, int batch, hipStream_t s) {
                                 (int)lds) != hipSuccess)
             return EMIP_E_LAUNCH;
     }
-    dim3 grid((a.Lq + 127) / 128, a.heads, batch * a.nwin);
+    dim3 grid((a.Lq + 127) / 128, a.heads * (a.ksplit > 1 ? a.ksplit : 1), batch * a.nwin);
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, s, a);
+    if (a.ksplit > 1) {
+        const long items = (long)batch * a.nwin * a.heads * a.Lq * (DV / 4);
+        long blocks = (items + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL((attn_merge_kernel<T, DV>), dim3((unsigned)blocks), dim3(256), 0, s, a, batch * a.nwin);
+    }
     return emip_launch_status();
 }
 
@@ -359,6 +438,23 @@ extern "C" int emip_attention(const void* Q, const void* K, const void* V, void*
                               long s_bs, long ldq, long ldk, long ldv, long ldo, long lds, long q_hs, long k_hs,
                               long v_hs, long o_hs, const int* q_rows, const int* k_rows, const int* q_gid,
                               const int* k_gid, float scale, int o_f32, int dtype, void* stream) {
+    return emip_attention_splitkv(Q, K, V, O, S, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_bs, o_bs, s_bs, ldq, ldk,
+                                  ldv, ldo, lds, q_hs, k_hs, v_hs, o_hs, q_rows, k_rows, q_gid, k_gid, scale, o_f32, 1,
+                                  nullptr, dtype, stream);
+}
+
+// emip_attention with the key range split over ksplit workgroups per query tile (flash-decoding style): for long key sets on
+// small grids (global matching / flow propagation: 1936 keys, the EMIP-long memory read: up to 9680) a workgroup otherwise
+// walks all key tiles serially while most of the chip idles.  ws: f32 [batch*nwin][heads][ksplit][Lq][DV + 2] scratch; a
+// second small launch merges the partial softmaxes and writes O.
+extern "C" int emip_attention_splitkv(const void* Q, const void* K, const void* V, void* O, void* S, int batch, int heads,
+                                      int nwin, int Lq, int Lk, int D, int DV, long q_bs, long k_bs, long v_bs, long o_bs,
+                                      long s_bs, long ldq, long ldk, long ldv, long ldo, long lds, long q_hs, long k_hs,
+                                      long v_hs, long o_hs, const int* q_rows, const int* k_rows, const int* q_gid,
+                                      const int* k_gid, float scale, int o_f32, int ksplit, float* ws, int dtype,
+                                      void* stream) {
+    EMIP_REQUIRE(ksplit >= 1 && ksplit <= 32 && (ksplit == 1 || (ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0)));
+    EMIP_REQUIRE((long)heads * ksplit < 65536);
     EMIP_REQUIRE(Q && K && V && O && batch > 0 && heads > 0 && nwin > 0 && Lq > 0 && Lk > 0);
     EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
     EMIP_REQUIRE((long)batch * nwin < 65536 && heads < 65536);
@@ -378,6 +474,7 @@ extern "C" int emip_attention(const void* Q, const void* K, const void* V, void*
     a.q_hs = q_hs; a.k_hs = k_hs; a.v_hs = v_hs; a.o_hs = o_hs;
     a.q_rows = q_rows; a.k_rows = k_rows; a.q_gid = q_gid; a.k_gid = k_gid;
     a.scale = scale; a.o_f32 = o_f32;
+    a.ksplit = ksplit; a.ws = ws;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define ATTN_CASE(d, dv)                                                                     \
     if (D == d && DV == dv)                                                                  \

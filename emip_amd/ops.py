@@ -180,11 +180,30 @@ def layernorm(x, gamma, beta, eps, out=None, res=None, out_stats=None):
     return out
 
 
+KV_SPLIT = True      # emip_attention_splitkv for >= 1024 keys on grids of < 256 workgroups
+
+
 def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo,
               q_hs=0, k_hs=0, v_hs=0, o_hs=0, q_rows=None, k_rows=None, q_gid=None, k_gid=None, scale=1.0,
-              scores=None, s_bs=0, lds=0):
+              scores=None, s_bs=0, lds=0, ksplit=None):
     _dev(q)
     o_f32 = 1 if (out.dtype == torch.float32 and q.dtype != torch.float32) else 0
+    # long key sets on small grids: split the keys over workgroups (about 256 workgroups in total, >= 4 key tiles each)
+    bkv = 64 if q.dtype == torch.bfloat16 else 32
+    ntile = (Lk + bkv - 1) // bkv
+    wgs = ((Lq + 127) // 128) * heads * batch * nwin
+    if ksplit is not None:
+        pass
+    elif not (KV_SPLIT and Lk >= 1024 and wgs < 256):
+        ksplit = 1
+    else:
+        ksplit = max(1, min(ntile // 4, (256 + wgs - 1) // wgs, 32))
+    if ksplit > 1:
+        ws = torch.empty(batch * nwin * heads * ksplit * Lq * (DV + 2), dtype=torch.float32, device=q.device)
+        _lib.call("emip_attention_splitkv", _p(q), _p(k), _p(v), _p(out), _p(scores), batch, heads, nwin, Lq, Lk, D, DV,
+                  q_bs, k_bs, v_bs, o_bs, s_bs, ldq, ldk, ldv, ldo, lds, q_hs, k_hs, v_hs, o_hs, _p(q_rows), _p(k_rows),
+                  _p(q_gid), _p(k_gid), float(scale), o_f32, ksplit, _p(ws), dt_code(q.dtype), _stream())
+        return out
     _lib.call("emip_attention", _p(q), _p(k), _p(v), _p(out), _p(scores), batch, heads, nwin, Lq, Lk, D, DV, q_bs,
               k_bs, v_bs, o_bs, s_bs, ldq, ldk, ldv, ldo, lds, q_hs, k_hs, v_hs, o_hs, _p(q_rows), _p(k_rows),
               _p(q_gid), _p(k_gid), float(scale), o_f32, dt_code(q.dtype), _stream())

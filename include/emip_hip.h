@@ -126,6 +126,15 @@ int emip_attention(const void* Q, const void* K, const void* V, void* O, void* S
                    long ldk, long ldv, long ldo, long lds, long q_hs, long k_hs, long v_hs, long o_hs,
                    const int* q_rows, const int* k_rows, const int* q_gid, const int* k_gid, float scale, int o_f32,
                    int dtype, void* stream);
+/* emip_attention with the key range split over ksplit workgroups per query tile (flash-decoding style) and a small merge
+ * launch: for long key sets on small grids (global matching / flow propagation, matching.py:8-41, transformer.py:503-533:
+ * 1936 keys; the EMIP-long memory read, LTM.py:49-68: up to 9680) one workgroup otherwise walks every key tile serially.
+ * ws: f32 [batch*nwin][heads][ksplit][Lq][DV + 2] scratch (16-byte aligned). */
+int emip_attention_splitkv(const void* Q, const void* K, const void* V, void* O, void* S, int batch, int heads, int nwin,
+                           int Lq, int Lk, int D, int DV, long q_bs, long k_bs, long v_bs, long o_bs, long s_bs, long ldq,
+                           long ldk, long ldv, long ldo, long lds, long q_hs, long k_hs, long v_hs, long o_hs,
+                           const int* q_rows, const int* k_rows, const int* q_gid, const int* k_gid, float scale,
+                           int o_f32, int ksplit, float* ws, int dtype, void* stream);
 
 /* MDTA channel attention matrix: L2-normalise q,k over pixels, 64x64 Gram per head, * temperature, softmax.
  * PromptInteract.py:423-428.  ws: f32 [B*heads*(4096+128)] scratch; attn out: T [B][heads][64][64]. */

@@ -185,6 +185,35 @@ def test_attention_scores_and_dv32(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("Lq,Lk,heads,ksplit", [(300, 2500, 1, 4), (484, 9680, 2, 7), (130, 1100, 1, 5), (1936, 1936, 1, 3)])
+def test_attention_kv_split(dtype, Lq, Lk, heads, ksplit):
+    """emip_attention_splitkv == the one-pass kernel == softmax(QK^T)V: ragged key counts, splits that own no key tile
+    ((130, 1100, ., 5) in bf16: 18 tiles -> 4 per split, the fifth split is empty), two heads, scattered output rows."""
+    from emip_amd import ops
+    B, D = 2, 128
+    C = heads * D
+    q, qf = prep(rnd(B, Lq, C, seed=1), dtype)
+    k, kf = prep(rnd(B, Lk, C, seed=2) * 1.5, dtype)
+    v, vf = prep(rnd(B, Lk, C, seed=3), dtype)
+    perm = torch.randperm(Lq, generator=torch.Generator().manual_seed(4)).to(torch.int32).to(dev())
+    outs = []
+    for ks in (1, ksplit):
+        out = torch.zeros(B, Lq, C, dtype=dtype, device=dev())
+        ops.attention(q, k, v, out, batch=B, heads=heads, nwin=1, Lq=Lq, Lk=Lk, D=D, DV=D, q_bs=Lq * C, k_bs=Lk * C,
+                      v_bs=Lk * C, o_bs=Lq * C, ldq=C, ldk=C, ldv=C, ldo=C, q_hs=D, k_hs=D, v_hs=D, o_hs=D,
+                      q_rows=perm, scale=D ** -0.5, ksplit=ks)
+        outs.append(out)
+    qh = qf[:, perm.cpu().long()].view(B, Lq, heads, D).permute(0, 2, 1, 3)
+    kh = kf.view(B, Lk, heads, D).permute(0, 2, 1, 3)
+    vh = vf.view(B, Lk, heads, D).permute(0, 2, 1, 3)
+    ref, _ = _attn_ref(qh, kh, vh, D ** -0.5)
+    ref_rows = torch.zeros(B, Lq, C)
+    ref_rows[:, perm.cpu().long()] = ref.permute(0, 2, 1, 3).reshape(B, Lq, C)
+    check(outs[1], ref_rows, dtype, f32=2e-4, bf16=3e-2, name="kv-split")
+    check(outs[1], outs[0].float().cpu(), dtype, f32=2e-4, bf16=2e-2, name="split-vs-one-pass")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_mdta_attn(dtype):
     from emip_amd import ops
     B, P, heads = 2, 1936, 2
