@@ -3,8 +3,9 @@
 Same classes / `step` / `get_results` protocol as /root/reference/eval/metrics.py (`MAE` :90-106, `Smeasure` :109-217),
 as `train.py:129-146` uses them, but `pred` and `gt` are device tensors: a frame costs one C-ABI call (three small
 reduction launches) and a 320-byte copy instead of a full-resolution f32 map to the host plus numpy.  The scalar
-finalisation below follows the reference's formulas in float64.  `WeightedFmeasure` (:333-397) needs an exact Euclidean
-distance transform (scipy `distance_transform_edt`) and is not moved."""
+finalisation below follows the reference's formulas in float64.  `WeightedFmeasure` (:333-397) runs the exact Euclidean
+feature transform (scipy's `distance_transform_edt(..., return_indices=True)`, including its choice among equidistant
+pixels), the 7x7 Gaussian and the weighted sums on the device (`emip_eval_wfm`)."""
 import numpy as np
 import torch
 
@@ -119,16 +120,85 @@ class Smeasure(object):
         return dict(sm=np.mean(np.array(self.sms, dtype=_TYPE)))
 
 
-class FrameMetrics(object):
-    """MAE and S-measure of the same frames from ONE device pass per frame (what train.py:129-131 steps separately)"""
+_wfm_consts = {}
 
-    def __init__(self, alpha=0.5):
-        self.mae, self.sm = MAE(), Smeasure(alpha)
+
+def _wfm_constants(device):
+    """49 taps of matlab_style_gauss2D((7, 7), sigma=5) (metrics.py:385-393) + log(0.5)/5 (:369), float64 on the device"""
+    key = str(device)
+    if key not in _wfm_consts:
+        y, x = np.ogrid[-3:4, -3:4]
+        h = np.exp(-(x * x + y * y) / (2.0 * 5 * 5))
+        h[h < np.finfo(h.dtype).eps * h.max()] = 0
+        sumh = h.sum()
+        if sumh != 0:
+            h /= sumh
+        kc = np.concatenate([h.reshape(-1), [np.log(0.5) / 5]]).astype(np.float64)
+        _wfm_consts[key] = torch.from_numpy(kc).to(device)
+    return _wfm_consts[key]
+
+
+def wfm_sums(pred, gt):
+    """-> numpy float64 [4]: n_gt, sum Ew[gt], sum Ew[~gt] (metrics.py:347-372 on the device)"""
+    assert pred.is_cuda and gt.is_cuda and pred.dim() == 2 and pred.shape == gt.shape
+    p = pred.contiguous().float()
+    g = gt.contiguous().float()
+    H, W = p.shape
+    out = torch.empty(4, dtype=torch.float64, device=p.device)
+    ws = torch.empty(256 + 16 * H * W, dtype=torch.uint8, device=p.device)
+    _lib.call("emip_eval_wfm", p.data_ptr(), g.data_ptr(), _wfm_constants(p.device).data_ptr(), out.data_ptr(),
+              ws.data_ptr(), H, W, torch.cuda.current_stream().cuda_stream)
+    return out.cpu().numpy()
+
+
+def edt_indices(gt):
+    """scipy.ndimage.distance_transform_edt(gt == 0, return_indices=True)[1] for gt [H,W] in 0..255 -> int32 [2,H,W]"""
+    g = gt.contiguous().float()
+    H, W = g.shape
+    idx = torch.empty((2, H, W), dtype=torch.int32, device=g.device)
+    ws = torch.empty(256 + 16 * H * W, dtype=torch.uint8, device=g.device)
+    _lib.call("emip_eval_edt_indices", g.data_ptr(), idx.data_ptr(), ws.data_ptr(), H, W,
+              torch.cuda.current_stream().cuda_stream)
+    return idx
+
+
+def _wfm(s, beta=1.0):
+    """metrics.py:341-383 from the three sums"""
+    n_gt, ew_fg, ew_bg = s[0], s[1], s[2]
+    if n_gt == 0:
+        return 0
+    tpw = n_gt - ew_fg
+    fpw = ew_bg
+    r = 1 - ew_fg / n_gt
+    p = tpw / (tpw + fpw + _EPS)
+    return (1 + beta) * r * p / (r + beta * p + _EPS)
+
+
+class WeightedFmeasure(object):
+    def __init__(self, beta=1):
+        self.beta = beta
+        self.weighted_fms = []
+
+    def step(self, pred, gt):
+        self.weighted_fms.append(_wfm(wfm_sums(pred, gt), self.beta))
+
+    def get_results(self):
+        return dict(wfm=np.mean(np.array(self.weighted_fms, dtype=_TYPE)))
+
+
+class FrameMetrics(object):
+    """MAE, S-measure and weighted F-measure of the same frames (what train.py:129-131 steps separately): one reduction
+    pass for the first two, the distance-transform pipeline for the third, two small D2H copies per frame"""
+
+    def __init__(self, alpha=0.5, beta=1):
+        self.mae, self.sm, self.wfm = MAE(), Smeasure(alpha), WeightedFmeasure(beta)
 
     def step(self, pred, gt):
         s, hw = frame_sums(pred, gt)
         self.mae.maes.append(_mae(s, hw))
         self.sm.sms.append(_sm(s, hw, self.sm.alpha))
+        self.wfm.step(pred, gt)
 
     def get_results(self):
-        return dict(mae=self.mae.get_results()["mae"], sm=self.sm.get_results()["sm"])
+        return dict(mae=self.mae.get_results()["mae"], sm=self.sm.get_results()["sm"],
+                    wFm=self.wfm.get_results()["wfm"])

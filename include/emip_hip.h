@@ -387,6 +387,17 @@ int emip_postprocess_mask_f32(const float* logits, float* out, int* ws, int B, i
  * 40 doubles (emip_amd/eval_metrics.py). */
 int emip_eval_frame(const float* pred, const float* gt, double* acc, int* ws, int H, int W, void* stream);
 
+/* WeightedFmeasure.cal_wfm (eval/metrics.py:347-383; stepped per validation frame at train.py:100,131) for one frame:
+ * scipy's exact Euclidean feature transform with its nearest-index choice on ties (bwdist(gt == 0, return_indices=True)),
+ * Et, the 7x7 Gaussian EA, MIN_E_EA, the distance weighting and the sums.  pred / gt as for emip_eval_frame; kc f64 [50]
+ * on the device = the 49 taps of matlab_style_gauss2D((7,7), 5) (:385-393) then log(0.5)/5, computed by the host in float64
+ * as the reference does; out f64 [4] = n_gt, sum Ew[gt], sum Ew[~gt], unused; ws: 256 + 16*H*W bytes of scratch,
+ * 16-byte aligned.  The host finalises R, P, Q (emip_amd/eval_metrics.py) and returns 0 when n_gt == 0 (:341-342). */
+int emip_eval_wfm(const float* pred, const float* gt, const double* kc, double* out, void* ws, int H, int W,
+                  void* stream);
+/* The feature transform alone: idx int [2][H][W] (row indices, then column indices; -1 when the frame has no foreground). */
+int emip_eval_edt_indices(const float* gt, int* idx, void* ws, int H, int W, void* stream);
+
 /* Input preparation of dataset/dataset.py:257-260,76-79 on the device:
  * transforms.Resize((Ho, Wo)) on the decoded 8-bit RGB frame -- Pillow's two-pass 8-bit resampling with 22-bit
  * quantised triangle coefficients, BIT-EXACT -- then ToTensor (/255) and Normalize ((x - mean) / std) in IEEE f32.

@@ -652,3 +652,34 @@ def metric_smeasure(pred, gt, alpha=0.5):
     region = (w1 * ssim(pred[0:cy, 0:cx], gt[0:cy, 0:cx]) + w2 * ssim(pred[0:cy, cx:w], gt[0:cy, cx:w]) +
               w3 * ssim(pred[cy:h, 0:cx], gt[cy:h, 0:cx]) + w4 * ssim(pred[cy:h, cx:w], gt[cy:h, cx:w]))
     return float(max(0, alpha * obj + (1 - alpha) * region))
+
+
+def metric_wfm(pred, gt, beta=1.0, return_parts=False):
+    """WeightedFmeasure.step / cal_wfm, eval/metrics.py:338-383 (scipy's distance_transform_edt and convolve are the
+    reference's own dependencies for this metric)"""
+    import numpy as np
+    from scipy.ndimage import convolve, distance_transform_edt
+    eps = np.spacing(1)
+    pred, gt = metric_prepare(pred, gt)
+    if np.all(~gt):
+        return 0.0
+    dst, idx = distance_transform_edt(gt == 0, return_indices=True)
+    e = np.abs(pred - gt)
+    et = np.copy(e)
+    et[gt == 0] = et[idx[0][gt == 0], idx[1][gt == 0]]
+    y, x = np.ogrid[-3:4, -3:4]                                     # matlab_style_gauss2D((7, 7), sigma=5), :385-393
+    k = np.exp(-(x * x + y * y) / (2.0 * 5 * 5))
+    k[k < np.finfo(k.dtype).eps * k.max()] = 0
+    k /= k.sum()
+    ea = convolve(et, weights=k, mode="constant", cval=0)
+    min_e_ea = np.where(gt & (ea < e), ea, e)
+    b = np.where(gt == 0, 2 - np.exp(np.log(0.5) / 5 * dst), np.ones_like(gt))
+    ew = min_e_ea * b
+    tpw = np.sum(gt) - np.sum(ew[gt == 1])
+    fpw = np.sum(ew[gt == 0])
+    r = 1 - np.mean(ew[gt == 1])
+    p = tpw / (tpw + fpw + eps)
+    q = (1 + beta) * r * p / (r + beta * p + eps)
+    if return_parts:
+        return float(q), idx, et
+    return float(q)

@@ -1,4 +1,4 @@
-"""Validation metrics (eval/metrics.py MAE / Smeasure): oracle restatement and the device reductions against values the
+"""Validation metrics (eval/metrics.py MAE / Smeasure / WeightedFmeasure): oracle restatement and the device reductions against values the
 reference's own classes produced (tests/golden/metrics_micro.npz, oracle/make_golden_metrics.py)."""
 import numpy as np
 import pytest
@@ -36,6 +36,57 @@ def test_device_metrics_match_reference_values(golden):
     assert abs(b.get_results()["sm"] - np.mean(want_sm)) < 2e-5
     r = both.get_results()
     assert abs(r["mae"] - np.mean(want_mae)) < 2e-6 and abs(r["sm"] - np.mean(want_sm)) < 2e-5
+
+
+def test_oracle_wfm_matches_reference_values(golden):
+    from oracle import emip_oracle as O
+    g = golden("metrics_micro.npz")
+    for i in range(int(g["n"])):
+        assert abs(O.metric_wfm(g["pred%d" % i], g["gt%d" % i].astype(np.float32)) - float(g["wfm%d" % i])) < 1e-12
+
+
+@pytest.mark.gpu
+def test_device_wfm_matches_reference_values(golden):
+    from emip_amd.eval_metrics import FrameMetrics, WeightedFmeasure
+    g = golden("metrics_micro.npz")
+    m, both, want = WeightedFmeasure(), FrameMetrics(), []
+    for i in range(int(g["n"])):
+        p = torch.from_numpy(g["pred%d" % i]).cuda()
+        t = torch.from_numpy(g["gt%d" % i].astype(np.float32)).cuda()
+        m.step(pred=p, gt=t)
+        both.step(pred=p, gt=t)
+        want.append(float(g["wfm%d" % i]))
+        assert abs(m.weighted_fms[-1] - want[-1]) < 1e-9, (i, m.weighted_fms[-1], want[-1])
+    assert abs(m.get_results()["wfm"] - np.mean(want)) < 1e-9
+    assert abs(both.get_results()["wFm"] - np.mean(want)) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,kind", [(90, 120, "rect"), (37, 203, "points"), (270, 481, "discs"), (64, 64, "dense"),
+                                      (5, 300, "points"), (300, 3, "dense"), (720, 1280, "discs"), (40, 40, "empty")])
+def test_device_edt_indices_equal_scipy(H, W, kind):
+    """the nearest-foreground index map is bit-identical to scipy's, including its choice among equidistant pixels"""
+    from scipy.ndimage import distance_transform_edt
+    from emip_amd.eval_metrics import edt_indices
+    rs = np.random.RandomState(H * 1000 + W)
+    gt = np.zeros((H, W), bool)
+    if kind == "rect":
+        gt[H // 4:H // 2, W // 3:2 * W // 3] = True
+        gt[-3:, :4] = True
+    elif kind == "points":
+        gt = rs.rand(H, W) > 0.99
+        gt[rs.randint(H), rs.randint(W)] = True
+    elif kind == "discs":
+        yy, xx = np.mgrid[0:H, 0:W]
+        gt = ((yy - H // 2) ** 2 + (xx - W // 3) ** 2 < (H // 5) ** 2) | ((yy - H // 4) ** 2 + (xx - 3 * W // 4) ** 2 < (H // 9) ** 2)
+    elif kind == "dense":
+        gt = rs.rand(H, W) > 0.5
+    got = edt_indices(torch.from_numpy(gt.astype(np.float32) * 255).cuda()).cpu().numpy()
+    if kind == "empty":
+        assert (got == -1).all()
+        return
+    _, idx = distance_transform_edt(gt == 0, return_indices=True)
+    assert np.array_equal(got, idx)
 
 
 @pytest.mark.gpu
