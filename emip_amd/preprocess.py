@@ -3,7 +3,7 @@
 
 The decoded frame stays 8-bit RGB until it is on the device; the resize is Pillow's own two-pass integer resampling
 (bit-exact, see csrc/preprocess.hip), so predictions do not change when the host-side PIL resize is replaced.  Decoding
-(JPEG/PNG) and the training-time augmentations (rotation / colour / pepper, dataset.py:10-57) stay on the host."""
+(JPEG/PNG) stays on the host; the training-time augmentations (dataset.py:95-98) are in emip_amd/data_augment.py."""
 import math
 
 import numpy as np
@@ -76,4 +76,21 @@ def rgb_to_model_input(img_u8, size=352, mean=IMAGENET_MEAN, std=IMAGENET_STD, r
               kh.shape[1], kv.data_ptr(), bv.data_ptr(), kv.shape[1], tmp.data_ptr(), out.data_ptr(),
               u8.data_ptr() if u8 is not None else None, size, size, ctypes.addressof(m), ctypes.addressof(s),
               torch.cuda.current_stream().cuda_stream)
+    return (out, u8) if return_resized else out
+
+
+def gray_to_model_input(gt_u8, size=352, return_resized=False):
+    """gt_u8: uint8 [B,H0,W0] (or [H0,W0]) 'L' masks on the device -> f32 [B,1,size,size] = `gt_transform(gt)` of
+    dataset.py:80-82 (Resize + ToTensor), stacked; optionally also the resized u8 pixels."""
+    assert gt_u8.is_cuda and gt_u8.dtype == torch.uint8
+    x = gt_u8 if gt_u8.dim() == 3 else gt_u8.unsqueeze(0)
+    x = x.contiguous()
+    B, H0, W0 = x.shape
+    kh, bh, kv, bv = _device_tables(H0, W0, size, size, x.device)
+    tmp = torch.empty((B, H0, size), dtype=torch.uint8, device=x.device)
+    out = torch.empty((B, 1, size, size), dtype=torch.float32, device=x.device)
+    u8 = torch.empty((B, size, size), dtype=torch.uint8, device=x.device) if return_resized else None
+    _lib.call("emip_preprocess_gray", x.data_ptr(), H0 * W0, W0, B, H0, W0, kh.data_ptr(), bh.data_ptr(), kh.shape[1],
+              kv.data_ptr(), bv.data_ptr(), kv.shape[1], tmp.data_ptr(), out.data_ptr(),
+              u8.data_ptr() if u8 is not None else None, size, size, torch.cuda.current_stream().cuda_stream)
     return (out, u8) if return_resized else out

@@ -408,6 +408,26 @@ int emip_preprocess_rgb(const unsigned char* img, long img_bs, long img_rs, int 
                         const int* bh, int ksh, const int* kv, const int* bv, int ksv, unsigned char* tmp, float* out,
                         unsigned char* out_u8, int Ho, int Wo, const float* mean3, const float* std3, void* stream);
 
+/* The ground-truth transform of dataset/dataset.py:80-82 (Resize on the 'L' mask + ToTensor): the same two integer passes
+ * on one channel, then v / 255.  img u8 [B][H0][W0] -> out f32 [B][1][Ho][Wo]; out_u8 (may be NULL) u8 [B][Ho][Wo];
+ * tmp u8 [B][H0][Wo] scratch; tables as for emip_preprocess_rgb. */
+int emip_preprocess_gray(const unsigned char* img, long img_bs, long img_rs, int B, int H0, int W0, const int* kh,
+                         const int* bh, int ksh, const int* kv, const int* bv, int ksv, unsigned char* tmp, float* out,
+                         unsigned char* out_u8, int Ho, int Wo, void* stream);
+
+/* Training-time augmentation (dataset/data_augment.py:12-45, applied at dataset/dataset.py:95-98), Pillow's 8-bit
+ * arithmetic reproduced bit for bit; the random draws stay with the host and only their values are passed.
+ * emip_color_enhance: colorEnhance (:22-31) = ImageEnhance Brightness -> Contrast -> Color -> Sharpness with the four
+ *   factors; img / out u8 [H][W][3] packed RGB (distinct buffers), tmp u8 [H][W][3] scratch, lsum 8 bytes of scratch.
+ * emip_rotate_bicubic: Image.rotate(angle, BICUBIC) (:13-18) given the inverse affine matrix Image.rotate derives from the
+ *   angle (HOST pointer to 6 doubles); img / out u8 [H][W][C], C = 3 or 1.
+ * emip_scatter_u8: randomPeper (:34-45), img[offs[i]] = vals[i] for n distinct offsets. */
+int emip_color_enhance(const unsigned char* img, unsigned char* out, unsigned char* tmp, void* lsum, int H, int W,
+                       float f_bright, float f_contrast, float f_color, float f_sharp, void* stream);
+int emip_rotate_bicubic(const unsigned char* img, unsigned char* out, int H, int W, int C, const double* matrix6,
+                        void* stream);
+int emip_scatter_u8(unsigned char* img, const int* offs, const unsigned char* vals, int n, void* stream);
+
 /* ---- optimizer ----------------------------------------------------------------------------------- */
 
 /* Element-wise gradient clamp to +-clip (utils/utils.py:1-11; clip <= 0 disables) fused with one AdamW step

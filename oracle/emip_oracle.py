@@ -683,3 +683,68 @@ def metric_wfm(pred, gt, beta=1.0, return_parts=False):
     if return_parts:
         return float(q), idx, et
     return float(q)
+
+
+# ---- training-time augmentation (dataset/data_augment.py:12-45, dataset/dataset.py:76-103) ------------------------------
+# The reference's functions are thin calls into Pillow (its own dependency, present in the image); the restatement keeps
+# them as such, on numpy uint8 arrays, consuming `random` / `np.random` in the reference's order.  The reference module
+# itself is not importable here (it imports cv2, which the image lacks), so these are pinned by Pillow directly.
+
+def aug_random_rotation(img1, img2, label):
+    """randomRotation, data_augment.py:12-19"""
+    import random
+    import numpy as np
+    from PIL import Image
+    if random.random() > 0.8:
+        random_angle = np.random.randint(-15, 15)
+        img1, img2, label = (np.asarray(Image.fromarray(a).rotate(random_angle, Image.BICUBIC)) for a in (img1, img2, label))
+    return img1, img2, label
+
+
+def aug_color_enhance(image, factors=None):
+    """colorEnhance, data_augment.py:22-31 (factors=None draws them like the reference)"""
+    import random
+    import numpy as np
+    from PIL import Image, ImageEnhance
+    im = Image.fromarray(image, "RGB")
+    f = factors
+    b = random.randint(5, 15) / 10.0 if f is None else f[0]
+    im = ImageEnhance.Brightness(im).enhance(b)
+    c = random.randint(5, 15) / 10.0 if f is None else f[1]
+    im = ImageEnhance.Contrast(im).enhance(c)
+    k = random.randint(0, 20) / 10.0 if f is None else f[2]
+    im = ImageEnhance.Color(im).enhance(k)
+    s = random.randint(0, 30) / 10.0 if f is None else f[3]
+    im = ImageEnhance.Sharpness(im).enhance(s)
+    return np.asarray(im)
+
+
+def aug_random_peper(img):
+    """randomPeper, data_augment.py:34-45"""
+    import random
+    import numpy as np
+    img = np.array(img)
+    noise_num = int(0.0015 * img.shape[0] * img.shape[1])
+    for _ in range(noise_num):
+        rx = random.randint(0, img.shape[0] - 1)
+        ry = random.randint(0, img.shape[1] - 1)
+        img[rx, ry] = 0 if random.randint(0, 1) == 0 else 255
+    return img
+
+
+def preprocess_gray(gt_u8, size=352):
+    """gt_transform, dataset/dataset.py:80-82: Resize((size, size)) on the 'L' image + ToTensor -> (f32 [1,S,S], u8 [S,S])"""
+    import numpy as np
+    import torch
+    from PIL import Image
+    r = np.asarray(Image.fromarray(gt_u8, "L").resize((size, size), Image.BILINEAR))
+    return (torch.from_numpy(r.astype(np.float32)) / 255).unsqueeze(0), r
+
+
+def train_sample(image1, image2, gt, size=352):
+    """ObjDataset.__getitem__ after decoding, dataset/dataset.py:94-103"""
+    image1, image2, gt = aug_random_rotation(image1, image2, gt)
+    image1 = aug_color_enhance(image1)
+    image2 = aug_color_enhance(image2)
+    gt = aug_random_peper(gt)
+    return preprocess_rgb(image1, size)[0], preprocess_rgb(image2, size)[0], preprocess_gray(gt, size)[0]
