@@ -313,8 +313,10 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 #pragma unroll
         for (int j = 0; j < VEC; ++j) aw[t][j] = 0.f;
     const int y0 = chunk * rows_per_block, y1 = min(H, y0 + rows_per_block);
-    for (int y = y0; y < y1; ++y) {
-        for (int x = pl; x < Wd; x += NPL) {
+    const int npix = (y1 - y0) * Wd;                 // the chunk's pixels, flattened so that every pixel lane has work
+    {
+        for (int p = pl; p < npix; p += NPL) {
+            const int y = y0 + p / Wd, x = p % Wd;
             const uint4 dv = mask4(*reinterpret_cast<const uint4*>(DY + ((b * H + y) * (long)Wd + x) * lddy + cc), cok);
             float dy[VEC];
 #pragma unroll
@@ -644,6 +646,12 @@ extern "C" int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy,
 }
 
 // dW f32 [9][C] and db f32 [C] (may be NULL) are ACCUMULATED into
+static int g_dww_chunks = 0;
+extern "C" int emip_debug_set_dww(int chunks) {
+    g_dww_chunks = chunks;
+    return EMIP_OK;
+}
+
 extern "C" int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, long lddy, float* dW, float* db, int B,
                                     int H, int Wd, int C, int dtype, void* stream) {
     REQ_DT(dtype);
@@ -651,8 +659,14 @@ extern "C" int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, lon
     const int vec = dtype == EMIP_F32 ? 4 : 8;
     EMIP_REQUIRE(C % vec == 0 && ldx % vec == 0 && lddy % vec == 0 && ldx >= C && lddy >= C);
     EMIP_REQUIRE((((uintptr_t)X) & 15) == 0 && (((uintptr_t)DY) & 15) == 0);
-    const int rpb = 4;
-    dim3 grid(((C + 63) / 64) * ((H + rpb - 1) / rpb), B);
+    // rows per workgroup: about 2048 workgroups in all (8 per CU), so that the per-workgroup tail (80 shuffle-reduced sums,
+    // 640 atomics) is spread over as many pixels as the grid allows
+    const int cgroups = (C + 63) / 64;
+    int chunks = (int)((2048 + (long)cgroups * B - 1) / ((long)cgroups * B));
+    if (g_dww_chunks > 0) chunks = g_dww_chunks;
+    chunks = chunks < 1 ? 1 : (chunks > H ? H : chunks);
+    const int rpb = (H + chunks - 1) / chunks;
+    dim3 grid(cgroups * ((H + rpb - 1) / rpb), B);
     DISPATCH_T(dtype, hipLaunchKernelGGL(dwconv_wgrad_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, (const T*)X,
                                          ldx, (const T*)DY, lddy, dW, db, B, H, Wd, C, rpb));
     return emip_launch_status();

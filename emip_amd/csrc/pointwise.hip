@@ -271,6 +271,174 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
 }
 
+// LayerNorm backward, the wide variant used whenever C % 8 == 0: 16-byte loads, U row groups in flight per wave, all four
+// row sums (x, x^2, g, g x with g = dy gamma) from ONE pass and one joint shuffle reduction
+//   mean = Sx / C,  var = Sx2 / C - mean^2,  mean_c(g xh) = rstd (Sgx - mean Sg) / C
+// and 1024-thread workgroups, at most one per CU: measured on MI355X, same-address f32 atomics retire at ~25 ns each
+// whatever the channel count (tools/atomic_bench.hip), so the dgamma / dbeta tail costs 25 ns x the number of workgroups;
+// 256 large workgroups keep it at ~7 us where 1024 small ones paid 26 us.
+template <typename T>
+__device__ __forceinline__ void store8(T* p, const float (&v)[8]);
+template <>
+__device__ __forceinline__ void store8<float>(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <>
+__device__ __forceinline__ void store8<bf16_t>(bf16_t* p, const float (&v)[8]) {
+    bf16x4 a, b;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        a[k] = (bf16_t)v[k];
+        b[k] = (bf16_t)v[4 + k];
+    }
+    *reinterpret_cast<bf16x4*>(p) = a;
+    *reinterpret_cast<bf16x4*>(p + 4) = b;
+}
+
+// eight channels as loaded (bf16 stays packed in 4 registers until the row's turn comes)
+template <typename T>
+struct Raw8;
+template <>
+struct Raw8<float> {
+    float4 a, b;
+    __device__ __forceinline__ void load(const float* p) {
+        a = *reinterpret_cast<const float4*>(p);
+        b = *reinterpret_cast<const float4*>(p + 4);
+    }
+    __device__ __forceinline__ void unpack(float (&v)[8], float keep) const {
+        v[0] = a.x * keep; v[1] = a.y * keep; v[2] = a.z * keep; v[3] = a.w * keep;
+        v[4] = b.x * keep; v[5] = b.y * keep; v[6] = b.z * keep; v[7] = b.w * keep;
+    }
+};
+template <>
+struct Raw8<bf16_t> {
+    uint4 t;
+    __device__ __forceinline__ void load(const bf16_t* p) { t = *reinterpret_cast<const uint4*>(p); }
+    __device__ __forceinline__ void unpack(float (&v)[8], float keep) const {
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            v[2 * k] = __uint_as_float(w[k] << 16) * keep;
+            v[2 * k + 1] = __uint_as_float(w[k] & 0xFFFF0000u) * keep;
+        }
+    }
+};
+
+template <typename T, int U>
+__global__ __launch_bounds__(1024) void layernorm_bwd_wide_kernel(const T* __restrict__ X, long ldx,
+                                                                  const T* __restrict__ DY, long lddy,
+                                                                  T* __restrict__ DX, long lddx,
+                                                                  const float* __restrict__ gamma,
+                                                                  float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                                  long M, int C, float eps, int lpr_log2, int nparts,
+                                                                  long part_stride) {
+    extern __shared__ float red[];   // [2][C]
+    const int LPR = 1 << lpr_log2;                       // lanes per row, two 8-channel vectors per lane
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1), rsub = lane >> lpr_log2;
+    const int rpw = 64 >> lpr_log2;                      // rows per wave and group
+    const int nv8 = C >> 3;
+    const int nwave = blockDim.x >> 6;
+    const long wave_global = (long)blockIdx.x * nwave + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * nwave * rpw * U;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    float gam[2][8], ag[2][8], ab[2][8];
+    bool act[2];
+    int vcl[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int vi = sub + i * LPR;
+        act[i] = vi < nv8;
+        vcl[i] = min(vi, nv8 - 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gam[i][j] = act[i] ? gamma[vcl[i] + j] : 0.f;
+            ag[i][j] = ab[i][j] = 0.f;
+        }
+    }
+    const float invC = 1.f / (float)C;
+    for (long row0 = wave_global * rpw * U; row0 < M; row0 += stride) {
+        Raw8<T> rx[U][2], rdy[U][2];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = row0 + u * rpw + rsub;
+            const long rowc = row < M ? row : M - 1;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                rx[u][i].load(X + rowc * ldx + vcl[i]);
+                rdy[u][i].load(DY + rowc * lddy + vcl[i]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long row = row0 + u * rpw + rsub;
+            float x[2][8], dy[2][8];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float keep = (row < M && act[i]) ? 1.f : 0.f;       // rows past the end / lanes past C contribute zeros
+                rx[u][i].unpack(x[i], keep);
+                rdy[u][i].unpack(dy[i], keep);
+            }
+            float s = 0.f, s2 = 0.f, sg = 0.f, sgx = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xv = x[i][j], g = dy[i][j] * gam[i][j];
+                    s += xv;
+                    s2 += xv * xv;
+                    sg += g;
+                    sgx += g * xv;
+                }
+            for (int o = LPR >> 1; o > 0; o >>= 1) {
+                s += __shfl_xor(s, o);
+                s2 += __shfl_xor(s2, o);
+                sg += __shfl_xor(sg, o);
+                sgx += __shfl_xor(sgx, o);
+            }
+            const float mean = s * invC;
+            const float rstd = rsqrtf(fmaxf(s2 * invC - mean * mean, 0.f) + eps);
+            const float mg = sg * invC, mgx = rstd * (sgx - mean * sg) * invC;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float o8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float xh = (x[i][j] - mean) * rstd;       // padded lanes: dy = 0, so nothing is accumulated
+                    ag[i][j] += dy[i][j] * xh;
+                    ab[i][j] += dy[i][j];
+                    o8[j] = rstd * (dy[i][j] * gam[i][j] - mg - xh * mgx);
+                }
+                if (row < M && act[i]) store8<T>(DX + row * lddx + vcl[i], o8);
+            }
+        }
+    }
+    // the wave's row groups hold partial dgamma / dbeta for the same channels: combine them with shuffles, then one LDS
+    // atomic per channel and wave, then one global atomic per channel and workgroup
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = ag[i][j], b = ab[i][j];
+            for (int o = 32; o >= LPR; o >>= 1) {
+                a += __shfl_xor(a, o);
+                b += __shfl_xor(b, o);
+            }
+            if (rsub == 0 && act[i]) {
+                atomicAdd(&red[vcl[i] + j], a);
+                atomicAdd(&red[C + vcl[i] + j], b);
+            }
+        }
+    __syncthreads();
+    const long po = (long)(blockIdx.x % nparts) * part_stride;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        atomicAdd(dgamma + po + i, red[i]);
+        atomicAdd(dbeta + po + i, red[C + i]);
+    }
+}
+
 // ----------------------------------------------------------------------------
 // Depthwise 3x3, stride 1, zero pad 1, channels-last.  Weights [9][C] f32.
 // GATED: X has 2*Ch channels, Y[c] = gelu(dw(X)[c]) * dw(X)[Ch + c] for c < Ch and 0 for
@@ -805,6 +973,12 @@ extern "C" int emip_rows_finalize(const float* A, long lda, void* Y, long ldy, f
     return emip_launch_status();
 }
 
+static int g_lnb_wide = 1;
+extern "C" int emip_debug_set_lnb(int wide) {
+    g_lnb_wide = wide;
+    return EMIP_OK;
+}
+
 // dgamma / dbeta are ACCUMULATED into (the caller zero-fills them, or keeps accumulating across micro-batches)
 extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx,
                                   const float* gamma, float* dgamma, float* dbeta, int nparts, long part_stride, long M,
@@ -813,6 +987,28 @@ extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long 
     EMIP_REQUIRE(X && DY && DX && gamma && dgamma && dbeta && M > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
     EMIP_REQUIRE(nparts >= 1 && (nparts == 1 || part_stride >= C));
     EMIP_REQUIRE((ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C && lddy >= C && lddx >= C);
+    if (g_lnb_wide && (C & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && (lddx & 7) == 0 && aligned16(X) && aligned16(DY) &&
+        aligned16(DX)) {
+        const int U = 1;
+        const int nv8 = C >> 3;
+        int lg = 0;
+        while ((2 << lg) < nv8 && lg < 6) ++lg;
+        const long rows_per_wave = (64 >> lg) * U;
+        const long waves = (M + rows_per_wave - 1) / rows_per_wave;
+        const int threads = waves >= 256 * 16 ? 1024 : (waves >= 256 * 8 ? 512 : 256);
+        long blocks = (waves + threads / 64 - 1) / (threads / 64);
+        if (blocks > 256) blocks = 256;
+        if (dtype == EMIP_F32) {
+            hipLaunchKernelGGL((layernorm_bwd_wide_kernel<float, 1>), dim3((unsigned)blocks), dim3(threads),
+                               2 * C * sizeof(float), (hipStream_t)stream, (const float*)X, ldx, (const float*)DY, lddy,
+                               (float*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg, nparts, part_stride);
+        } else {
+            hipLaunchKernelGGL((layernorm_bwd_wide_kernel<bf16_t, 1>), dim3((unsigned)blocks), dim3(threads),
+                               2 * C * sizeof(float), (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)DY, lddy,
+                               (bf16_t*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg, nparts, part_stride);
+        }
+        return emip_launch_status();
+    }
     const int nv = C >> 2;
     int lg = 0;
     while ((1 << lg) < nv && lg < 6) ++lg;

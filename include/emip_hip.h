@@ -258,6 +258,7 @@ int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B, int H, in
 int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx, const float* gamma,
                        float* dgamma, float* dbeta, int nparts, long part_stride, long M, int C, float eps, int dtype,
                        void* stream);
+int emip_debug_set_lnb(int wide);   /* calibration: 0 = the narrow LayerNorm-backward kernel */
 
 /* Backward of the softmax attentions (lib/pvt_v2.py:113-121; gmflow/transformer.py:46-105,503-533; matching.py:8-41).
  * Row softmax of the first L columns (columns L..ld-1 are written as 0): Y = softmax(X*scale + mask), mask = -100
@@ -290,6 +291,7 @@ int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy, void* DZ, 
 /* Depthwise 3x3 weight/bias gradient (lib/pvt_v2.py:316-327; PromptInteract.py q/kv/ffn dwconv), ACCUMULATED into dW f32 [9][C] and db f32 [C] (db may be NULL). */
 int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, long lddy, float* dW, float* db, int B, int H, int Wd,
                          int C, int dtype, void* stream);
+int emip_debug_set_dww(int chunks);   /* calibration: row chunks per image of the depthwise weight gradient (0 = auto) */
 
 /* Train-mode BatchNorm2d (+ReLU when OUT != NULL) backward (ConvBR, create_backbone.py:22-42; conv_corr, model.py:59-62).  X: pre-BN conv output, OUT: the forward output,
  * fsums: the forward's emip_chan_stats (groups = 1); dgamma/dbeta accumulated; ws: f32 [2*C]. */

@@ -1,11 +1,12 @@
-"""Calibration: LayerNorm backward, plain accumulation (1024 workgroups) against 32 partial accumulators (4096)."""
+"""Calibration: LayerNorm backward, the narrow kernel (8-byte loads, 1024 small workgroups) against the wide one (16-byte
+loads, one-pass row sums, <= 256 workgroups of 1024 threads)."""
 import os
 import sys
 
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from emip_amd import ops  # noqa: E402
+from emip_amd import _lib, ops  # noqa: E402
 
 
 def timeit(fn, iters=30):
@@ -22,11 +23,15 @@ def timeit(fn, iters=30):
 
 
 dev, dt = "cuda:0", torch.bfloat16
-for M, C in [(30976, 320), (123904, 128), (495616, 64), (7744, 512)]:
+for M, C in [(30976, 320), (123904, 128), (495616, 64), (7744, 512), (123904, 256), (7744, 320)]:
     x = torch.randn(M, C, device=dev).to(dt)
     dy = torch.randn(M, C, device=dev).to(dt)
     g = torch.ones(C, device=dev)
     dg = torch.zeros(C, device=dev)
     db = torch.zeros(C, device=dev)
-    print(M, C, "plain %.1f us | partial accumulators (incl. fill + column sum) %.1f us" % (
-        timeit(lambda: ops.layernorm_bwd(x, dy, g, 1e-6, dg, db)), timeit(lambda: ops.layernorm_bwd_fresh(x, dy, g, 1e-6))))
+    _lib.call("emip_debug_set_lnb", 0)
+    t0 = timeit(lambda: ops.layernorm_bwd(x, dy, g, 1e-6, dg, db))
+    _lib.call("emip_debug_set_lnb", 1)
+    t1 = timeit(lambda: ops.layernorm_bwd(x, dy, g, 1e-6, dg, db))
+    gb = 3 * M * C * 2 / 1e3
+    print(M, C, "narrow %.1f us (%.0f GB/s) | wide %.1f us (%.0f GB/s)" % (t0, gb / t0, t1, gb / t1))
