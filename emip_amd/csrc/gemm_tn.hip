@@ -240,10 +240,16 @@ int launch_tn(TnArgs& a, int batch, int dtype, hipStream_t s) {
     if (splits > 65535) splits = 65535;
     a.m_per_split = ((a.M + splits - 1) / splits + bms - 1) / bms * bms;
     splits = (a.M + a.m_per_split - 1) / a.m_per_split;
+    const size_t c_floats = (size_t)a.N * a.K * batch, db_floats = a.db ? (size_t)a.N * batch : 0;
+    bool db_cleared = a.db == nullptr || a.prezeroed;
     if (splits > 1 && !a.prezeroed) {   // partial tiles are combined with atomics: clear the output first (dense rows only)
         if (a.ldc != a.K || (batch > 1 && a.bsC != (long)a.N * a.K)) return EMIP_E_INVALID;
-        if (emip_zero_async(a.C, sizeof(float) * (size_t)a.N * a.K * batch, s) != EMIP_OK) return EMIP_E_LAUNCH;
+        // a bias gradient placed right behind the weight gradient is cleared by the same launch
+        const bool joint = !db_cleared && a.db == a.C + c_floats;
+        if (emip_zero_async(a.C, sizeof(float) * (c_floats + (joint ? db_floats : 0)), s) != EMIP_OK) return EMIP_E_LAUNCH;
+        db_cleared = db_cleared || joint;
     }
+    if (!db_cleared && emip_zero_async(a.db, sizeof(float) * db_floats, s) != EMIP_OK) return EMIP_E_LAUNCH;
     dim3 grid((unsigned)(a.tiles_n * a.tiles_k), (unsigned)splits, (unsigned)batch);
     if (dtype == EMIP_F32) hipLaunchKernelGGL((gemm_tn_kernel<float, CONV>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, CONV>), grid, dim3(256), 0, s, a);
@@ -256,8 +262,9 @@ extern "C" int emip_gemm_tn(const void* A, const void* B, float* C, long M, int 
     return emip_gemm_tn_bias(A, B, C, nullptr, M, N, K, lda, ldb, ldc, batch, bsA, bsB, bsC, dtype, stream);
 }
 
-// emip_gemm_tn that also accumulates db[n] += sum_m A[m][n] (the bias gradient of the same Linear; db f32 [batch][N], zero
-// beforehand): the dY tile is already being staged, so the separate column-sum pass over dY disappears.
+// emip_gemm_tn that also produces db[n] = sum_m A[m][n] (the bias gradient of the same Linear; db f32 [batch][N], cleared by
+// this call -- in the same zero launch as C when it sits right behind it): the dY tile is already being staged, so the
+// separate column-sum pass over dY disappears.
 extern "C" int emip_gemm_tn_bias(const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda,
                                  long ldb, long ldc, int batch, long bsA, long bsB, long bsC, int dtype, void* stream) {
     EMIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0 && batch > 0 && batch < 65536);

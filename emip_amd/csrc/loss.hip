@@ -78,7 +78,8 @@ __global__ __launch_bounds__(256) void occ_corner_kernel(const float* __restrict
             const long long ii = (long long)id[k];
             if (indices) indices[(b * 4 + k) * n + pix] = ii;
             if (weights) weights[(b * 4 + k) * n + pix] = wv[k];
-            if (cmap) atomicAdd(cmap + b * n + ii, wv[k]);
+            if (cmap && wv[k] != 0.f) atomicAdd(cmap + b * n + ii, wv[k]);   // clamped (out-of-frame) corners carry weight 0:
+                                                                              // skipping them avoids piling atomics on the border
         }
     }
 }

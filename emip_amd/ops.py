@@ -409,11 +409,12 @@ def gemm_tn(a, b, with_colsum=False):
     M, N, lda = rows(a)
     Mb, K, ldb = rows(b)
     assert M == Mb and a.dtype == b.dtype
-    c = torch.empty((N, K), dtype=torch.float32, device=a.device)
     if not with_colsum:
+        c = torch.empty((N, K), dtype=torch.float32, device=a.device)
         _lib.call("emip_gemm_tn", _p(a), _p(b), _p(c), M, N, K, lda, ldb, K, 1, 0, 0, 0, dt_code(a.dtype), _stream())
         return c
-    db = torch.zeros(N, dtype=torch.float32, device=a.device)
+    buf = torch.empty(N * K + N, dtype=torch.float32, device=a.device)     # db right behind c: one clearing launch for both
+    c, db = buf[:N * K].view(N, K), buf[N * K:]
     _lib.call("emip_gemm_tn_bias", _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, 1, 0, 0, 0, dt_code(a.dtype),
               _stream())
     return c, db

@@ -242,8 +242,8 @@ int emip_photometric_loss(const float* im, const float* rec, const float* mask, 
 int emip_gemm_tn(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc, int batch,
                  long bsA, long bsB, long bsC, int dtype, void* stream);
 
-/* emip_gemm_tn that also accumulates the bias gradient db[n] += sum_m A[m][n] (f32 [batch][N], zero beforehand) from the dY
- * tiles it stages anyway. */
+/* emip_gemm_tn that also produces the bias gradient db[n] = sum_m A[m][n] (f32 [batch][N]; cleared by this call, in the
+ * same zero launch as C when db == C + batch*N*K) from the dY tiles it stages anyway. */
 int emip_gemm_tn_bias(const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda, long ldb, long ldc,
                       int batch, long bsA, long bsB, long bsC, int dtype, void* stream);
 
