@@ -322,6 +322,8 @@ def main():
     if os.environ.get("EMIP_KV_SPLIT"):
         from emip_amd import ops
         ops.KV_SPLIT = os.environ["EMIP_KV_SPLIT"] != "0"
+        if int(os.environ["EMIP_KV_SPLIT"]) > 1:
+            ops.KV_SPLIT_MIN_KEYS = int(os.environ["EMIP_KV_SPLIT"])
     if args.workload == "train":
         return main_train(args)
     if args.workload == "long":

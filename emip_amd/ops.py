@@ -180,7 +180,8 @@ def layernorm(x, gamma, beta, eps, out=None, res=None, out_stats=None):
     return out
 
 
-KV_SPLIT = True      # emip_attention_splitkv for >= 1024 keys on grids of < 256 workgroups
+KV_SPLIT = True      # emip_attention_splitkv for >= KV_SPLIT_MIN_KEYS keys on grids of < 256 workgroups
+KV_SPLIT_MIN_KEYS = 1024
 
 
 def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo,
@@ -194,7 +195,7 @@ def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_
     wgs = ((Lq + 127) // 128) * heads * batch * nwin
     if ksplit is not None:
         pass
-    elif not (KV_SPLIT and Lk >= 1024 and wgs < 256):
+    elif not (KV_SPLIT and Lk >= KV_SPLIT_MIN_KEYS and wgs < 256):
         ksplit = 1
     else:
         ksplit = max(1, min(ntile // 4, (256 + wgs - 1) // wgs, 32))
