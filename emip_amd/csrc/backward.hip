@@ -280,11 +280,32 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const T* __restrict__ Z, 
         Vec4<T>::load(DY + row * lddy + vi * 4, dy);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float cdf = 0.5f * (1.f + erff(z[j] * 0.70710678118654752440f));
-            const float pdf = 0.3989422804014327f * expf(-0.5f * z[j] * z[j]);
-            o[j] = dy[j] * (cdf + z[j] * pdf);
+            o[j] = dy[j] * gelu_grad_t<T>(z[j]);
         }
         Vec4<T>::store(DZ + row * lddz + vi * 4, o);
+    }
+}
+
+// the same with 16-byte accesses (C a multiple of 16 / sizeof(T), 16-byte aligned rows)
+template <typename T>
+__global__ __launch_bounds__(256) void gelu_bwd_wide_kernel(const T* __restrict__ Z, long ldz, const T* __restrict__ DY,
+                                                            long lddy, T* __restrict__ DZ, long lddz, long M, int C) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int nv = C / VEC;
+    const long total = M * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int vi = (int)(idx % nv);
+        const long row = idx / nv;
+        const uint4 zv = *reinterpret_cast<const uint4*>(Z + row * ldz + vi * VEC);
+        const uint4 dv = *reinterpret_cast<const uint4*>(DY + row * lddy + vi * VEC);
+        uint4 ov;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float z = to_f32<T>(reinterpret_cast<const T*>(&zv)[j]);
+            const float dy = to_f32<T>(reinterpret_cast<const T*>(&dv)[j]);
+            reinterpret_cast<T*>(&ov)[j] = from_f32<T>(dy * gelu_grad_t<T>(z));
+        }
+        *reinterpret_cast<uint4*>(DZ + row * lddz + vi * VEC) = ov;
     }
 }
 
@@ -640,6 +661,14 @@ extern "C" int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy,
     REQ_DT(dtype);
     EMIP_REQUIRE(Z && DY && DZ && M > 0 && C >= 4 && (C & 3) == 0 && (ldz & 3) == 0 && (lddy & 3) == 0 &&
                  (lddz & 3) == 0 && ldz >= C && lddy >= C && lddz >= C);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    if (C % vec == 0 && ldz % vec == 0 && lddy % vec == 0 && lddz % vec == 0 && ((((uintptr_t)Z) | ((uintptr_t)DY) |
+                                                                                   ((uintptr_t)DZ)) & 15) == 0) {
+        DISPATCH_T(dtype, hipLaunchKernelGGL(gelu_bwd_wide_kernel<T>, dim3(grid_for(M * (C / vec), 256)), dim3(256), 0,
+                                             (hipStream_t)stream, (const T*)Z, ldz, (const T*)DY, lddy, (T*)DZ, lddz, M,
+                                             C));
+        return emip_launch_status();
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(gelu_bwd_kernel<T>, dim3(grid_for(M * (C >> 2), 256)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)Z, ldz, (const T*)DY, lddy, (T*)DZ, lddz, M, C));
     return emip_launch_status();

@@ -67,6 +67,29 @@ __device__ __forceinline__ float gelu_t<bf16_t>(float x) {
     return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 
+// d gelu(z) / dz = Phi(z) + z phi(z).  bf16 mode shares ONE exp between the Abramowitz-Stegun erf and the density
+// (both need e^{-z^2/2}); f32 parity mode keeps libm's erff / expf.
+template <typename T>
+__device__ __forceinline__ float gelu_grad_t(float z);
+template <>
+__device__ __forceinline__ float gelu_grad_t<float>(float z) {
+    const float cdf = 0.5f * (1.f + erff(z * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * expf(-0.5f * z * z);
+    return cdf + z * pdf;
+}
+template <>
+__device__ __forceinline__ float gelu_grad_t<bf16_t>(float z) {
+    const float az = fabsf(z) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * z * z);      // e^{-z^2/2}
+    const float cdf = 0.5f * (1.f + copysignf(fmaf(-p * t, e, 1.0f), z));
+    return fmaf(z * 0.3989422804014327f, e, cdf);
+}
+
 // 4 consecutive elements as a vector (16 B for f32, 8 B for bf16)
 template <typename T>
 struct Vec4;

@@ -36,3 +36,9 @@ for H, C in [(88, 256), (44, 512), (22, 1280), (11, 2048), (44, 680)]:
         res.append("%d: %.0f us" % (chunks, t))
     _lib.call("emip_debug_set_dww", 0)
     print("dwconv wgrad B=%d %dx%d C=%d (%.0f MB) chunks -> %s" % (B, H, H, C, gb / 1e3, " | ".join(res)))
+
+for M, C in [(64 * 484, 1280), (64 * 1936, 512), (64 * 7744, 256)]:
+    z = torch.randn(M, C, device=dev).to(dt)
+    dy = torch.randn(M, C, device=dev).to(dt)
+    t = timeit(lambda: ops.gelu_bwd(z, dy))
+    print("gelu_bwd %d x %d: %.1f us (%.0f GB/s)" % (M, C, t, 3 * M * C * 2 / 1e3 / t))
