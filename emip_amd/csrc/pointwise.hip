@@ -699,6 +699,59 @@ __global__ __launch_bounds__(256) void chan_norm_apply_kernel(const T* __restric
     }
 }
 
+// The same with one channel vector per thread for the whole launch: mean / rstd (float64 division and square root) are
+// evaluated once per thread instead of once per element -- the element-wise form above spent its time in f64 VALU work --
+// and rows are read 16 bytes per lane.  grid (row chunks, groups); same operation order per element as above.
+template <typename T>
+__global__ __launch_bounds__(256) void chan_norm_apply_wide_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y,
+                                                                   long ldy, const T* __restrict__ R, long ldr,
+                                                                   const double* __restrict__ sums,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, long rows, int C,
+                                                                   float eps, int relu_inner, int relu_outer) {
+    constexpr int VEC = 16 / sizeof(T);
+    __shared__ float s_mean[1024], s_rstd[1024];
+    const int nv = C / VEC, rl = 256 / nv;
+    const long g = blockIdx.y;
+    for (int c = threadIdx.x; c < C; c += 256) {               // one channel per thread: the float64 part, once per workgroup
+        const double m = sums[(g * C + c) * 2] / (double)rows;
+        const double var = fmax(sums[(g * C + c) * 2 + 1] / (double)rows - m * m, 0.0);
+        s_mean[c] = (float)m;
+        s_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    if ((int)threadIdx.x >= nv * rl) return;
+    const int vi = threadIdx.x % nv, lr = threadIdx.x / nv;
+    float mean[VEC], rstd[VEC], ga[VEC], be[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+        const int c = vi * VEC + j;
+        mean[j] = s_mean[c];
+        rstd[j] = s_rstd[c];
+        ga[j] = gamma ? gamma[c] : 1.f;
+        be[j] = gamma ? beta[c] : 0.f;
+    }
+    const long rpb = (rows + gridDim.x - 1) / gridDim.x;
+    const long r0 = (long)blockIdx.x * rpb, r1 = min(rows, r0 + rpb);
+    for (long r = r0 + lr; r < r1; r += rl) {
+        const long row = g * rows + r;
+        const uint4 xv = *reinterpret_cast<const uint4*>(X + row * ldx + vi * VEC);
+        uint4 rv = xv;
+        if (R) rv = *reinterpret_cast<const uint4*>(R + row * ldr + vi * VEC);
+        uint4 ov;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            float t = (to_f32<T>(reinterpret_cast<const T*>(&xv)[j]) - mean[j]) * rstd[j];
+            if (gamma) t = t * ga[j] + be[j];
+            if (relu_inner) t = fmaxf(t, 0.f);
+            if (R) t += to_f32<T>(reinterpret_cast<const T*>(&rv)[j]);
+            if (relu_outer) t = fmaxf(t, 0.f);
+            reinterpret_cast<T*>(&ov)[j] = from_f32<T>(t);
+        }
+        *reinterpret_cast<uint4*>(Y + row * ldy + vi * VEC) = ov;
+    }
+}
+
 // ----------------------------------------------------------------------------
 // Bilinear resize of a channels-last tensor.  align_corners=1: src = dst*(in-1)/(out-1);
 // align_corners=0: src = max((dst+0.5)*in/out-0.5, 0).  Index/weight arithmetic in f32
@@ -1087,6 +1140,19 @@ extern "C" int emip_chan_norm_apply(const void* X, long ldx, void* Y, long ldy, 
     EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
     EMIP_REQUIRE((gamma == nullptr) == (beta == nullptr));
     if (R) EMIP_REQUIRE((ldr & 3) == 0 && ldr >= C);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    if (C % vec == 0 && C / vec <= 256 && C <= 1024 && ldx % vec == 0 && ldy % vec == 0 && (!R || ldr % vec == 0) && aligned16(X) &&
+        aligned16(Y) && (!R || aligned16(R)) && groups < 65536) {
+        const int rl = 256 / (C / vec);
+        long chunks = (2048 + groups - 1) / groups;                    // about 2048 workgroups, at least 4 rows per thread
+        const long max_chunks = (rows + 4L * rl - 1) / (4L * rl);
+        if (chunks > max_chunks) chunks = max_chunks;
+        if (chunks < 1) chunks = 1;
+        DISPATCH_T(dtype, hipLaunchKernelGGL(chan_norm_apply_wide_kernel<T>, dim3((unsigned)chunks, (unsigned)groups),
+                                             dim3(256), 0, (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, (const T*)R,
+                                             ldr, sums, gamma, beta, rows, C, eps, relu_inner, relu_outer));
+        return emip_launch_status();
+    }
     const long total = groups * rows * (C >> 2);
     DISPATCH_T(dtype, hipLaunchKernelGGL(chan_norm_apply_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, (const T*)R, ldr, sums,

@@ -38,7 +38,7 @@ _lib.load()
 if os.environ.get("DEEP") is not None:
     _lib.call("emip_debug_set", 6, int(os.environ["DEEP"]))
 dev, dt = "cuda:0", torch.bfloat16
-for B in (8, 32):
+for B in (int(b) for b in os.environ.get("BATCHES", "8,32").split(",")):
     for H, Cin, Cout, k, s, p in [(88, 64, 64, 8, 8, 0), (44, 128, 128, 4, 4, 0), (22, 320, 320, 2, 2, 0), (88, 64, 128, 3, 2, 1),
                                   (44, 128, 320, 3, 2, 1), (22, 320, 512, 3, 2, 1), (176, 64, 64, 3, 1, 1), (88, 96, 96, 3, 1, 1),
                                   (44, 128, 128, 3, 1, 1), (44, 128, 32, 3, 1, 1), (11, 512, 32, 3, 1, 1)]:

@@ -42,3 +42,10 @@ for M, C in [(64 * 484, 1280), (64 * 1936, 512), (64 * 7744, 256)]:
     dy = torch.randn(M, C, device=dev).to(dt)
     t = timeit(lambda: ops.gelu_bwd(z, dy))
     print("gelu_bwd %d x %d: %.1f us (%.0f GB/s)" % (M, C, t, 3 * M * C * 2 / 1e3 / t))
+
+for B, H, C in [(8, 176, 64), (8, 88, 96), (8, 44, 128), (64, 176, 64)]:
+    x = torch.randn(B, H, H, C, device=dev).to(dt)
+    r = torch.randn(B, H, H, C, device=dev).to(dt)
+    sums = ops.chan_stats(x, B)
+    t = timeit(lambda: ops.chan_norm_apply(x, sums, B, 1e-5, True, True, res=r))
+    print("instance-norm apply B=%d %dx%d C=%d: %.1f us (%.0f GB/s)" % (B, H, H, C, t, 3 * x.numel() * 2 / 1e3 / t))
