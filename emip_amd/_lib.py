@@ -9,7 +9,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "emip_hip.h")
-LIB_PATH = os.path.join(_HERE, "libemip_hip.so")
+LIB_PATH = os.environ.get("EMIP_HIP_LIB") or os.path.join(_HERE, "libemip_hip.so")   # override: A/B calibration of two builds
 
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p,
