@@ -47,6 +47,12 @@ struct GemmArgs {
     float* out_stats;
     int ln_C;
     float ln_eps;
+    // The same LayerNorm applied on the OUTPUT side of a dense GEMM: the product runs on the raw rows (any main loop, in
+    // particular the LDS-DMA one) and the epilogue uses  xhat W^T = rstd (x W^T) - rstd mean colsum(W):
+    // lne_stats [M][2] like ln_stats, lne_colsum [N] = sum_k W[n][k] of the packed (rounded) weights.  Two FMAs per
+    // output element instead of a normalisation of every staged operand element in every N tile.
+    const float* lne_stats;
+    const float* lne_colsum;
     // split-K (small-M, long-K launches): blockIdx.y owns a range of K tiles and adds its partial tile into acc_out (f32
     // [M][ldacc], zero beforehand) with atomics; bias is added by split 0; the row cast / statistics happen in
     // emip_rows_finalize
@@ -409,6 +415,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
     const int nb = n0 + wn * WN;
     const bool act_gelu = p.act == EMIP_ACT_GELU, act_relu = p.act == EMIP_ACT_RELU;
     float4 bias_v[TN];      // this lane's 4 output channels of each sub-tile column, loaded once
+    float4 csum_v[TN];      // the same channels of lne_colsum (output-side LayerNorm)
+#pragma unroll
+    for (int a = 0; a < TN; ++a) {
+        csum_v[a] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.lne_stats) {
+            const int n = nb + 16 * a + 4 * fq;
+            csum_v[a] = make_float4(p.lne_colsum[min(n + 0, p.N - 1)], p.lne_colsum[min(n + 1, p.N - 1)],
+                                    p.lne_colsum[min(n + 2, p.N - 1)], p.lne_colsum[min(n + 3, p.N - 1)]);
+        }
+    }
 #pragma unroll
     for (int a = 0; a < TN; ++a) {
         bias_v[a] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -434,10 +450,20 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
                 rres[i] = *reinterpret_cast<const uint4*>(R + (long)mc * p.ldr + nc);
             }
         }
+        float rs = 1.f, mrs = 0.f;       // output-side LayerNorm of this lane's row: rstd and mean * rstd
+        if (p.lne_stats) {
+            const int mrow = min(m0 + wm * WM + 16 * b + fr, p.M - 1);
+            const float2 st = *reinterpret_cast<const float2*>(p.lne_stats + 2 * ((long)z * p.M + mrow));
+            const float mu = st.x / (float)p.ln_C;
+            rs = rsqrtf(fmaxf(st.y / (float)p.ln_C - mu * mu, 0.f) + p.ln_eps);
+            mrs = mu * rs;
+        }
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
-            float4 v = make_float4(acc[a][b][0] + bias_v[a].x, acc[a][b][1] + bias_v[a].y, acc[a][b][2] + bias_v[a].z,
-                                   acc[a][b][3] + bias_v[a].w);
+            float4 v = make_float4(fmaf(acc[a][b][0], rs, fmaf(-mrs, csum_v[a].x, bias_v[a].x)),
+                                   fmaf(acc[a][b][1], rs, fmaf(-mrs, csum_v[a].y, bias_v[a].y)),
+                                   fmaf(acc[a][b][2], rs, fmaf(-mrs, csum_v[a].z, bias_v[a].z)),
+                                   fmaf(acc[a][b][3], rs, fmaf(-mrs, csum_v[a].w, bias_v[a].w)));
             if (act_gelu) {          // wave-uniform flags, tested once per sub-tile (not per element)
                 v.x = gelu_t<T>(v.x); v.y = gelu_t<T>(v.y); v.z = gelu_t<T>(v.z); v.w = gelu_t<T>(v.w);
             } else if (act_relu) {
@@ -608,6 +634,8 @@ int dispatch(GemmArgs& a, int batch, hipStream_t s) {
 extern "C" int emip_gemm_ln(const void*, const void*, const void*, void*, const float*, const void*, int, int, int, int, long,
                             long, long, long, long, int, int, long, long, long, long, const float*, int, float, float*, void*,
                             long, int, void*);
+extern "C" int emip_gemm_lne(const void*, const void*, void*, const float*, const void*, int, int, int, long, long, long, long,
+                             int, const float*, const float*, float, float*, void*, long, int, void*);
 extern "C" int emip_conv2d_ln(const void*, const void*, void*, const float*, const void*, int, int, int, int, long, int, int, int,
                               int, int, long, long, int, void*, long, const float*, float, float*, int, void*);
 extern "C" int emip_conv2d_splitk(const void*, const void*, void*, const float*, const void*, int, int, int, int, long, int, int,
@@ -648,6 +676,24 @@ extern "C" int emip_gemm_heads(const void* A, const void* W, void* C, int M, int
 // emip_gemm plus the LayerNorm-elimination hooks: ln_stats [M][2] (sum, sum of squares over ln_C = K channels of every A
 // row): the loader feeds (x - mean) * rstd; out_stats [M][2]: row sums of the stored output, accumulated with atomics
 // (cleared beforehand, e.g. through an earlier launch's zero_ptr); zero_ptr / zero_bytes: scratch this launch clears.
+// output-side parameters handed from emip_gemm_lne to the shared entry body (host-side, set and cleared around the call)
+static thread_local const float* t_lne_stats = nullptr;
+static thread_local const float* t_lne_colsum = nullptr;
+
+// emip_gemm_ln with the LayerNorm applied on the output side (see GemmArgs::lne_stats): same result as ln_stats up to f32
+// rounding, but the main loop stages the raw rows (LDS-DMA path) and the normalisation costs two FMAs per OUTPUT element.
+// colsum f32 [N] = sum_k W[n][k] over the packed weights (the values the MFMA sees).
+extern "C" int emip_gemm_lne(const void* A, const void* W, void* C, const float* bias, const void* R, int M, int N, int K,
+                             long lda, long ldw, long ldc, long ldr, int act, const float* ln_stats, const float* colsum,
+                             float ln_eps, float* out_stats, void* zero_ptr, long zero_bytes, int dtype, void* stream) {
+    EMIP_REQUIRE(ln_stats && colsum && ln_eps > 0.f && (reinterpret_cast<uintptr_t>(ln_stats) & 7) == 0);
+    t_lne_stats = ln_stats; t_lne_colsum = colsum;
+    const int rc = emip_gemm_ln(A, nullptr, W, C, bias, R, M, N, K, K, lda, 0, ldw, ldc, ldr, act, 1, 0, 0, 0, 0, nullptr, K,
+                                ln_eps, out_stats, zero_ptr, zero_bytes, dtype, stream);
+    t_lne_stats = t_lne_colsum = nullptr;
+    return rc;
+}
+
 extern "C" int emip_gemm_ln(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R,
                             int M, int N, int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act,
                             int batch, long bsA, long bsW, long bsC, long bsR, const float* ln_stats, int ln_C,
@@ -674,6 +720,7 @@ extern "C" int emip_gemm_ln(const void* A, const void* A2, const void* W, void* 
     a.heads = t_heads; a.hsA = t_hsA; a.hsW = t_hsW; a.hsC = t_hsC;
     if (t_heads > 1) EMIP_REQUIRE(A2 == nullptr && R == nullptr && batch % t_heads == 0 && t_hsA % vec == 0 && t_hsW % vec == 0);
     a.ln_stats = ln_stats; a.ln_C = ln_C; a.ln_eps = ln_eps; a.out_stats = out_stats;
+    a.lne_stats = t_lne_stats; a.lne_colsum = t_lne_colsum;
     if (zero_ptr) EMIP_REQUIRE(zero_bytes > 0 && (zero_bytes & 3) == 0 && (reinterpret_cast<uintptr_t>(zero_ptr) & 3) == 0);
     a.zero_ptr = static_cast<unsigned*>(zero_ptr);
     a.zero_words = zero_ptr ? zero_bytes / 4 : 0;

@@ -7,6 +7,8 @@ embed to the stage output (no permutes), every Linear is the MFMA GEMM with bias
 its epilogue, the spatial-reduction conv is an implicit GEMM over non-overlapping patches, and
 softmax(q k^T) v runs in one fused attention kernel whose 121-key K/V tile lives in LDS.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -33,6 +35,10 @@ FUSED_LN = True
 SPLITK_SR = False
 # q projection + spatial-reduction conv of a block hosted by one launch (emip_conv2d_pair)
 PAIR_Q_SR = True
+# Dense GEMMs behind a folded LayerNorm (fc1, kv, the stage-4 q) apply it on the OUTPUT side (emip_gemm_lne):
+# LN(x) W^T = rstd (x W^T) - rstd mean colsum(W).  The operand loader no longer normalises every staged element once per
+# N tile (10x per element for fc1), and the main loop becomes the LDS-DMA one.
+LN_EPILOGUE = os.environ.get("EMIP_LN_EPILOGUE", "1") != "0"
 
 
 def _lin_packs(w, dt):
@@ -198,6 +204,9 @@ class Block(EmipModule):
                            kv=(f(wkv) * gs).to(dt).contiguous(), bkv=(f(bkv) + f(wkv) @ bs).contiguous())
             else:
                 out.update(kv=(f(wkv) * g1).to(dt).contiguous(), bkv=(f(bkv) + f(wkv) @ b1).contiguous())
+            # column sums of the packed (rounded) weights: the output-side form of the folded LayerNorm (emip_gemm_lne)
+            for k in ("q", "kv", "w1"):
+                out["s" + k] = out[k].float().sum(1).contiguous()
             return out
         params = (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, a.q.weight, a.q.bias,
                   a.kv.weight, a.kv.bias, a.proj.weight, a.proj.bias, m.fc1.weight, m.fc1.bias,
@@ -233,9 +242,9 @@ class Block(EmipModule):
             s = torch.empty((B, H // sr, W // sr, C), dtype=dt, device=x.device)
             ops.conv2d_pair(ops.conv_desc(x, w["q"], 1, 1, 0, w["bq"], q, stats, self.norm1.eps),
                             ops.conv_desc(x, w["sr"], sr, sr, 0, w["bsr"], s, stats, self.norm1.eps, out_stats=st_sr), dt)
-            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps)
+            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"] if LN_EPILOGUE else None)
         else:
-            q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps)
+            q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["sq"] if LN_EPILOGUE else None)
         if sr > 1 and PAIR_Q_SR and not SPLITK_SR:
             pass
         elif sr > 1:
@@ -250,17 +259,17 @@ class Block(EmipModule):
             else:            # enough output tiles to fill the chip on their own
                 s = ops.conv2d(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps,
                                out_stats=st_sr)
-            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps)
+            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"] if LN_EPILOGUE else None)
         else:
             s = x
-            kv = ops.gemm(x, w["kv"], bias=w["bkv"], ln_stats=stats, ln_eps=self.norm1.eps)
+            kv = ops.gemm(x, w["kv"], bias=w["bkv"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["skv"] if LN_EPILOGUE else None)
         Lk = s.shape[1] * s.shape[2]
         att = torch.empty((B, H, W, C), dtype=dt, device=x.device)
         ops.attention(q, kv, kv[..., C:], att, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
                       k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
                       k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
         ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)                          # x += proj(attn)
-        t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps)
+        t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, colsum=w["sw1"] if LN_EPILOGUE else None)
         t = ops.dwconv3x3(t, w["wd"], w["bd"], act=ops.ACT_GELU)
         ops.gemm(t, w["w2"], bias=w["b2"], res=x, out=x, out_stats=st2)                           # x += mlp(...)
         return x, st2

@@ -48,9 +48,10 @@ def _nbytes(t):
 
 
 def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=None, ln_eps=0.0, out_stats=None,
-         zero=None):
+         zero=None, colsum=None):
     """out[m, n] = act(a[m, :] . w[n, :] (+ a2 . w[n, K1:]) + bias[n]) + res[m, n]
     ln_stats f32 [M,2]: normalise the rows of a on the fly ((x - mean) * rstd; gamma / beta folded into w / bias);
+    colsum f32 [N] (= w.float().sum(1)) with ln_stats: the same LayerNorm applied on the output side (emip_gemm_lne);
     out_stats f32 [M,2]: accumulate (sum, sum of squares) of the stored rows; zero: scratch tensor this launch clears."""
     M, K1, lda = rows(a)
     N, K = w.shape
@@ -76,6 +77,11 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=No
         return out
     for t in (ln_stats, out_stats):
         assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 2 * M)
+    if colsum is not None and ln_stats is not None:
+        assert a2 is None and colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous()
+        _lib.call("emip_gemm_lne", _p(a), _p(w), _p(out), _p(bias), _p(res), M, N, K, lda, K, ldc, ldr, act, _p(ln_stats),
+                  _p(colsum), float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), dt_code(a.dtype), _stream())
+        return out
     _lib.call("emip_gemm_ln", _p(a), _p(a2), _p(w), _p(out), _p(bias), _p(res), M, N, K, K1, lda, lda2, K, ldc, ldr, act,
               1, 0, 0, 0, 0, _p(ln_stats), K, float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), dt_code(a.dtype),
               _stream())

@@ -64,6 +64,15 @@ int emip_gemm_ln(const void* A, const void* A2, const void* W, void* C, const fl
                  long bsC, long bsR, const float* ln_stats, int ln_C, float ln_eps, float* out_stats, void* zero_ptr,
                  long zero_bytes, int dtype, void* stream);
 
+/* emip_gemm_ln with the LayerNorm applied on the OUTPUT side of the product (lib/pvt_v2.py:139-142 norm2 -> fc1,
+ * :107-110 norm -> kv):  LN(x) W^T = rstd (x W^T) - rstd mean colsum(W) (+ the folded bias), so the main loop stages the raw
+ * rows (LDS-DMA path) and the normalisation costs two FMAs per output element instead of one per staged operand element
+ * and N tile.  ln_stats f32 [M][2] = (sum, sum of squares) over the K channels of every A row; colsum f32 [N] = sum_k of
+ * the PACKED weights (the rounded values the MFMA multiplies). */
+int emip_gemm_lne(const void* A, const void* W, void* C, const float* bias, const void* R, int M, int N, int K, long lda,
+                  long ldw, long ldc, long ldr, int act, const float* ln_stats, const float* colsum, float ln_eps,
+                  float* out_stats, void* zero_ptr, long zero_bytes, int dtype, void* stream);
+
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
 int emip_gemm_tile(long M, long N, long batch, long K);
 

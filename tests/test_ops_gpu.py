@@ -436,6 +436,22 @@ def test_gemm_with_folded_layernorm_and_row_statistics(dt, tol, M, N, K):
     assert err < tol * max(1.0, ref.abs().max().item()), err
     want = torch.stack([y.float().sum(1), (y.float() ** 2).sum(1)], 1)
     assert ((out_stats - want).abs() / (want.abs() + 1.0)).max().item() < 1e-3
+    # the output-side form of the same LayerNorm (emip_gemm_lne): rstd (x W^T) - rstd mean colsum(W)
+    out_stats2 = torch.zeros(M, 2, device=dev)
+    y2 = ops.gemm(xs, wf, bias=bf, res=res.to(dev), ln_stats=stats, ln_eps=1e-6, out_stats=out_stats2,
+                  colsum=wf.float().sum(1).contiguous())
+    err2 = (y2.float().cpu() - ref).abs().max().item()
+    assert err2 < tol * max(1.0, ref.abs().max().item()), err2
+    want2 = torch.stack([y2.float().sum(1), (y2.float() ** 2).sum(1)], 1)
+    assert ((out_stats2 - want2).abs() / (want2.abs() + 1.0)).max().item() < 1e-3
+    # a row mean far from zero (|mean| = 40 sigma): the cancellation in the output-side form stays inside the tolerance
+    xo = (x.float() * 0.25 + 10.0).to(dt).to(dev)
+    so = torch.stack([xo.float().sum(1), (xo.float() ** 2).sum(1)], 1).contiguous()
+    refo = torch.nn.functional.layer_norm(xo.float().cpu(), (K,), gamma, beta, 1e-6) @ w.t() + b
+    yo = ops.gemm(xo, wf, bias=bf, ln_stats=so, ln_eps=1e-6, colsum=wf.float().sum(1).contiguous())
+    yl = ops.gemm(xo, wf, bias=bf, ln_stats=so, ln_eps=1e-6)
+    lim = (4 if dt == torch.bfloat16 else 40) * tol * max(1.0, refo.abs().max().item())
+    assert (yo.float().cpu() - refo).abs().max().item() < lim, ((yo.float().cpu() - refo).abs().max().item(), (yl.float().cpu() - refo).abs().max().item())
     # the scratch-clearing hook: a following launch zeroes a buffer while doing its own work
     scratch = torch.ones(37, device=dev)
     ops.gemm(xs, wf, bias=bf, zero=scratch)
