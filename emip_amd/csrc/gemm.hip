@@ -59,6 +59,10 @@ struct GemmArgs {
     float* acc_out;
     long ldacc;
     int ksplit;
+    // fused split-K: with `ticket` (one zeroed counter per output tile) the LAST split workgroup of a tile to arrive takes the
+    // summed tile back out of acc_out (atomic exchange with 0, so accumulator and counter are clean for the next launch)
+    // and runs the normal epilogue: no finalize launch, no zero-fill
+    unsigned* ticket;
     unsigned* zero_ptr;   // optional scratch the first workgroup clears (saves the consumer's zero-fill launch)
     long zero_words;
     int dbg;   // experiment flags (emip_debug_set key 2): 1 = skip epilogue stores, 2 = skip global loads in the K loop
@@ -394,14 +398,34 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (n + j < p.N) {
-                            const float v = acc[a][b][j] + ((first && p.bias) ? p.bias[n + j] : 0.f);
+                            const float v = acc[a][b][j] + ((first && p.bias && !p.ticket) ? p.bias[n + j] : 0.f);
                             atomicAdd(p.acc_out + (long)m * p.ldacc + n + j, v);
                         }
                     }
                 }
             }
         }
-        return;
+        if (!p.ticket) return;
+        // every thread's atomics have been acknowledged once it passes the barrier (s_waitcnt vmcnt(0) + s_barrier); the
+        // ticket then orders this workgroup's contribution before the last arrival's read-back
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) *flag = atomicAdd(p.ticket + swz, 1u);
+        __syncthreads();
+        if (*flag != (unsigned)p.ksplit - 1u) return;
+        __syncthreads();
+        if (tid == 0) atomicExch(p.ticket + swz, 0u);
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = n0 + wn * (BN / 2) + 16 * a + 4 * fq;
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int m = m0 + wm * (BM / 2) + 16 * b + fr;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[a][b][j] = (m < p.M && n + j < p.N) ? atomicExch(p.acc_out + (long)m * p.ldacc + n + j, 0.f) : 0.f;
+            }
+        }
     }
     T* C = reinterpret_cast<T*>(p.C) + zb * p.bsC + zh * p.hsC;   // may alias R (in-place residual update)
     const T* R = p.R ? reinterpret_cast<const T*>(p.R) + z * p.bsR : nullptr;
@@ -545,8 +569,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 // accumulates into (the statistics scratch of a stage is cleared by the stage's patch-embed conv).
 template <typename T, int NBUF>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmArgs a, const GemmArgs b, const int na) {
-    if ((int)blockIdx.x < na) gemm_body<T, 64, 64, true, NBUF, true>(a, blockIdx.x, 0, 0, na);
-    else gemm_body<T, 64, 64, true, NBUF, true>(b, (int)blockIdx.x - na, 0, 0, (int)gridDim.x - na);
+    if ((int)blockIdx.x < na) {
+        gemm_body<T, 64, 64, true, NBUF, true>(a, blockIdx.x, 0, 0, na);
+    } else {                                            // problem b may be split along K: block = split * tiles + tile
+        const int idx = (int)blockIdx.x - na, tiles = b.tiles_m * b.tiles_n;
+        const int split = idx / tiles;
+        gemm_body<T, 64, 64, true, NBUF, true>(b, idx - split * tiles, split, 0, tiles);
+    }
 }
 
 int g_gemm_nbuf = 1;  // debug/tuning knob (emip_debug_set)
@@ -799,6 +828,7 @@ struct emip_conv_desc_t {      // mirrors emip_conv_desc of include/emip_hip.h
     const void* X; const void* W; void* Y; const float* bias; const void* R;
     int B, H, Wd, Cin; long ldx; int Cout, KH, KW, stride, pad; long ldy, ldr; int act;
     const float* ln_stats; float ln_eps; float* out_stats;
+    float* acc; unsigned* ticket; int ksplit;
 };
 
 static int fill_pair_args(const emip_conv_desc_t& d, int dtype, GemmArgs& a) {
@@ -820,6 +850,10 @@ static int fill_pair_args(const emip_conv_desc_t& d, int dtype, GemmArgs& a) {
     a.H = d.H; a.Wd = d.Wd; a.Cin = d.Cin; a.Ho = Ho; a.Wo = Wo; a.KH = d.KH; a.KW = d.KW; a.stride = d.stride; a.pad = d.pad;
     a.ln_stats = d.ln_stats; a.ln_C = d.Cin; a.ln_eps = d.ln_eps; a.out_stats = d.out_stats;
     a.ksplit = 1;
+    if (d.ksplit > 1) {      // fused split-K (second problem of a pair only, checked by the caller)
+        EMIP_REQUIRE(d.acc && d.ticket && d.ksplit <= 64 && (reinterpret_cast<uintptr_t>(d.acc) & 3) == 0 && d.R == nullptr);
+        a.ksplit = d.ksplit; a.acc_out = d.acc; a.ldacc = d.Cout; a.ticket = d.ticket;
+    }
     a.heads = 1;
     a.tiles_m = (a.M + 63) / 64;
     a.tiles_n = (a.N + 63) / 64;
@@ -833,7 +867,8 @@ extern "C" int emip_conv2d_pair(const void* da, const void* db, int dtype, void*
     GemmArgs a, b;
     if (fill_pair_args(*static_cast<const emip_conv_desc_t*>(da), dtype, a) != EMIP_OK) return EMIP_E_INVALID;
     if (fill_pair_args(*static_cast<const emip_conv_desc_t*>(db), dtype, b) != EMIP_OK) return EMIP_E_INVALID;
-    const int na = a.tiles_m * a.tiles_n, nb = b.tiles_m * b.tiles_n;
+    EMIP_REQUIRE(a.ksplit == 1);
+    const int na = a.tiles_m * a.tiles_n, nb = b.tiles_m * b.tiles_n * b.ksplit;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (dtype == EMIP_F32)
         hipLaunchKernelGGL((gemm_pair_kernel<float, 5>), dim3(na + nb), dim3(256), 128 * 128, s, a, b, na);

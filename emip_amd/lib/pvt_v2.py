@@ -35,6 +35,13 @@ FUSED_LN = True
 SPLITK_SR = False
 # q projection + spatial-reduction conv of a block hosted by one launch (emip_conv2d_pair)
 PAIR_Q_SR = True
+# ... with the sr conv's long K walk split over workgroups INSIDE that launch: partial tiles meet in an f32 accumulator, the
+# last split of a tile to arrive (a ticket counter) takes the sum back out and runs the epilogue (bias, bf16 store, row
+# statistics).  No finalize launch, no zero-fill: accumulator and tickets are left zero by every launch.  Parity-tested
+# (tests/test_ops_gpu.py::test_conv_pair_with_fused_split_k) but OFF: in an in-call A/B the 16-pair step went from 970 to
+# 900 pairs/s -- the launch gets shorter in isolation, but under four-stream replay the 1.3 M extra f32 atomics and the
+# 4x workgroups per launch cost more than the shorter dependency chain returns (same verdict as the unfused variant).
+PAIR_KSPLIT = os.environ.get("EMIP_PAIR_KSPLIT", "0") != "0"
 # Dense GEMMs behind a folded LayerNorm (fc1, kv, the stage-4 q) apply it on the OUTPUT side (emip_gemm_lne):
 # LN(x) W^T = rstd (x W^T) - rstd mean colsum(W).  The operand loader no longer normalises every staged element once per
 # N tile (10x per element for fc1), and the main loop becomes the LDS-DMA one.
@@ -222,7 +229,15 @@ class Block(EmipModule):
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
         return (Ms * C if (sr > 1 and SPLITK_SR) else 0) + 2 * (Ms + 2 * M)
 
-    def run_fused(self, x, stats, buf):
+    @staticmethod
+    def shared_scratch_floats(B, H, W, C, sr):
+        """f32 words the blocks of a stage share for the fused split-K of the sr conv: accumulator + one ticket per tile"""
+        if not (sr > 1 and PAIR_Q_SR and PAIR_KSPLIT and not SPLITK_SR):
+            return 0
+        Ms = B * (H // sr) * (W // sr)
+        return Ms * C + ((Ms + 63) // 64) * ((C + 63) // 64)
+
+    def run_fused(self, x, stats, buf, shared=None):
         """Inference block without LayerNorm launches.  x [B,H,W,C] (updated in place), stats f32 [B*H*W, 2] = (sum, sum of
         squares) of its rows, buf: this block's slice of the stage's ZEROED scratch -> (x, stats of the new rows)."""
         a = self.attn
@@ -240,8 +255,15 @@ class Block(EmipModule):
             # q projection (as a 1x1 conv over the tokens) and the spatial-reduction conv in ONE launch
             q = torch.empty((B, H, W, C), dtype=dt, device=x.device)
             s = torch.empty((B, H // sr, W // sr, C), dtype=dt, device=x.device)
+            ksplit, acc, ticket = 1, None, None
+            if PAIR_KSPLIT and shared is not None and shared.numel() > 0:
+                tiles = ((Ms + 63) // 64) * ((C + 63) // 64)
+                nk = sr * sr * C // (64 if dt == torch.bfloat16 else 32)
+                ksplit = max(1, min(nk // 4, (256 + tiles - 1) // tiles, 16))      # >= 4 K tiles per split, ~256 workgroups
+                acc, ticket = shared[:Ms * C], shared[Ms * C:].view(torch.int32)
             ops.conv2d_pair(ops.conv_desc(x, w["q"], 1, 1, 0, w["bq"], q, stats, self.norm1.eps),
-                            ops.conv_desc(x, w["sr"], sr, sr, 0, w["bsr"], s, stats, self.norm1.eps, out_stats=st_sr), dt)
+                            ops.conv_desc(x, w["sr"], sr, sr, 0, w["bsr"], s, stats, self.norm1.eps, out_stats=st_sr,
+                                          acc=acc, ticket=ticket, ksplit=ksplit), dt)
             kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"] if LN_EPILOGUE else None)
         else:
             q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["sq"] if LN_EPILOGUE else None)
@@ -357,10 +379,12 @@ class PyramidVisionTransformerV2(EmipModule):
                 # statistics scratch of the whole stage: one allocation, cleared by the patch-embed conv's workgroups
                 a0 = blocks[0].attn
                 per = Block.scratch_floats(x.shape[0], Ho, Wo, a0.dim, a0.sr_ratio)
-                scratch = torch.empty((len(blocks), per), dtype=torch.float32, device=x.device)
+                nshared = Block.shared_scratch_floats(x.shape[0], Ho, Wo, a0.dim, a0.sr_ratio)
+                scratch = torch.empty(len(blocks) * per + nshared, dtype=torch.float32, device=x.device)
                 x = pe.run(x, out_stats=stats, zero=scratch)
+                shared = scratch[len(blocks) * per:]
                 for j, blk in enumerate(blocks):
-                    x, stats = blk.run_fused(x, stats, scratch[j])
+                    x, stats = blk.run_fused(x, stats, scratch[j * per:(j + 1) * per], shared)
             else:
                 x = pe.run(x)
                 for blk in blocks:

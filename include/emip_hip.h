@@ -118,6 +118,9 @@ typedef struct emip_conv_desc {
     const void* X; const void* W; void* Y; const float* bias; const void* R;
     int B, H, Wd, Cin; long ldx; int Cout, KH, KW, stride, pad; long ldy, ldr; int act;
     const float* ln_stats; float ln_eps; float* out_stats;
+    /* fused split-K of the SECOND problem (ksplit > 1): acc f32 [B*Ho*Wo][Cout] and ticket u32 [output tiles of 64x64], both
+     * zero before the first launch and left zero by every launch; the last split to arrive runs the epilogue */
+    float* acc; unsigned* ticket; int ksplit;
 } emip_conv_desc;
 int emip_conv2d_pair(const void* desc_a, const void* desc_b, int dtype, void* stream);   /* -> const emip_conv_desc* */
 

@@ -513,3 +513,41 @@ def test_sr_conv_splitk_and_finalize(dt, tol, B, H, C, k, ks):
     assert err < tol * max(1.0, ref.abs().max().item()), err
     want = torch.stack([y.float().sum(-1), (y.float() ** 2).sum(-1)], -1).view(-1, 2)
     assert ((st - want).abs() / (want.abs() + 1.0)).max().item() < 1e-3
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,H,C,k,ksplit", [(2, 88, 64, 8, 1), (2, 88, 64, 8, 16), (3, 44, 128, 4, 8), (2, 22, 320, 2, 4),
+                                            (1, 22, 320, 2, 5)])
+def test_conv_pair_with_fused_split_k(dt, tol, B, H, C, k, ksplit):
+    """emip_conv2d_pair (q projection as a 1x1 conv + the spatial-reduction conv, both behind the folded LayerNorm) against
+    the two separate launches; with ksplit > 1 the sr conv's K walk is split inside the launch and the last split to arrive
+    runs the epilogue.  Launched three times on the same accumulator / tickets: every launch must leave them zero."""
+    from emip_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + C + ksplit)
+    dev = "cuda:0"
+    x = (torch.randn(B, H, H, C, generator=g) * 1.3 + 0.4).to(dt).to(dev)
+    wq = (torch.randn(C, C, generator=g) / C ** 0.5).to(dt).to(dev)
+    wsr = (torch.randn(C, k * k * C, generator=g) / (k * k * C) ** 0.5).to(dt).to(dev)
+    bq, bsr = (0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    xf = x.float().view(-1, C)
+    stats = torch.stack([xf.sum(1), (xf ** 2).sum(1)], 1).contiguous()
+    Ho = H // k
+    Ms = B * Ho * Ho
+    q_ref = ops.conv2d(x, wq, 1, 1, 1, 0, bias=bq, ln_stats=stats, ln_eps=1e-6)
+    st_ref = torch.zeros(Ms, 2, device=dev)
+    s_ref = ops.conv2d(x, wsr, k, k, k, 0, bias=bsr, ln_stats=stats, ln_eps=1e-6, out_stats=st_ref)
+    tiles = ((Ms + 63) // 64) * ((C + 63) // 64)
+    acc = torch.zeros(Ms * C, device=dev)
+    ticket = torch.zeros(tiles, dtype=torch.int32, device=dev)
+    for _ in range(3):
+        q = torch.empty_like(q_ref)
+        s_out = torch.empty_like(s_ref)
+        st = torch.zeros(Ms, 2, device=dev)
+        ops.conv2d_pair(ops.conv_desc(x, wq, 1, 1, 0, bq, q, stats, 1e-6),
+                        ops.conv_desc(x, wsr, k, k, 0, bsr, s_out, stats, 1e-6, out_stats=st, acc=acc, ticket=ticket,
+                                      ksplit=ksplit), dt)
+        assert torch.equal(q, q_ref)
+        scale = max(1.0, s_ref.float().abs().max().item())
+        assert (s_out.float() - s_ref.float()).abs().max().item() < tol * scale
+        assert ((st - st_ref).abs() / (st_ref.abs() + 1.0)).max().item() < (2e-2 if dt == torch.bfloat16 else 1e-3)
+        assert acc.abs().max().item() == 0 and ticket.abs().max().item() == 0
