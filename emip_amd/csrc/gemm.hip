@@ -169,6 +169,15 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
         w_off[i] = (long)(w_ok[i] ? n : p.N - 1) * p.ldw;
     }
 
+    // CONV: per-chunk image base pointers (the pixel offset inside an image fits 32 bits: H * W * lda < 2^31 is checked by
+    // the entry points) and the wave-uniform tap state of load_tile_ln
+    const T* a_base[CA];
+#pragma unroll
+    for (int i = 0; i < CA; ++i) a_base[i] = CONV ? A + a_off[i] * p.lda : A;
+    const bool cin_tiled = CONV && (p.Cin % BK) == 0;
+    int tap_next_k0 = -1, tap_ci0 = 0, tap_ky = 0, tap_kx = 0;
+    (void)cin_tiled; (void)tap_next_k0; (void)tap_ci0; (void)tap_ky; (void)tap_kx;
+
     // Loads are UNCONDITIONAL on clamped (always valid) addresses and masked afterwards: a load inside an
     // `if` makes hipcc branch around it and wait for it on the spot, which serialises the tile's loads.
     // LNA: per-row (sum, sum of squares) of the A operand's source rows; the normalisation itself happens in store_tile, when
@@ -190,20 +199,43 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
         const int kkc = kok ? kk : 0;
         if (LNA) ln.ok = 0;
         if (CONV) {
-            const int tap = kkc / p.Cin;
-            const int ci = kkc - tap * p.Cin;
-            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            // tap decode.  When Cin is a multiple of the K tile, a tile lies inside one tap and consecutive calls walk the
+            // taps in order: the (ky, kx, channel base) state is carried in wave-uniform registers instead of two integer
+            // divisions per thread and tile (the loader's address arithmetic, not the MFMA, is what a 64x64 conv tile
+            // spends its issue slots on)
+            int ci, ky, kx;
+            if (cin_tiled) {
+                if (k0 != tap_next_k0) {                 // first call of this workgroup (or a jump): decode once
+                    const int tap = k0 / p.Cin;
+                    tap_ci0 = k0 - tap * p.Cin;
+                    tap_ky = tap / p.KW;
+                    tap_kx = tap - tap_ky * p.KW;
+                }
+                ci = tap_ci0 + sc * VEC; ky = tap_ky; kx = tap_kx;
+                tap_next_k0 = k0 + BK;
+                tap_ci0 += BK;
+                if (tap_ci0 >= p.Cin) {
+                    tap_ci0 = 0;
+                    if (++tap_kx == p.KW) { tap_kx = 0; ++tap_ky; }
+                }
+            } else {
+                const int tap = kkc / p.Cin;
+                ci = kkc - tap * p.Cin;
+                ky = tap / p.KW; kx = tap - ky * p.KW;
+            }
+            {
 #pragma unroll
-            for (int i = 0; i < CA; ++i) {
-                const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-                const bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
-                const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.Wd - 1);
-                const long pix = a_off[i] + (long)iyc * p.Wd + ixc;
-                const uint4 v = *reinterpret_cast<const uint4*>(A + pix * p.lda + ci);
-                ra[i] = mask4(v, ok);
-                if (LNA) {
-                    ln.st[LNA ? i : 0] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * pix);
-                    ln.ok |= ok ? (1u << i) : 0u;
+                for (int i = 0; i < CA; ++i) {
+                    const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
+                    const bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                    const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.Wd - 1);
+                    const int po = iyc * p.Wd + ixc;
+                    const uint4 v = *reinterpret_cast<const uint4*>(a_base[i] + (long)(po * (int)p.lda + ci));
+                    ra[i] = mask4(v, ok);
+                    if (LNA) {
+                        ln.st[LNA ? i : 0] = *reinterpret_cast<const float2*>(p.ln_stats + 2 * (a_off[i] + po));
+                        ln.ok |= ok ? (1u << i) : 0u;
+                    }
                 }
             }
         } else {
@@ -801,7 +833,7 @@ extern "C" int emip_conv2d_splitk(const void* X, const void* W, void* Y, const f
     EMIP_REQUIRE(aligned16(X) && aligned16(W));
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
     EMIP_REQUIRE(Ho > 0 && Wo > 0);
-    EMIP_REQUIRE((long)B * Ho * Wo < 2147483647L && (long)KH * KW * Cin < 2147483647L);
+    EMIP_REQUIRE((long)B * Ho * Wo < 2147483647L && (long)KH * KW * Cin < 2147483647L && (long)H * Wd * ldx < 2147483647L);
     if (R) EMIP_REQUIRE(ldr >= Cout);
     EMIP_REQUIRE(act >= EMIP_ACT_NONE && act <= EMIP_ACT_GELU);
     GemmArgs a{};
@@ -842,7 +874,8 @@ static int fill_pair_args(const emip_conv_desc_t& d, int dtype, GemmArgs& a) {
     if (d.out_stats) EMIP_REQUIRE((reinterpret_cast<uintptr_t>(d.out_stats) & 3) == 0);
     EMIP_REQUIRE(d.act >= EMIP_ACT_NONE && d.act <= EMIP_ACT_GELU);
     const int Ho = (d.H + 2 * d.pad - d.KH) / d.stride + 1, Wo = (d.Wd + 2 * d.pad - d.KW) / d.stride + 1;
-    EMIP_REQUIRE(Ho > 0 && Wo > 0 && (long)d.B * Ho * Wo < 2147483647L && (long)d.KH * d.KW * d.Cin < 2147483647L);
+    EMIP_REQUIRE(Ho > 0 && Wo > 0 && (long)d.B * Ho * Wo < 2147483647L && (long)d.KH * d.KW * d.Cin < 2147483647L &&
+                 (long)d.H * d.Wd * d.ldx < 2147483647L);
     a = GemmArgs{};
     a.A = d.X; a.W = d.W; a.C = d.Y; a.bias = d.bias; a.R = d.R;
     a.M = d.B * Ho * Wo; a.N = d.Cout; a.K = d.KH * d.KW * d.Cin; a.K1 = a.K;
