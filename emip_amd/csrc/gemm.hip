@@ -103,10 +103,31 @@ __device__ __forceinline__ uint4 ln_apply(uint4 v, float mu, float rs) {
     for (int j = 0; j < (int)(16 / sizeof(T)); ++j) e[j] = from_f32<T>((to_f32<T>(e[j]) - mu) * rs);
     return v;
 }
+// bf16: the normalisation sits on the K loop's critical path (loaded chunk -> LDS store), so it is written as one packed
+// FMA per channel pair, x * rstd + (-mean * rstd), on values unpacked with a shift / mask
+template <>
+__device__ __forceinline__ uint4 ln_apply<bf16_t>(uint4 v, float mu, float rs) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+    const float nmr = -mu * rs;
+    unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        f32x2 x = {__uint_as_float(w[k] << 16), __uint_as_float(w[k] & 0xFFFF0000u)};
+        x = x * rs + nmr;
+        bf16x2 o;
+        o[0] = (bf16_t)x.x;
+        o[1] = (bf16_t)x.y;
+        w[k] = __builtin_bit_cast(unsigned, o);
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
 
 // The kernel body is a device function over an explicit block id so that one launch can host several problems
 // (gemm_pair_kernel below): bx = tile index, by = split-K index, bz = batch index, gx = number of tile blocks.
-template <typename T, int BM, int BN, bool CONV, int NBUF, bool LNA>
+// NOPAD (CONV only): the caller guarantees pad == 0, so every tap of a valid output pixel lies inside the image and the
+// loader skips the bounds tests and clamps (as a template flag: a run-time branch around the loads would serialise them)
+template <typename T, int BM, int BN, bool CONV, int NBUF, bool LNA, bool NOPAD = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const int by, const int bz, const int gx) {
     constexpr int VEC = 16 / sizeof(T);   // elements per 16-B chunk
     constexpr int BK = 128 / sizeof(T);   // K elements per tile
@@ -227,8 +248,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
 #pragma unroll
                 for (int i = 0; i < CA; ++i) {
                     const int iy = a_iy[i] + ky, ix = a_ix[i] + kx;
-                    const bool ok = kok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
-                    const int iyc = min(max(iy, 0), p.H - 1), ixc = min(max(ix, 0), p.Wd - 1);
+                    const bool ok = NOPAD ? (kok && a_ok[i])
+                                          : (kok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd);
+                    const int iyc = NOPAD ? iy : min(max(iy, 0), p.H - 1), ixc = NOPAD ? ix : min(max(ix, 0), p.Wd - 1);
                     const int po = iyc * p.Wd + ixc;
                     const uint4 v = *reinterpret_cast<const uint4*>(a_base[i] + (long)(po * (int)p.lda + ci));
                     ra[i] = mask4(v, ok);
@@ -602,11 +624,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 template <typename T, int NBUF>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmArgs a, const GemmArgs b, const int na) {
     if ((int)blockIdx.x < na) {
-        gemm_body<T, 64, 64, true, NBUF, true>(a, blockIdx.x, 0, 0, na);
+        gemm_body<T, 64, 64, true, NBUF, true, true>(a, blockIdx.x, 0, 0, na);
     } else {                                            // problem b may be split along K: block = split * tiles + tile
         const int idx = (int)blockIdx.x - na, tiles = b.tiles_m * b.tiles_n;
         const int split = idx / tiles;
-        gemm_body<T, 64, 64, true, NBUF, true>(b, idx - split * tiles, split, 0, tiles);
+        gemm_body<T, 64, 64, true, NBUF, true, true>(b, idx - split * tiles, split, 0, tiles);
     }
 }
 
@@ -865,7 +887,7 @@ struct emip_conv_desc_t {      // mirrors emip_conv_desc of include/emip_hip.h
 
 static int fill_pair_args(const emip_conv_desc_t& d, int dtype, GemmArgs& a) {
     EMIP_REQUIRE(d.X && d.W && d.Y && d.ln_stats && d.B > 0 && d.H > 0 && d.Wd > 0 && d.Cin > 0 && d.Cout > 0);
-    EMIP_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.pad >= 0 && d.ln_eps > 0.f);
+    EMIP_REQUIRE(d.KH > 0 && d.KW > 0 && d.stride > 0 && d.pad == 0 && d.ln_eps > 0.f);     // the pair kernel is the NOPAD loader
     const int vec = dtype == EMIP_F32 ? 4 : 8;
     EMIP_REQUIRE(d.Cin % vec == 0 && d.ldx % vec == 0 && d.ldx >= d.Cin && d.ldy >= d.Cout && d.Cout % vec == 0);
     EMIP_REQUIRE(aligned16(d.X) && aligned16(d.W) && aligned16(d.Y) && d.ldy % vec == 0);
