@@ -621,10 +621,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 // read the same normalised tokens and are independent: the sr conv is 16-80 workgroups walking a long K, alone it leaves the
 // chip idle for its whole duration, next to the q tiles it is hidden.  Neither problem may clear scratch the other one
 // accumulates into (the statistics scratch of a stage is cleared by the stage's patch-embed conv).
-template <typename T, int NBUF>
+// ADENSE: problem a is a plain GEMM over the raw rows with the LayerNorm on the output side (lne_stats / lne_colsum) on the
+// LDS-DMA main loop -- the q projection then neither normalises its operand once per N tile nor stages it through registers.
+template <typename T, int NBUF, bool ADENSE>
 __global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmArgs a, const GemmArgs b, const int na) {
     if ((int)blockIdx.x < na) {
-        gemm_body<T, 64, 64, true, NBUF, true, true>(a, blockIdx.x, 0, 0, na);
+        if constexpr (ADENSE) gemm_body<T, 64, 64, false, 3, false>(a, blockIdx.x, 0, 0, na);
+        else gemm_body<T, 64, 64, true, NBUF, true, true>(a, blockIdx.x, 0, 0, na);
     } else {                                            // problem b may be split along K: block = split * tiles + tile
         const int idx = (int)blockIdx.x - na, tiles = b.tiles_m * b.tiles_n;
         const int split = idx / tiles;
@@ -883,6 +886,7 @@ struct emip_conv_desc_t {      // mirrors emip_conv_desc of include/emip_hip.h
     int B, H, Wd, Cin; long ldx; int Cout, KH, KW, stride, pad; long ldy, ldr; int act;
     const float* ln_stats; float ln_eps; float* out_stats;
     float* acc; unsigned* ticket; int ksplit;
+    const float* colsum;
 };
 
 static int fill_pair_args(const emip_conv_desc_t& d, int dtype, GemmArgs& a) {
@@ -913,6 +917,12 @@ static int fill_pair_args(const emip_conv_desc_t& d, int dtype, GemmArgs& a) {
     a.tiles_m = (a.M + 63) / 64;
     a.tiles_n = (a.N + 63) / 64;
     a.dbg = 0;
+    if (d.colsum) {          // a 1x1 conv handed over as a dense GEMM with the output-side LayerNorm (first problem only)
+        const int bk = dtype == EMIP_F32 ? 32 : 64;
+        EMIP_REQUIRE(d.KH == 1 && d.KW == 1 && d.stride == 1 && d.ksplit <= 1 && d.Cin % bk == 0);
+        a.lne_stats = d.ln_stats; a.lne_colsum = d.colsum; a.ln_stats = nullptr;
+        a.bsA = a.bsW = a.bsC = a.bsR = 0;
+    }
     return EMIP_OK;
 }
 
@@ -925,10 +935,18 @@ extern "C" int emip_conv2d_pair(const void* da, const void* db, int dtype, void*
     EMIP_REQUIRE(a.ksplit == 1);
     const int na = a.tiles_m * a.tiles_n, nb = b.tiles_m * b.tiles_n * b.ksplit;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    EMIP_REQUIRE(b.lne_stats == nullptr);
+    if (a.lne_stats) {       // dense first problem: two LDS-DMA buffers of a 64x64 tile pair
+        if (dtype == EMIP_F32)
+            hipLaunchKernelGGL((gemm_pair_kernel<float, 5, true>), dim3(na + nb), dim3(256), 2 * 128 * 128, s, a, b, na);
+        else
+            hipLaunchKernelGGL((gemm_pair_kernel<bf16_t, 5, true>), dim3(na + nb), dim3(256), 2 * 128 * 128, s, a, b, na);
+        return emip_launch_status();
+    }
     if (dtype == EMIP_F32)
-        hipLaunchKernelGGL((gemm_pair_kernel<float, 5>), dim3(na + nb), dim3(256), 128 * 128, s, a, b, na);
+        hipLaunchKernelGGL((gemm_pair_kernel<float, 5, false>), dim3(na + nb), dim3(256), 128 * 128, s, a, b, na);
     else
-        hipLaunchKernelGGL((gemm_pair_kernel<bf16_t, 5>), dim3(na + nb), dim3(256), 128 * 128, s, a, b, na);
+        hipLaunchKernelGGL((gemm_pair_kernel<bf16_t, 5, false>), dim3(na + nb), dim3(256), 128 * 128, s, a, b, na);
     return emip_launch_status();
 }
 

@@ -261,7 +261,8 @@ class Block(EmipModule):
                 nk = sr * sr * C // (64 if dt == torch.bfloat16 else 32)
                 ksplit = max(1, min(nk // 4, (256 + tiles - 1) // tiles, 16))      # >= 4 K tiles per split, ~256 workgroups
                 acc, ticket = shared[:Ms * C], shared[Ms * C:].view(torch.int32)
-            ops.conv2d_pair(ops.conv_desc(x, w["q"], 1, 1, 0, w["bq"], q, stats, self.norm1.eps),
+            ops.conv2d_pair(ops.conv_desc(x, w["q"], 1, 1, 0, w["bq"], q, stats, self.norm1.eps,
+                                          colsum=w["sq"] if LN_EPILOGUE else None),
                             ops.conv_desc(x, w["sr"], sr, sr, 0, w["bsr"], s, stats, self.norm1.eps, out_stats=st_sr,
                                           acc=acc, ticket=ticket, ksplit=ksplit), dt)
             kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"] if LN_EPILOGUE else None)

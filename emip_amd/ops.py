@@ -127,11 +127,11 @@ class ConvDesc(_ct.Structure):
                 ("Cout", _ct.c_int), ("KH", _ct.c_int), ("KW", _ct.c_int), ("stride", _ct.c_int), ("pad", _ct.c_int),
                 ("ldy", _ct.c_long), ("ldr", _ct.c_long), ("act", _ct.c_int), ("ln_stats", _ct.c_void_p),
                 ("ln_eps", _ct.c_float), ("out_stats", _ct.c_void_p), ("acc", _ct.c_void_p), ("ticket", _ct.c_void_p),
-                ("ksplit", _ct.c_int)]
+                ("ksplit", _ct.c_int), ("colsum", _ct.c_void_p)]
 
 
 def conv_desc(x, w, k, stride, pad, bias, out, ln_stats, ln_eps, out_stats=None, res=None, act=ACT_NONE, acc=None,
-              ticket=None, ksplit=1):
+              ticket=None, ksplit=1, colsum=None):
     """acc / ticket / ksplit: fused split-K (second problem of a pair): f32 [rows, Cout] accumulator and one u32 counter per
     64x64 output tile, zero before the first launch (every launch leaves them zero)"""
     B, H, W, Cin = x.shape
@@ -141,7 +141,7 @@ def conv_desc(x, w, k, stride, pad, bias, out, ln_stats, ln_eps, out_stats=None,
         assert ticket.numel() >= ((rows(out)[0] + 63) // 64) * ((w.shape[0] + 63) // 64)
     return ConvDesc(_p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, x.stride(2), w.shape[0], k, k, stride, pad,
                     rows(out)[2], rows(res)[2] if res is not None else 0, act, _p(ln_stats), float(ln_eps), _p(out_stats),
-                    _p(acc) if ksplit > 1 else None, _p(ticket) if ksplit > 1 else None, int(ksplit))
+                    _p(acc) if ksplit > 1 else None, _p(ticket) if ksplit > 1 else None, int(ksplit), _p(colsum))
 
 
 def conv2d_pair(da, db, dtype):

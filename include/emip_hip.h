@@ -121,6 +121,9 @@ typedef struct emip_conv_desc {
     /* fused split-K of the SECOND problem (ksplit > 1): acc f32 [B*Ho*Wo][Cout] and ticket u32 [output tiles of 64x64], both
      * zero before the first launch and left zero by every launch; the last split to arrive runs the epilogue */
     float* acc; unsigned* ticket; int ksplit;
+    /* FIRST problem, 1x1 conv only: f32 [Cout] column sums of the packed weights -> it runs as a dense GEMM over the raw rows
+     * with the LayerNorm on the output side (see emip_gemm_lne) */
+    const float* colsum;
 } emip_conv_desc;
 int emip_conv2d_pair(const void* desc_a, const void* desc_b, int dtype, void* stream);   /* -> const emip_conv_desc* */
 
