@@ -347,6 +347,8 @@ def main():
     _lib.load()
     if os.environ.get("EMIP_TILE_SHARE"):
         _lib.call("emip_debug_set", 4, int(os.environ["EMIP_TILE_SHARE"]))
+    if os.environ.get("EMIP_PAIR_TWO"):
+        _lib.call("emip_debug_set", 8, int(os.environ["EMIP_PAIR_TWO"]))
     if os.environ.get("EMIP_GEMM_NBUF"):
         _lib.call("emip_debug_set", 0, int(os.environ["EMIP_GEMM_NBUF"]))
     g = os.path.join(ROOT, "tests", "golden")

@@ -395,6 +395,30 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
             if (kt + 1 < nk) store_tile(cur ^ 1, ra, rw);
             __syncthreads();
         }
+    } else if (NBUF == 6) {
+        // KPB = 2 K tiles per barrier interval (as many LDS buffers and register stages): a 64x64 tile's K step is a
+        // latency chain (LDS store -> barrier -> ds_read -> 8 MFMAs -> barrier, ~0.65 us with one workgroup per CU whatever
+        // the prefetch depth), so the long-K small-grid convs cut the number of chains instead of trying to hide them.  The
+        // next group's global loads are issued before the multiplications.
+        constexpr int KPB = 2;       // 4 (64 KB of LDS for the whole pair launch) measured slower: 965 vs 984 pairs/s
+        uint4 ra[KPB][CA], rw[KPB][CW];
+        LnStage lns[KPB];
+#pragma unroll
+        for (int j = 0; j < KPB; ++j)
+            if (kt_lo + j < nk) load_tile_ln((kt_lo + j) * BK, ra[j], rw[j], lns[j]);
+        for (int kt = kt_lo; kt < nk; kt += KPB) {
+#pragma unroll
+            for (int j = 0; j < KPB; ++j)
+                if (kt + j < nk) store_tile_ln(j, ra[j], rw[j], lns[j]);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < KPB; ++j)
+                if (kt + KPB + j < nk) load_tile_ln((kt + KPB + j) * BK, ra[j], rw[j], lns[j]);
+#pragma unroll
+            for (int j = 0; j < KPB; ++j)
+                if (kt + j < nk) compute_tile(j);
+            __syncthreads();
+        }
     } else if (NBUF == 5) {
         // one LDS buffer, THREE register stages: the global loads of K tiles kt+1 and kt+2 are in flight while tile kt is
         // multiplied.  For grids of about one workgroup per CU (the 121-token spatial-reduction convs: 16-80 workgroups
@@ -639,6 +663,7 @@ int g_gemm_nbuf = 1;  // debug/tuning knob (emip_debug_set)
 int g_gemm_tile = 0;  // 0 = heuristic, else BM*1000+BN
 int g_gemm_dbg = 0;
 int g_gemm_glds = 1;  // LDS-DMA main loop for dense GEMMs
+int g_pair_two = 1;   // pair launch: the sr conv walks two K tiles per barrier interval (emip_debug_set key 8)
 int g_gemm_deep = 512;    // 64x64 tiles: 3-stage register prefetch for grids of at most this many workgroups (0 = off)
 int g_gemm_share = 1; // concurrent streams sharing the GPU (tile choice assumes 256 / share CUs); measured: no gain
 
@@ -939,6 +964,8 @@ extern "C" int emip_conv2d_pair(const void* da, const void* db, int dtype, void*
     if (a.lne_stats) {       // dense first problem: two LDS-DMA buffers of a 64x64 tile pair
         if (dtype == EMIP_F32)
             hipLaunchKernelGGL((gemm_pair_kernel<float, 5, true>), dim3(na + nb), dim3(256), 2 * 128 * 128, s, a, b, na);
+        else if (g_pair_two)
+            hipLaunchKernelGGL((gemm_pair_kernel<bf16_t, 6, true>), dim3(na + nb), dim3(256), 2 * 128 * 128, s, a, b, na);
         else
             hipLaunchKernelGGL((gemm_pair_kernel<bf16_t, 5, true>), dim3(na + nb), dim3(256), 2 * 128 * 128, s, a, b, na);
         return emip_launch_status();
@@ -977,6 +1004,10 @@ extern "C" int emip_debug_set(int key, int value) {
     }
     if (key == 6 && value >= 0) {
         g_gemm_deep = value;
+        return EMIP_OK;
+    }
+    if (key == 8) {
+        g_pair_two = value ? 1 : 0;
         return EMIP_OK;
     }
     if (key == 4 && (value == 1 || value == 2 || value == 4 || value == 8)) {
