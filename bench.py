@@ -45,6 +45,10 @@ def _algo_flops(name, a):
         K = {344: 340}.get(K, K)
         byt = 2.0 * batch * (M * K + N * K + M * N * (2 if a[5] else 1))
         return 2.0 * M * N * K * batch, (M, N, batch, False, ("1,ln" if ln else (3 if lds_dma else 1)), a[8]), byt
+    if name == "emip_gemm_lne":      # (A, W, C, bias, R, M, N, K, ...): dense LDS-DMA loop, LayerNorm on the output side
+        M, N, K = a[5], a[6], a[7]
+        byt = 2.0 * (M * K + N * K + M * N * (2 if a[4] else 1))
+        return 2.0 * M * N * K, (M, N, 1, False, 3 if K % 64 == 0 else 1, K), byt
     if name in ("emip_conv2d", "emip_conv2d_ln"):
         B, H, W, Cin, Cout, KH, KW, s, p = a[5], a[6], a[7], a[8], a[10], a[11], a[12], a[13], a[14]
         Ho, Wo = (H + 2 * p - KH) // s + 1, (W + 2 * p - KW) // s + 1
