@@ -10,9 +10,7 @@ What is NOT reproduced: the reference's second conv_corr pass on `corr_bw` (mode
 is never used (65 GFLOP of dead work per frame).
 """
 import torch
-import torch.nn as nn
 
-from ... import ops
 from ...nn_base import EmipModule
 from ..EMIP_short.create_backbone import DimensionalReduction, NeighborConnectionDecoder
 from ..EMIP_short.model import CoUpdater

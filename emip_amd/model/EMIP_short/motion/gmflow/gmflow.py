@@ -13,7 +13,7 @@ import torch.nn as nn
 from ..... import ops
 from .....autograd import (ActFn, BcastAddFn, BilinearPlanarFn, ConcatFn, ConvFn, ConvexUpsampleFn, CorrespToFlowFn,
                            FlowToActFn, GlobalMatchFn, LinearFn)
-from .....nn_base import EmipModule, f32, pack_conv, pack_linear, to_cl, to_planar
+from .....nn_base import EmipModule, f32, pack_conv, pack_linear, to_cl
 from .backbone import CNNEncoder
 from .tables import grid_values, position_table
 from .transformer import FeatureFlowAttention, FeatureTransformer
