@@ -66,7 +66,10 @@ __device__ __forceinline__ int v_off(int row, int c) {
 // BKV = keys per K/V tile: 64 (bf16 streaming), 32 (f32), or 128 (bf16, whole K/V of the 121-key SRA
 // attention resident in one tile: a single pass, no online rescale, one barrier).
 template <typename T, int D, int DV, int BKV>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
+// amdgpu_waves_per_eu(2): left alone, hipcc gives the D = DV = 128 bf16 instance 256 VGPRs + 81 AGPRs (one wave per SIMD);
+// asked for two waves it fits 246 VGPRs without a spill.  A wave that owns the whole register file of its SIMD also
+// keeps every other stream's waves off it: 983 -> 1012 pairs/s in-call.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void attn_kernel(const AttnArgs p) {
     constexpr int ES = sizeof(T);
     constexpr bool BF = ES == 2;
     constexpr int NKT = BKV / 32;
