@@ -648,7 +648,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 // ADENSE: problem a is a plain GEMM over the raw rows with the LayerNorm on the output side (lne_stats / lne_colsum) on the
 // LDS-DMA main loop -- the q projection then neither normalises its operand once per N tile nor stages it through registers.
 template <typename T, int NBUF, bool ADENSE>
-__global__ __launch_bounds__(256) void gemm_pair_kernel(const GemmArgs a, const GemmArgs b, const int na) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void gemm_pair_kernel(const GemmArgs a, const GemmArgs b, const int na) {
     if ((int)blockIdx.x < na) {
         if constexpr (ADENSE) gemm_body<T, 64, 64, false, 3, false>(a, blockIdx.x, 0, 0, na);
         else gemm_body<T, 64, 64, true, NBUF, true, true>(a, blockIdx.x, 0, 0, na);
