@@ -40,8 +40,9 @@ PAIR_Q_SR = True
 # statistics).  No finalize launch, no zero-fill: accumulator and tickets are left zero by every launch.  Parity-tested
 # (tests/test_ops_gpu.py::test_conv_pair_with_fused_split_k) but OFF: in an in-call A/B the 16-pair step went from 970 to
 # 900 pairs/s -- the launch gets shorter in isolation, but under four-stream replay the 1.3 M extra f32 atomics and the
-# 4x workgroups per launch cost more than the shorter dependency chain returns (same verdict as the unfused variant).
-PAIR_KSPLIT = os.environ.get("EMIP_PAIR_KSPLIT", "0") != "0"
+# 4x workgroups per launch cost more than the shorter dependency chain returns (same verdict as the unfused variant; a cap
+# of 2 splits still loses 4 %, 1012 -> 968).  The value is the maximum number of splits.
+PAIR_KSPLIT = int(os.environ.get("EMIP_PAIR_KSPLIT", "0"))        # 0 = off, n = at most n splits
 # Dense GEMMs behind a folded LayerNorm (fc1, kv, the stage-4 q) apply it on the OUTPUT side (emip_gemm_lne):
 # LN(x) W^T = rstd (x W^T) - rstd mean colsum(W).  The operand loader no longer normalises every staged element once per
 # N tile (10x per element for fc1), and the main loop becomes the LDS-DMA one.
@@ -259,7 +260,7 @@ class Block(EmipModule):
             if PAIR_KSPLIT and shared is not None and shared.numel() > 0:
                 tiles = ((Ms + 63) // 64) * ((C + 63) // 64)
                 nk = sr * sr * C // (64 if dt == torch.bfloat16 else 32)
-                ksplit = max(1, min(nk // 4, (256 + tiles - 1) // tiles, 16))      # >= 4 K tiles per split, ~256 workgroups
+                ksplit = max(1, min(nk // 4, (256 + tiles - 1) // tiles, PAIR_KSPLIT))      # >= 4 K tiles per split, ~256 workgroups
                 acc, ticket = shared[:Ms * C], shared[Ms * C:].view(torch.int32)
             ops.conv2d_pair(ops.conv_desc(x, w["q"], 1, 1, 0, w["bq"], q, stats, self.norm1.eps,
                                           colsum=w["sq"] if LN_EPILOGUE else None),
