@@ -484,13 +484,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
             }
         }
         if (!p.ticket) return;
-        // every thread's atomics have been acknowledged once it passes the barrier (s_waitcnt vmcnt(0) + s_barrier); the
-        // ticket then orders this workgroup's contribution before the last arrival's read-back
+        // Order this workgroup's accumulator adds before its ticket: no-return atomics are only known to have landed
+        // once the issuing wave has waited for vmcnt(0) -- a workgroup barrier alone emits no such wait on gfx950 -- so
+        // every wave drains, the workgroup meets, and one lane publishes with an agent-scope release in front of the
+        // ticket increment (the explicit wait after the fence stays: hipcc can drop the fence's own).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(smem);
-        if (tid == 0) *flag = atomicAdd(p.ticket + swz, 1u);
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            *flag = __hip_atomic_fetch_add(p.ticket + swz, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         __syncthreads();
         if (*flag != (unsigned)p.ksplit - 1u) return;
+        if (tid == 0) {        // last arrival: acquire before the read-back (the exchanges below are memory-side atomics)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __syncthreads();
         if (tid == 0) atomicExch(p.ticket + swz, 0u);
 #pragma unroll

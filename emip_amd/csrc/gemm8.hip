@@ -1,0 +1,441 @@
+// 8-wave bf16 MFMA GEMM / implicit-GEMM conv for gfx950 -- the large-launch body of libemip_hip.so.
+//
+//   C[m, n] = act( LNout( sum_k A[m, k] W[n, k] ) + bias[n] ) + R[m, n]          (bf16 in / out, f32 accumulation)
+//
+// Used for every Linear / 1x1 conv / dense conv of the path whose launch is big enough to fill the chip with
+// 128..256-row tiles (PVTv2 q / proj / fc1 / fc2, /root/reference/lib/pvt_v2.py:45-54,101-129; GMFlow q/k/v/merge/FFN,
+// gmflow/transformer.py:128-196; conv_corr, model/EMIP_short/model.py:59-62; GMFlow CNN, gmflow/backbone.py:154-192).
+//
+// Structure (one workgroup = 8 waves = one BM x BN output tile, one workgroup per CU):
+//   * operands go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no ds_write pass.
+//     K tile = 64 bf16 = one 128-B LDS row per tile row; the XOR swizzle (16-B chunk ^ row&7) is applied on the per-lane
+//     SOURCE offset, the LDS image is lane-linear.  Out-of-range rows / channels / padding taps are loaded from an
+//     offset beyond the buffer descriptor's extent, which the hardware returns as zeros.
+//   * NST LDS stages (3 where they fit), ONE raw s_barrier per K tile and a counted s_waitcnt vmcnt(LPT): the loads of
+//     tile kt+1 stay in flight across the barrier while tile kt is multiplied and tile kt+2 is issued.
+//   * the weight tile is the MFMA A operand, so a lane owns 4 consecutive output channels of one row; the W rows of a
+//     32-column block are PERMUTED when they are staged so that the two accumulators of the block give every lane 8
+//     consecutive channels: the epilogue stores 16 B per lane straight from registers (no LDS bounce), with bias /
+//     output-side LayerNorm / GELU / ReLU / residual / row statistics fused.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (stride 0, `bytes` records, 32-bit data format): offsets >= bytes read as zero
+__device__ __forceinline__ i32x4 make_rsrc(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    return i32x4{(int)(unsigned)a, (int)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+
+// One LDS-DMA wave instruction: 64 lanes x 16 B from descriptor `rs` at (voff + soff) into LDS at lds_dst + 16 lane.
+// Written in asm so that hipcc does not know an LDS write is pending: with the builtin it drains vmcnt(0) in front of the
+// first ds_read of every K tile, which serialises the stage ring; the counted waits of the main loop order the data.
+__device__ __forceinline__ void dma16(unsigned lds_dst, unsigned voff, i32x4 rs, int soff) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff)
+        : "memory");
+}
+
+struct G8Args {
+    const bf16_t* A;      // dense: [M, lda]; conv: X [B, H, Wd, ldx = lda]
+    const bf16_t* A2;     // optional second K source (columns K1..K-1 of the logical A), dense only
+    const bf16_t* W;      // [N, ldw]
+    bf16_t* C;            // [M, ldc]
+    const float* bias;    // [N] or null
+    const bf16_t* R;      // [M, ldr] or null (may alias C)
+    int M, N, K, K1;
+    long lda, lda2, ldw, ldc, ldr;
+    int act;
+    const float* lne_stats;    // [M, 2] (sum, sum of squares) of the rows of A: LayerNorm applied on the output side
+    const float* lne_colsum;   // [N] column sums of W
+    float lne_eps;
+    float* out_stats;          // [M, 2]: accumulates (sum, sum of squares) of the stored rows
+    unsigned* zero_ptr;
+    long zero_words;
+    int H, Wd, Cin, KH, KW, stride, pad, Ho, Wo;   // conv geometry (CONV instances)
+    unsigned a_bytes, a2_bytes, w_bytes;            // descriptor extents (< 2^31)
+    int tiles_m, tiles_n;
+};
+
+constexpr unsigned OOB = 0x80000000u;   // beyond every descriptor extent: the load returns zeros
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int WGM, int WGN, int NST, bool CONV>
+__global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;      // wave tile
+    constexpr int TM = WTM / 16, TN = WTN / 16;        // 16x16 accumulators per wave
+    constexpr int NPAIR = TN / 2;                      // 32-column blocks stored 16 B per lane
+    constexpr int R = BM + BN;                         // tile rows per stage (128 B each)
+    constexpr int LPT = R / 64;                        // LDS-DMA instructions per wave per stage
+    constexpr int LA = BM / 64;                        // ... of which the first LA move A rows
+    constexpr int STAGE = R * 128;
+    static_assert(WGM * WGN == 8 && WTM % 16 == 0 && WTN % 16 == 0 && BM % 64 == 0 && BN % 64 == 0, "tile shape");
+    static_assert(NST * STAGE <= 160 * 1024, "LDS");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+
+    if (p.zero_ptr && blockIdx.x == 0)
+        for (long i = tid; i < p.zero_words; i += 512) p.zero_ptr[i] = 0u;
+
+    const i32x4 rsA = make_rsrc(p.A, p.a_bytes);
+    const i32x4 rsA2 = make_rsrc(p.A2 ? p.A2 : p.A, p.A2 ? p.a2_bytes : p.a_bytes);
+    const i32x4 rsW = make_rsrc(p.W, p.w_bytes);
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
+
+    // ---- staging plan: instruction j of this wave moves the 8 tile rows of group g = 8 j + wave ------------------
+    const int lrow = lane >> 3, lslot = lane & 7;
+    const unsigned chunk = (unsigned)(lslot ^ lrow);          // source chunk of this lane's slot (row & 7 == lrow)
+    unsigned arow[LA];        // dense: byte offset of the row in A (or OOB); conv: output pixel index m (or OOB)
+    unsigned arow2[LA];
+    int a_oy[LA], a_ox[LA], a_img[LA];
+    unsigned woff[LPT - LA];
+#pragma unroll
+    for (int j = 0; j < LA; ++j) {
+        const int r = 8 * (8 * j + wave) + lrow;
+        const int m = m0 + r;
+        if (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int b = m / hw, rem = m - b * hw;
+            a_oy[j] = (rem / p.Wo) * p.stride - p.pad;
+            a_ox[j] = (rem % p.Wo) * p.stride - p.pad;
+            a_img[j] = b * p.H;
+            arow[j] = m < p.M ? 0u : OOB;
+            arow2[j] = 0u;
+        } else {
+            arow[j] = m < p.M ? (unsigned)((long)m * p.lda * 2) + chunk * 16u : OOB;
+            arow2[j] = m < p.M ? (unsigned)((long)m * p.lda2 * 2) + chunk * 16u : OOB;
+            a_oy[j] = a_ox[j] = a_img[j] = 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < LPT - LA; ++j) {
+        const int pr = 8 * (8 * j + wave) + lrow;              // W tile row
+        const int wv = pr / WTN, wi = pr % WTN;
+        int nl = wi;
+        if (wi < 32 * NPAIR) {                                  // paired 16-blocks: (i -> 8 (i >> 2) + 4 half + (i & 3))
+            const int i = wi & 15;
+            nl = (wi & ~31) + 8 * (i >> 2) + 4 * ((wi >> 4) & 1) + (i & 3);
+        }
+        const int n = n0 + wv * WTN + nl;
+        woff[j] = n < p.N ? (unsigned)((long)n * p.ldw * 2) + chunk * 16u : OOB;
+    }
+
+    const int ctiles = CONV ? (p.Cin + 63) / 64 : 0;
+    const int nk = CONV ? p.KH * p.KW * ctiles : p.K / 64;
+
+    auto issue = [&](int kt, int stage) {
+        const unsigned base = lds0 + stage * STAGE + wave * 1024;
+        if (CONV) {
+            const int tap = kt / ctiles, c0 = (kt - tap * ctiles) * 64;
+            const int ky = tap / p.KW, kx = tap - ky * p.KW;
+            const bool cok = c0 + (int)chunk * 8 < p.Cin;
+#pragma unroll
+            for (int j = 0; j < LA; ++j) {
+                const int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
+                const bool ok = cok && arow[j] == 0u && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                const unsigned off = ok ? (unsigned)(((long)(a_img[j] + iy) * p.Wd + ix) * p.lda * 2) + (c0 + chunk * 8) * 2 : OOB;
+                dma16(base + j * 8192, off, rsA, 0);
+            }
+            const int kw0 = (tap * p.Cin + c0) * 2;
+#pragma unroll
+            for (int j = 0; j < LPT - LA; ++j)
+                dma16(base + (LA + j) * 8192, cok ? woff[j] : OOB, rsW, kw0);
+        } else {
+            const int k0 = kt * 64;
+            if (k0 < p.K1) {
+#pragma unroll
+                for (int j = 0; j < LA; ++j)
+                    dma16(base + j * 8192, arow[j], rsA, k0 * 2);
+            } else {
+#pragma unroll
+                for (int j = 0; j < LA; ++j)
+                    dma16(base + j * 8192, arow2[j], rsA2, (k0 - p.K1) * 2);
+            }
+#pragma unroll
+            for (int j = 0; j < LPT - LA; ++j)
+                dma16(base + (LA + j) * 8192, woff[j], rsW, k0 * 2);
+        }
+    };
+
+    // ---- main loop ------------------------------------------------------------------------------------------------
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int loff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) loff[ks] = fr * 128 + (((ks * 4 + fq) ^ (lane & 7)) * 16);
+    const int a_base = wm * WTM * 128, w_base = (BM + wn * WTN) * 128;
+
+    auto compute = [&](int stage) {
+        const char* sb = smem + stage * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 af[TM], wf[TN];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const uint4*>(sb + w_base + b * 2048 + loff[ks]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const uint4*>(sb + a_base + a * 2048 + loff[ks]);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]),
+                                                                        __builtin_bit_cast(bf16x8, af[a]), acc[a][b], 0, 0, 0);
+        }
+    };
+
+    issue(0, 0);
+    if (NST == 3 && nk > 1) issue(1, 1);
+    int st = 0;        // stage of tile kt
+    for (int kt = 0; kt < nk; ++kt) {
+        if (NST == 3) {
+            if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 2 < nk) issue(kt + 2, st >= 1 ? st - 1 : 2);        // (st + 2) % 3
+            compute(st);
+            st = st == 2 ? 0 : st + 1;
+        } else {
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + 1 < nk) issue(kt + 1, st ^ 1);     // stage st^1 was read in iteration kt-1: every wave is past it
+            compute(st);
+            st ^= 1;
+        }
+    }
+
+    // ---- epilogue: registers -> HBM, 16 B per lane --------------------------------------------------------------
+    const int nb = n0 + wn * WTN;
+    const bool gelu = p.act == EMIP_ACT_GELU, relu = p.act == EMIP_ACT_RELU;
+    const float invK = 1.f / (float)p.K;
+    const bool vec_ok = ((p.ldc & 7) == 0) && (!p.R || (p.ldr & 7) == 0);
+    float bv[NPAIR > 0 ? NPAIR : 1][8], cs[NPAIR > 0 ? NPAIR : 1][8];     // this lane's 8 channels of every 32-column block
+#pragma unroll
+    for (int pb = 0; pb < NPAIR; ++pb) {
+        const int n = nb + 32 * pb + 8 * fq;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int nc = min(n + j, p.N - 1);
+            bv[pb][j] = p.bias ? p.bias[nc] : 0.f;
+            cs[pb][j] = p.lne_stats ? p.lne_colsum[nc] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int m = m0 + wm * WTM + 16 * a + fr;
+        const bool mok = m < p.M;
+        float rs = 1.f, mrs = 0.f;
+        if (p.lne_stats) {
+            const float2 s2 = *reinterpret_cast<const float2*>(p.lne_stats + 2 * (long)min(m, p.M - 1));
+            const float mu = s2.x * invK;
+            rs = rsqrtf(fmaxf(s2.y * invK - mu * mu, 0.f) + p.lne_eps);
+            mrs = mu * rs;
+        }
+        float st1 = 0.f, st2 = 0.f;
+#pragma unroll
+        for (int pb = 0; pb < NPAIR; ++pb) {
+            const int n = nb + 32 * pb + 8 * fq;
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = acc[a][2 * pb][j];
+                v[4 + j] = acc[a][2 * pb + 1][j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float x = fmaf(v[j], rs, fmaf(-mrs, cs[pb][j], bv[pb][j]));
+                if (gelu) x = gelu_t<bf16_t>(x);
+                else if (relu) x = fmaxf(x, 0.f);
+                v[j] = x;
+            }
+            if (mok && n < p.N) {
+                bf16_t* cp = p.C + (long)m * p.ldc + n;
+                if (vec_ok && n + 8 <= p.N) {
+                    if (p.R) {
+                        const uint4 rr = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+                        const bf16_t* rv = reinterpret_cast<const bf16_t*>(&rr);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+                    }
+                    uint4 ov;
+                    bf16_t* o = reinterpret_cast<bf16_t*>(&ov);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        o[j] = (bf16_t)v[j];
+                        const float q = (float)o[j];
+                        st1 += q;
+                        st2 += q * q;
+                    }
+                    *reinterpret_cast<uint4*>(cp) = ov;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        if (n + j < p.N) {
+                            float x = v[j];
+                            if (p.R) x += (float)p.R[(long)m * p.ldr + n + j];
+                            const bf16_t o = (bf16_t)x;
+                            cp[j] = o;
+                            st1 += (float)o;
+                            st2 += (float)o * (float)o;
+                        }
+                    }
+                }
+            }
+        }
+        if (TN & 1) {          // unpaired last 16-block: 4 channels (8 B) per lane
+            const int n = nb + 32 * NPAIR + 4 * fq;
+            if (n < p.N && mok) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (n + j < p.N) {
+                        float x = fmaf(acc[a][TN - 1][j], rs, fmaf(-mrs, p.lne_stats ? p.lne_colsum[n + j] : 0.f,
+                                                                    p.bias ? p.bias[n + j] : 0.f));
+                        if (gelu) x = gelu_t<bf16_t>(x);
+                        else if (relu) x = fmaxf(x, 0.f);
+                        if (p.R) x += (float)p.R[(long)m * p.ldr + n + j];
+                        const bf16_t o = (bf16_t)x;
+                        p.C[(long)m * p.ldc + n + j] = o;
+                        st1 += (float)o;
+                        st2 += (float)o * (float)o;
+                    }
+                }
+            }
+        }
+        if (p.out_stats) {      // the 4 lanes fr, fr+16, fr+32, fr+48 hold the same row
+            st1 += __shfl_xor(st1, 16);
+            st2 += __shfl_xor(st2, 16);
+            st1 += __shfl_xor(st1, 32);
+            st2 += __shfl_xor(st2, 32);
+            if (fq == 0 && mok) {
+                atomicAdd(p.out_stats + 2 * (long)m, st1);
+                atomicAdd(p.out_stats + 2 * (long)m + 1, st2);
+            }
+        }
+    }
+}
+
+struct Cfg {
+    int bm, bn, nst;
+    void (*dense)(const G8Args);
+    void (*conv)(const G8Args);
+};
+
+#define G8_CFG(BM, BN, WGM, WGN, NST) \
+    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>}
+
+const Cfg g_cfg[] = {
+    G8_CFG(256, 128, 4, 2, 3),   // 1: wave 64 x 64
+    G8_CFG(128, 256, 2, 4, 3),   // 2: wave 64 x 64
+    G8_CFG(128, 128, 2, 4, 3),   // 3: wave 64 x 32
+    G8_CFG(128, 320, 2, 4, 2),   // 4: wave 64 x 80 (N = 320 in one tile)
+    G8_CFG(64, 320, 2, 4, 3),    // 5: wave 32 x 80
+    G8_CFG(256, 64, 4, 2, 3),    // 6: wave 64 x 32
+    G8_CFG(256, 256, 2, 4, 2),   // 7: wave 128 x 64
+    G8_CFG(128, 64, 4, 2, 3),    // 8: wave 32 x 32
+    G8_CFG(64, 128, 2, 4, 3),    // 9: wave 32 x 32
+};
+constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
+
+int pick_cfg(int M, int N, long K) {
+    // fewest padded MACs among the tiles that give at least ~one workgroup per CU, larger tiles first on ties
+    int best = 3;
+    double best_cost = 1e30;
+    for (int c = 1; c <= NCFG; ++c) {
+        const Cfg& g = g_cfg[c - 1];
+        const long tm = (M + g.bm - 1) / g.bm, tn = (N + g.bn - 1) / g.bn;
+        const long tiles = tm * tn;
+        const long rounds = (tiles + 255) / 256;
+        // time model: rounds x (tile MACs / CU rate + fixed per-tile cost), small tiles pay more LDS traffic per MAC
+        const double tile_macs = (double)g.bm * g.bn * (double)K;
+        const double eff = 1.0 / (1.0 + 48.0 * (1.0 / g.bm + 1.0 / g.bn));     // operand bytes per MAC penalty
+        const double cost = rounds * (tile_macs / eff + 3.0e6);
+        if (cost < best_cost) { best_cost = cost; best = c; }
+    }
+    return best;
+}
+
+int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
+    G8Args a = a0;
+    if (cfg <= 0 || cfg > NCFG) cfg = pick_cfg(a.M, a.N, conv ? (long)a.KH * a.KW * a.Cin : a.K);
+    const Cfg& g = g_cfg[cfg - 1];
+    a.tiles_m = (a.M + g.bm - 1) / g.bm;
+    a.tiles_n = (a.N + g.bn - 1) / g.bn;
+    const size_t lds = (size_t)g.nst * (g.bm + g.bn) * 128;
+    auto fn = conv ? g.conv : g.dense;
+    static bool attr_done[NCFG][2];
+    if (!attr_done[cfg - 1][conv]) {
+        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return EMIP_E_LAUNCH;
+        attr_done[cfg - 1][conv] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+    return emip_launch_status();
+}
+
+}  // namespace
+
+extern "C" int emip_gemm8_auto_cfg(int M, int N, int K) { return pick_cfg(M, N, K); }
+
+extern "C" int emip_gemm8(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M,
+                          int N, int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act,
+                          const float* lne_stats, const float* lne_colsum, float lne_eps, float* out_stats, void* zero_ptr,
+                          long zero_bytes, int cfg, void* stream) {
+    EMIP_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && (K % 64) == 0);
+    EMIP_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C) && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= (A2 ? K1 : K) &&
+                 ldw >= K && ldc >= N);
+    EMIP_REQUIRE(!R || (aligned16(R) && ldr >= N));
+    EMIP_REQUIRE(!A2 || (aligned16(A2) && K1 > 0 && K1 < K && (K1 % 64) == 0 && (lda2 % 8) == 0 && lda2 >= K - K1));
+    EMIP_REQUIRE(!lne_stats || lne_colsum);
+    EMIP_REQUIRE((zero_bytes % 4) == 0 && (!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 3u) == 0));
+    const long ab = ((long)(M - 1) * lda + (A2 ? K1 : K)) * 2, wb = ((long)(N - 1) * ldw + K) * 2;
+    const long a2b = A2 ? ((long)(M - 1) * lda2 + (K - K1)) * 2 : 0;
+    EMIP_REQUIRE(ab < (1L << 31) && wb < (1L << 31) && a2b < (1L << 31));
+    G8Args a = {};
+    a.A = (const bf16_t*)A; a.A2 = (const bf16_t*)A2; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias;
+    a.R = (const bf16_t*)R; a.M = M; a.N = N; a.K = K; a.K1 = A2 ? K1 : K; a.lda = lda; a.lda2 = A2 ? lda2 : 0; a.ldw = ldw;
+    a.ldc = ldc; a.ldr = ldr; a.act = act; a.lne_stats = lne_stats; a.lne_colsum = lne_colsum; a.lne_eps = lne_eps;
+    a.out_stats = out_stats; a.zero_ptr = (unsigned*)zero_ptr; a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
+    a.a_bytes = (unsigned)ab; a.a2_bytes = (unsigned)a2b; a.w_bytes = (unsigned)wb;
+    return launch(a, cfg, false, (hipStream_t)stream);
+}
+
+extern "C" int emip_conv8(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd,
+                          int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act,
+                          float* out_stats, void* zero_ptr, long zero_bytes, int cfg, void* stream) {
+    EMIP_REQUIRE(X && W && Y && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    EMIP_REQUIRE((Cin % 8) == 0 && (ldx % 8) == 0 && ldx >= Cin && aligned16(X) && aligned16(W) && aligned16(Y) && ldy >= Cout);
+    EMIP_REQUIRE(!R || (aligned16(R) && ldr >= Cout));
+    EMIP_REQUIRE((zero_bytes % 4) == 0 && (!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 3u) == 0));
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
+    EMIP_REQUIRE(Ho > 0 && Wo > 0);
+    const long ab = (((long)B * H * Wd - 1) * ldx + Cin) * 2, wb = (long)Cout * KH * KW * Cin * 2;
+    EMIP_REQUIRE(ab < (1L << 31) && wb < (1L << 31) && (long)B * Ho * Wo < (1L << 31));
+    G8Args a = {};
+    a.A = (const bf16_t*)X; a.W = (const bf16_t*)W; a.C = (bf16_t*)Y; a.bias = bias; a.R = (const bf16_t*)R;
+    a.M = B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin; a.K1 = a.K; a.lda = ldx; a.ldw = (long)KH * KW * Cin; a.ldc = ldy;
+    a.ldr = ldr; a.act = act; a.out_stats = out_stats; a.zero_ptr = (unsigned*)zero_ptr;
+    a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
+    a.H = H; a.Wd = Wd; a.Cin = Cin; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.Ho = Ho; a.Wo = Wo;
+    a.a_bytes = (unsigned)ab; a.w_bytes = (unsigned)wb;
+    return launch(a, cfg, true, (hipStream_t)stream);
+}

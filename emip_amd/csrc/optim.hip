@@ -67,8 +67,9 @@ extern "C" int emip_clamp_adamw(const void* recs, const void* blockmap, int nblo
                                 float beta2, float eps, float weight_decay, float clip, int step, void* stream) {
     EMIP_REQUIRE(recs && blockmap && nblocks > 0 && step >= 1 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f &&
                  beta2 >= 0.f && beta2 < 1.f);
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+    // bias corrections in double on the host, as torch.optim.AdamW evaluates them (float powf is ~6e-5 relative off at small t)
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(clamp_adamw_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream,
                        (const TensorRec*)recs, (const int2*)blockmap, lr, beta1, beta2, eps, weight_decay, clip, bc1,
                        bc2s);

@@ -88,6 +88,58 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=No
     return out
 
 
+def gemm8(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=None, ln_eps=0.0, colsum=None,
+          out_stats=None, zero=None, cfg=0):
+    """emip_gemm8: the 8-wave bf16 body (same arithmetic and hooks as `gemm`; the LayerNorm hook is the output-side form)"""
+    M, K1, lda = rows(a)
+    N, K = w.shape
+    lda2 = 0
+    if a2 is not None:
+        M2, K2, lda2 = rows(a2)
+        assert M2 == M and K1 + K2 == K
+    else:
+        assert K1 == K, (K1, K)
+    assert a.dtype == torch.bfloat16 and w.dtype == a.dtype and w.is_contiguous()
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
+    Mo, No, ldc = rows(out)
+    assert Mo == M and No == N and out.dtype == a.dtype
+    ldr = 0
+    if res is not None:
+        Mr, Nr, ldr = rows(res)
+        assert Mr == M and Nr == N and res.dtype == a.dtype
+    for t in (ln_stats, out_stats):
+        assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == 2 * M)
+    assert (ln_stats is None) == (colsum is None)
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == N)
+    _lib.call("emip_gemm8", _p(a), _p(a2), _p(w), _p(out), _p(bias), _p(res), M, N, K, K1, lda, lda2, K, ldc, ldr, act,
+              _p(ln_stats), _p(colsum), float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), int(cfg), _stream())
+    return out
+
+
+def conv8(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None, zero=None, out_stats=None, cfg=0):
+    """emip_conv8: implicit-GEMM conv on the 8-wave bf16 body; x [B,H,W,Cin] channels-last, w packed [Cout, kh*kw*Cin]"""
+    _dev(x)
+    B, H, W, Cin = x.shape
+    assert x.stride(-1) == 1 and x.stride(1) == W * x.stride(2) and (B == 1 or x.stride(0) == H * x.stride(1))
+    ldx = x.stride(2)
+    Cout = w.shape[0]
+    assert w.shape[1] == kh * kw * Cin and w.is_contiguous() and w.dtype == x.dtype == torch.bfloat16
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    Mo, No, ldy = rows(out)
+    assert Mo == B * Ho * Wo and No == Cout
+    ldr = 0
+    if res is not None:
+        Mr, Nr, ldr = rows(res)
+        assert Mr == Mo and Nr == Cout
+    _lib.call("emip_conv8", _p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, ldx, Cout, kh, kw, stride, pad, ldy,
+              ldr, act, _p(out_stats), _p(zero), _nbytes(zero), int(cfg), _stream())
+    return out
+
+
 def gemm_batched(a, w, out, batch, M, N, K, lda, ldw, ldc, bsA, bsW, bsC):
     """Strided-batched gemm on raw views (a, w, out are tensors whose data_ptr is the first operand)."""
     _dev(a)

@@ -18,7 +18,8 @@ class FusedClampAdamW(torch.optim.Optimizer):
 
     def _table(self, gi, plist):
         """device tables for one param group; rebuilt if the tensors' storage moved"""
-        key = tuple((p.data_ptr(), p.grad.data_ptr()) for p in plist)
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(),
+                     self.state[p]["exp_avg_sq"].data_ptr()) for p in plist)
         hit = self._tables.get(gi)
         if hit is not None and hit[0] == key:
             return hit[1], hit[2], hit[3]
@@ -49,7 +50,7 @@ class FusedClampAdamW(torch.optim.Optimizer):
                     st["step"] = 0
                     st["exp_avg"] = torch.zeros_like(p)
                     st["exp_avg_sq"] = torch.zeros_like(p)
-            steps = {self.state[p]["step"] for p in plist}
+            steps = {int(self.state[p]["step"]) for p in plist}       # torch.optim.AdamW keeps `step` as a tensor
             assert len(steps) == 1, "parameters of one group must share the step count"
             step = steps.pop() + 1
             recs, bmap, nb = self._table(gi, plist)
@@ -58,5 +59,13 @@ class FusedClampAdamW(torch.optim.Optimizer):
                       float(b2), float(group["eps"]), float(group["weight_decay"]), float(group["clip"] or 0.0), step,
                       torch.cuda.current_stream().cuda_stream)
             for p in plist:
-                self.state[p]["step"] = step
+                st = self.state[p]
+                st["step"] = (st["step"].new_tensor(float(step)) if torch.is_tensor(st["step"]) else step)
+            # The kernel wrote the parameters (and moments) through raw pointers: bump the version counters so every
+            # cache keyed on them (EmipModule.packed: bf16 copies, conv / dgrad packs, folded norms) is rebuilt.
+            torch.autograd.graph.increment_version(plist)
         return loss
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._tables.clear()                      # the moment tensors were replaced: their pointers are in the tables

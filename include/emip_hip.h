@@ -73,6 +73,23 @@ int emip_gemm_lne(const void* A, const void* W, void* C, const float* bias, cons
                   long ldw, long ldc, long ldr, int act, const float* ln_stats, const float* colsum, float ln_eps,
                   float* out_stats, void* zero_ptr, long zero_bytes, int dtype, void* stream);
 
+/* The large-launch bf16 body of emip_gemm / emip_gemm_ln(e) / emip_conv2d (gemm8.hip): 8-wave workgroups, 64..256-row
+ * output tiles, operands by LDS-DMA through a 2-3 stage ring, epilogue stored 16 B per lane from registers.  Same
+ * arithmetic and the same hooks as above (bias, output-side LayerNorm from ln_stats + colsum, GELU / ReLU, residual R,
+ * out_stats of the stored rows, zero_ptr scratch), bf16 only, one problem per launch.  Replaces the same reference call
+ * sites as emip_gemm (nn.Linear: lib/pvt_v2.py:45-54,101-129; gmflow/transformer.py:128-196) and emip_conv2d
+ * (nn.Conv2d: model/EMIP_short/model.py:59-62 conv_corr; gmflow/backbone.py:44-47,83,97).
+ * Requirements (else EMIP_E_INVALID): K % 64 == 0 (dense), Cin % 8 == 0 (conv), lda / ldw / ldx % 8 == 0, 16-byte aligned
+ * bases, every operand extent < 2 GiB.  cfg: 0 = tile chosen by emip_gemm8_auto_cfg, 1.. = explicit (calibration). */
+int emip_gemm8(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M, int N,
+               int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, const float* ln_stats,
+               const float* colsum, float ln_eps, float* out_stats, void* zero_ptr, long zero_bytes, int cfg,
+               void* stream);
+int emip_conv8(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd, int Cin,
+               long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act, float* out_stats,
+               void* zero_ptr, long zero_bytes, int cfg, void* stream);
+int emip_gemm8_auto_cfg(int M, int N, int K);
+
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
 int emip_gemm_tile(long M, long N, long batch, long K);
 
