@@ -1,7 +1,11 @@
 #!/usr/bin/env python3
 """Benchmark of the EMIP two-stream hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]        (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1: either the driver launches the ranks (torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK) or, when they
+are not set, this script starts `python -m torch.distributed.run --nproc-per-node N bench.py ...` itself as a fresh child
+process BEFORE any GPU call (/root/reference/train.py:185-219 sets its ranks up the same way) and exits with its code.
 
 A step = one EMIP-short inference forward (CoUpdater.forward) over a batch of 16 synthetic 352x352 frame
 pairs per GPU in bf16 (BASELINE.json configs[1]), inputs resident in HBM, replayed as a hipGraph.
@@ -37,7 +41,7 @@ def _algo_flops(name, a):
         byt = 2.0 * z * (Lq * D + Lk * D + Lk * dv) + (4.0 if a[-3] else 2.0) * z * Lq * dv
         if a[4]:                                            # raw scores (the correlation volume) written out
             byt += 2.0 * z * Lq * Lk
-        return 2.0 * z * Lq * Lk * (D + dv), ("attn", D, DV, bkv), byt
+        return 2.0 * z * Lq * Lk * (D + dv), ("attn", D, DV, bkv, "+scores" if a[4] else ""), byt
     if name in ("emip_gemm", "emip_gemm_ln"):
         M, N, K, batch = a[6], a[7], a[8], a[16]
         ln = name == "emip_gemm_ln" and a[21] is not None     # normalising loader: the register-staged loop
@@ -88,7 +92,7 @@ def kernel_breakdown(net, im1, im2, splits=1):
         fl, tile, byt = _algo_flops(name, a)
         key = name
         if tile is not None and tile[0] == "attn":
-            key = "attn_kernel<bf16,%d,%d,%d>" % tile[1:]
+            key = "attn_kernel<bf16,%d,%d,%d>%s" % tile[1:]
         elif tile is not None:
             t = lib.emip_gemm_tile(tile[0], tile[1], tile[2], tile[5])
             key = "gemm_kernel<bf16,%d,%d,%s,%s>" % (t // 1000, t % 1000, "conv" if tile[3] else "dense", tile[4])
@@ -108,7 +112,7 @@ def rocprof_avg(key):
     path = os.path.join(ROOT, "profiles", "r01_bench_kernel_stats_final.csv")
     if not os.path.exists(path):
         return None
-    m = re.match(r"(gemm|attn)_kernel<bf16,(.*)>", key)
+    m = re.match(r"(gemm|attn)_kernel<bf16,(.*)>", key.replace("+scores", ""))
     if not m:
         return None
     f = m.group(2).split(",")
@@ -121,6 +125,31 @@ def rocprof_avg(key):
         if pat in r["Name"]:
             return round(float(r["AverageNs"]) / 1e3, 2)
     return None
+
+
+def named_roofline(agg, key, what):
+    """roofline record (same fields as `roofline`) of one named contraction, from the per-launch HIP-event timings"""
+    v = agg.get(key)
+    if v is None or v[0] <= 0:
+        return None
+    ms, fl, cnt, byt = v
+    tflops, tbs = fl / (ms * 1e-3) / 1e12, byt / (ms * 1e-3) / 1e12
+    ai = fl / max(byt, 1.0)
+    hbm = ai < PEAK_BF16_TFLOPS / PEAK_HBM_TBS
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tf):
+        traffic = json.load(open(tf)).get(key, {}).get("hbm_bytes_per_launch")
+    rec = ({"bound": "hbm", "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
+            "frac": round(tbs / PEAK_HBM_TBS, 4)} if hbm else
+           {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tflops / PEAK_BF16_TFLOPS, 4)})
+    rec.update({"kernel": key, "what": what, "traffic": traffic, "achieved_TFLOPs": round(tflops, 2),
+                "mfma_frac": round(tflops / PEAK_BF16_TFLOPS, 4), "arithmetic_intensity_flop_per_byte": round(ai, 1),
+                "hbm_bound_ceiling_TFLOPs": round(ai * PEAK_HBM_TBS, 1), "launches": cnt,
+                "algorithmic_bytes_per_launch": round(byt / cnt), "algorithmic_flops_per_launch": round(fl / cnt),
+                "avg_launch_us": round(ms / cnt * 1e3, 2), "rocprofv3_avg_launch_us": rocprof_avg(key)})
+    return rec
 
 
 def cpu_baseline(sd):
@@ -168,22 +197,34 @@ def parity_figures(net_bf16, margs, sd, ref_mask, dev):
             "pair": "synthetic seed 1234, batch 1"}
 
 
-def main_train(args):
-    """--workload train: BASELINE.json configs[2] / configs[4] -- one EMIP-short training step (forward, hybrid_e_loss +
-    unFlowLoss, backward, bucketed gradient all-reduce over RCCL when N > 1, fused clamp + AdamW) on a batch of 32
-    synthetic pairs per GPU in bf16.  Reported beside, never instead of, the inference headline."""
+def _dist_setup():
+    """(world, rank, device, dist-or-None, device for the timing reductions); EMIP_DIST_BACKEND=gloo = rehearsal of the
+    N > 1 code path on a box with fewer GPUs than ranks (ranks share devices)"""
     from emip_amd import dist as edist
     world, rank, local = edist.env_world()
-    dist = None
-    # EMIP_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices)
-    backend = os.environ.get("EMIP_DIST_BACKEND", "nccl")
+    backend = os.environ.get("EMIP_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm
     local = local % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
-    if world > 1:
-        dist = edist.init(backend)
+    dist = edist.init(backend) if world > 1 else None
     dev = torch.device("cuda", local)
-    red_dev = dev if backend == "nccl" else "cpu"
-    from emip_amd import _lib, nn_base
+    return world, rank, dev, dist, (dev if backend == "nccl" else "cpu")
+
+
+def _barrier(dist):
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+F_ALG_TRAIN_PAIR_GFLOP = 702.0   # SURVEY.md section 8(d): fwd F + dgrad where a trainable consumer exists + wgrad for trainable layers
+F_ALG_LONG_FRAME_GFLOP = 280.63  # F_alg(short) + 10 GF (LTM convs, memory read, long_dr, second injector / decoder)
+
+
+def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev):
+    """BASELINE.json configs[2] / configs[4]: one EMIP-short training step (forward, hybrid_e_loss + unFlowLoss, backward,
+    bucketed gradient all-reduce over RCCL when N > 1, fused clamp + AdamW) on B synthetic pairs per GPU in bf16."""
+    from emip_amd import _lib, dist as edist, nn_base
     from emip_amd.dp import GradReducer, broadcast_parameters
     from emip_amd.filler import state_dict_from_manifest, synthetic_gt, synthetic_pair
     from emip_amd.model.EMIP_short.model import CoUpdater
@@ -199,58 +240,56 @@ def main_train(args):
     broadcast_parameters(net)
     opt = build_optimizer(net)
     red = GradReducer(trainable(net)) if world > 1 else None
-    B = args.pairs or 32
     im1, im2 = synthetic_pair(B, seed=edist.pair_seed(1234, rank))
     gt = synthetic_gt(B, seed=edist.pair_seed(99, rank))
     im1, im2, gt = im1.to(dev), im2.to(dev), gt.to(dev)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     loss = None
-    for _ in range(args.warmup):
+    torch.cuda.reset_peak_memory_stats(dev)
+    for _ in range(warmup):
         loss = train_step(net, opt, red, im1, im2, gt)
-    barrier()
+    _barrier(dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         loss = train_step(net, opt, red, im1, im2, gt)
-    barrier()
+    _barrier(dist)
     dt = edist.max_over_ranks(time.perf_counter() - t0, red_dev)
+    value = world * B * steps / dt
+    rec = {
+        "metric": "frame_pairs_per_sec_352x352_emip_short_train_step", "value": round(value, 3),
+        "unit": "pairs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "EMIP-short training step (fwd + hybrid_e_loss + unFlowLoss + bwd + clamp/AdamW), "
+                               "batch=%d 352x352 pairs per GPU, bf16 storage / f32 accumulate and f32 master "
+                               "weights, DropPath 0.1, GMFlow frozen" % B,
+                   "pairs_per_gpu": B, "parallelism": "dp%d (bucketed all-reduce over RCCL)" % world},
+        "achieved_TFLOPs_per_gpu": round(value / world * F_ALG_TRAIN_PAIR_GFLOP / 1e3, 1),
+        "frac_of_bf16_mfma_peak": round(value / world * F_ALG_TRAIN_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
+        "flops_convention": "702 GFLOP per pair (SURVEY.md 8d)",
+        "last_loss": [round(float(x), 5) for x in loss],
+        "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+    if red is not None:
+        red.remove()
+    del net, opt, red
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main_train(args):
+    """--workload train: reported beside, never instead of, the inference headline."""
+    world, rank, dev, dist, red_dev = _dist_setup()
+    rec = measure_train(args.pairs or 32, args.steps, args.warmup, world, rank, dev, dist, red_dev)
     if rank == 0:
-        print(json.dumps({
-            "metric": "frame_pairs_per_sec_352x352_emip_short_train_step", "value": round(world * B * args.steps / dt, 3),
-            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "EMIP-short training step (fwd + hybrid_e_loss + unFlowLoss + bwd + clamp/AdamW), "
-                                   "batch=%d 352x352 pairs per GPU, bf16 storage / f32 accumulate and f32 master "
-                                   "weights, DropPath 0.1, GMFlow frozen" % B,
-                       "pairs_per_gpu": B, "parallelism": "dp%d (bucketed all-reduce over RCCL)" % world},
-            "last_loss": [round(float(x), 5) for x in loss],
-            "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}), flush=True)
+        print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def main_long(args):
-    """--workload long: BASELINE.json configs[3] -- EMIP-long historical-prompt inference, 8 independent video streams
-    per GPU, steady state (5-frame memory window full, memory fed back from the previous step), bf16, eager launches."""
-    from emip_amd import dist as edist
-    world, rank, local = edist.env_world()
-    dist = None
-    # EMIP_DIST_BACKEND=gloo: rehearsal of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices)
-    backend = os.environ.get("EMIP_DIST_BACKEND", "nccl")
-    local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    if world > 1:
-        dist = edist.init(backend)
-    dev = torch.device("cuda", local)
-    red_dev = dev if backend == "nccl" else "cpu"
-    from emip_amd import _lib, nn_base
+def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=False, streams=2):
+    """BASELINE.json configs[3]: EMIP-long historical-prompt inference, S independent video streams per GPU, steady state
+    (5-frame memory window full, memory fed back from the previous step), bf16."""
+    from emip_amd import _lib, dist as edist, nn_base
     from emip_amd.filler import state_dict_from_manifest, synthetic_pair
     from emip_amd.model.EMIP_long.model_long import Model_long
     _lib.load()
@@ -261,7 +300,6 @@ def main_long(args):
     net = Model_long(margs)
     net.load_state_dict(sd)
     net = net.to(dev).eval()
-    S = args.pairs or 8
     f0, f1 = synthetic_pair(S, seed=edist.pair_seed(1234, rank))
     f0, f1 = f0.to(dev), f1.to(dev)
     state = {"k": None, "v": None, "i": 0}
@@ -271,42 +309,121 @@ def main_long(args):
             _, k, v = net.forward_streams(f0, f1, state["i"], state["k"], state["v"])
         state["k"], state["v"], state["i"] = k, v, state["i"] + 1
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(Model_long.WINDOW + 2):                        # fill the memory window before timing
         eager_step()
-    if args.no_graph:
+    nsplit = 1
+    if no_graph:
         step = eager_step
     else:
         from emip_amd.graph import GraphedLong
-        runner = GraphedLong(net, S, device=dev, splits=min(args.streams, 2))    # 8 streams: 2 graphs x 4 measured best
+        runner = GraphedLong(net, S, device=dev, splits=min(streams, 2))    # 8 streams: 2 graphs x 4 measured best
+        nsplit = runner.splits
         runner.seed_memory(state["k"], state["v"])
         runner.load(f0, f1)
         torch.cuda.synchronize()
         step = runner.replay_free
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
-    barrier()
+    _barrier(dist)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    _barrier(dist)
+    dt = edist.max_over_ranks(time.perf_counter() - t0, red_dev)
+    value = world * S * steps / dt
+    rec = {
+        "metric": "stream_frames_per_sec_352x352_emip_long", "value": round(value, 3),
+        "unit": "frames/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": round(dt / steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "EMIP-long inference step (short-term forward + LTM memorize/segment over a 5-frame "
+                               "window + long decoder), %d video streams per GPU, bf16" % S,
+                   "streams_per_gpu": S, "memory_frames": int(state["k"].shape[3]), "hipgraph": not no_graph,
+                   "concurrent_streams": nsplit,
+                   "parallelism": "dp%d (independent replicas, no collective)" % world},
+        "achieved_TFLOPs_per_gpu": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3, 1),
+        "frac_of_bf16_mfma_peak": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
+        "flops_convention": "F_alg(short) 270.63 + 10 GFLOP per stream-frame (SURVEY.md 8d)"}
+    del net
+    if not no_graph:
+        del runner
+    torch.cuda.empty_cache()
+    return rec
+
+
+def main_long(args):
+    """--workload long: reported beside, never instead of, the inference headline."""
+    world, rank, dev, dist, red_dev = _dist_setup()
+    rec = measure_long(args.pairs or 8, args.steps, args.warmup, world, rank, dev, dist, red_dev, args.no_graph,
+                       args.streams)
+    if rank == 0:
+        print(json.dumps(rec), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def measure_f32_mode(margs, sd, im1, im2, dev, steps=3):
+    """pairs/s of the f32 PARITY mode (exact-f32 MFMA, the mode in which the 1e-3 mask bound holds) on the same batch"""
+    from emip_amd import nn_base
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    nn_base.set_default_dtype(torch.float32)
+    try:
+        net32 = CoUpdater(margs)
+        net32.load_state_dict(sd)
+        net32 = net32.to(dev).eval()
+        with torch.no_grad():
+            net32.run(im1, im2)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                net32.run(im1, im2)
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        nn_base.set_default_dtype(torch.bfloat16)
+    del net32
+    torch.cuda.empty_cache()
+    return {"value": round(im1.shape[0] / dt, 2), "unit": "pairs/s", "ms_per_step": round(dt * 1e3, 2), "dtype": "f32",
+            "note": "eager launches, batch %d, exact-f32 MFMA (1/16 of the bf16 rate)" % im1.shape[0]}
+
+
+def launch_ranks(n):
+    """--gpus N without a launcher: start the N ranks as a fresh child process tree (this process has made no GPU call)
+    and hand back the child's exit code; rank 0 of the child prints the JSON line on the inherited stdout."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def main_dry(args):
+    """--dry-run: the launch / barrier / max-over-ranks / JSON plumbing with a no-op step and no GPU (CPU tests of N > 1)"""
+    from emip_amd import dist as edist
+    world, rank, _ = edist.env_world()
+    dist = edist.init("gloo") if world > 1 else None
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    barrier()
-    dt = edist.max_over_ranks(time.perf_counter() - t0, red_dev)
+        time.sleep(0.002 * (rank + 1))
+    if dist is not None:
+        dist.barrier()
+    dt = edist.max_over_ranks(time.perf_counter() - t0, "cpu")
     if rank == 0:
-        print(json.dumps({
-            "metric": "stream_frames_per_sec_352x352_emip_long", "value": round(world * S * args.steps / dt, 3),
-            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "EMIP-long inference step (short-term forward + LTM memorize/segment over a 5-frame "
-                                   "window + long decoder), %d video streams per GPU, bf16" % S,
-                       "streams_per_gpu": S, "memory_frames": int(state["k"].shape[3]), "hipgraph": not args.no_graph,
-                       "concurrent_streams": 1 if args.no_graph else min(args.streams, 2),
-                       "parallelism": "dp%d (independent replicas, no collective)" % world}}), flush=True)
+        print(json.dumps({"metric": "frame_pairs_per_sec_352x352_emip_short_fwd", "dry_run": True,
+                          "value": round(world * PAIRS_PER_GPU * args.steps / dt, 3), "unit": "pairs/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4)}),
+              flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -322,7 +439,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=4, help="sub-batches replayed concurrently on separate HIP streams")
+    ap.add_argument("--no-sub", action="store_true", help="skip the train / long / f32 sub-records of the default run")
+    ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the N-rank launch and timing plumbing only")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))          # before any GPU call in this process
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
+    if args.dry_run:
+        return main_dry(args)
     if os.environ.get("EMIP_KV_SPLIT"):
         from emip_amd import ops
         ops.KV_SPLIT = os.environ["EMIP_KV_SPLIT"] != "0"
@@ -334,15 +459,7 @@ def main():
         return main_long(args)
 
     from emip_amd import dist as edist
-    world, rank, local = edist.env_world()
-    dist = None
-    backend = os.environ.get("EMIP_DIST_BACKEND", "nccl")   # "nccl" is RCCL on ROCm; gloo = rehearsal on a smaller box
-    local = local % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local)
-    if world > 1:
-        dist = edist.init(backend)         # only barriers / the timing max-reduce use it
-    dev = torch.device("cuda", local)
-    red_dev = dev if backend == "nccl" else "cpu"
+    world, rank, dev, dist, red_dev = _dist_setup()        # only barriers / the timing max-reduce use the process group
 
     from emip_amd import _lib, nn_base
     from emip_amd.filler import state_dict_from_manifest, synthetic_pair
@@ -384,19 +501,13 @@ def main():
         torch.cuda.synchronize()
         step = runner.replay_free
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    _barrier(dist)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    barrier()
+    _barrier(dist)
     dt = time.perf_counter() - t0
     dt = edist.max_over_ranks(dt, red_dev)
 
@@ -450,10 +561,39 @@ def main():
                                  "%.1f ms vs %.1f ms wall per step)" % (nsplit, total_ms, dt / args.steps * 1e3),
                          "same_kernel_unsplit_batch_TFLOPs": (round(whole[1] / (whole[0] * 1e-3) / 1e12, 2)
                                                               if whole else None)})
+        out["roofline_named"] = {
+            "sra": named_roofline(agg, "attn_kernel<bf16,64,64,64>",
+                                  "PVTv2 spatial-reduction attention softmax(q k^T / 8) v, lib/pvt_v2.py:113-125"),
+            "correlation": named_roofline(agg, "attn_kernel<bf16,128,32,64>+scores",
+                                          "GMFlow all-pairs correlation + softmax expectation, raw correlation "
+                                          "written once as [src][tgt], gmflow/matching.py:13-41")}
         out["kernel_breakdown_ms"] = {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], ref_mask = cpu_baseline(sd)
             out["parity"] = parity_figures(net, margs, sd, ref_mask, dev)
+    # Sub-records (driver-timed beside the headline, same JSON line): BASELINE.json configs[2] / [4] = the training step
+    # (every rank takes part: its gradient all-reduce is the one real exchange of the path), configs[3] = EMIP-long, and the
+    # f32 parity mode's throughput.  A failure here is recorded, never allowed to lose the headline.
+    sub = {}
+    if not args.no_sub:
+        if not args.no_graph:
+            del runner
+        torch.cuda.empty_cache()
+        try:
+            sub["train"] = measure_train(32, 5, 2, world, rank, dev, dist, red_dev)
+        except Exception as e:                                   # noqa: BLE001
+            sub["train"] = {"error": repr(e)[:300]}
+        if world == 1:
+            try:
+                sub["long"] = measure_long(8, 10, 3, world, rank, dev, dist, red_dev)
+            except Exception as e:                               # noqa: BLE001
+                sub["long"] = {"error": repr(e)[:300]}
+            try:
+                sub["f32_parity_mode"] = measure_f32_mode(margs, sd, im1, im2, dev)
+            except Exception as e:                               # noqa: BLE001
+                sub["f32_parity_mode"] = {"error": repr(e)[:300]}
+    if rank == 0:
+        out.update(sub)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -86,8 +86,17 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
-    const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+
+    // Persistent over output tiles: workgroup b works on tiles {round * G + remap(b)}; inside a round every XCD owns a
+    // contiguous chunk of tile ids (tiles that share an A panel sit in one L2).  The stage ring runs on ACROSS tile
+    // boundaries: the first K tiles of the next output tile are in flight while the current one is finished and stored.
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int G = gridDim.x;
+    const int rounds = (ntiles - (int)blockIdx.x + G - 1) / G;
+    auto tile_of = [&](int i) {
+        const int base = i * G;
+        return base + xcd_remap(blockIdx.x, min(G, ntiles - base));
+    };
 
     if (p.zero_ptr && blockIdx.x == 0)
         for (long i = tid; i < p.zero_words; i += 512) p.zero_ptr[i] = 0u;
@@ -97,43 +106,45 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     const i32x4 rsW = make_rsrc(p.W, p.w_bytes);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
 
-    // ---- staging plan: instruction j of this wave moves the 8 tile rows of group g = 8 j + wave ------------------
+    // ---- staging plan of the tile being ISSUED: instruction j of this wave moves the 8 tile rows of group 8 j + wave ----
     const int lrow = lane >> 3, lslot = lane & 7;
     const unsigned chunk = (unsigned)(lslot ^ lrow);          // source chunk of this lane's slot (row & 7 == lrow)
-    unsigned arow[LA];        // dense: byte offset of the row in A (or OOB); conv: output pixel index m (or OOB)
+    unsigned arow[LA];        // dense: byte offset of the row in A (or OOB); conv: 0 = valid output pixel, OOB = beyond M
     unsigned arow2[LA];
     int a_oy[LA], a_ox[LA], a_img[LA];
     unsigned woff[LPT - LA];
+    auto setup = [&](int t) {
+        const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
 #pragma unroll
-    for (int j = 0; j < LA; ++j) {
-        const int r = 8 * (8 * j + wave) + lrow;
-        const int m = m0 + r;
-        if (CONV) {
-            const int hw = p.Ho * p.Wo;
-            const int b = m / hw, rem = m - b * hw;
-            a_oy[j] = (rem / p.Wo) * p.stride - p.pad;
-            a_ox[j] = (rem % p.Wo) * p.stride - p.pad;
-            a_img[j] = b * p.H;
-            arow[j] = m < p.M ? 0u : OOB;
-            arow2[j] = 0u;
-        } else {
-            arow[j] = m < p.M ? (unsigned)((long)m * p.lda * 2) + chunk * 16u : OOB;
-            arow2[j] = m < p.M ? (unsigned)((long)m * p.lda2 * 2) + chunk * 16u : OOB;
-            a_oy[j] = a_ox[j] = a_img[j] = 0;
+        for (int j = 0; j < LA; ++j) {
+            const int m = m0 + 8 * (8 * j + wave) + lrow;
+            if (CONV) {
+                const int hw = p.Ho * p.Wo;
+                const int b = m / hw, rem = m - b * hw;
+                a_oy[j] = (rem / p.Wo) * p.stride - p.pad;
+                a_ox[j] = (rem % p.Wo) * p.stride - p.pad;
+                a_img[j] = b * p.H;
+                arow[j] = m < p.M ? 0u : OOB;
+                arow2[j] = 0u;
+            } else {
+                arow[j] = m < p.M ? (unsigned)((long)m * p.lda * 2) + chunk * 16u : OOB;
+                arow2[j] = m < p.M ? (unsigned)((long)m * p.lda2 * 2) + chunk * 16u : OOB;
+                a_oy[j] = a_ox[j] = a_img[j] = 0;
+            }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < LPT - LA; ++j) {
-        const int pr = 8 * (8 * j + wave) + lrow;              // W tile row
-        const int wv = pr / WTN, wi = pr % WTN;
-        int nl = wi;
-        if (wi < 32 * NPAIR) {                                  // paired 16-blocks: (i -> 8 (i >> 2) + 4 half + (i & 3))
-            const int i = wi & 15;
-            nl = (wi & ~31) + 8 * (i >> 2) + 4 * ((wi >> 4) & 1) + (i & 3);
+        for (int j = 0; j < LPT - LA; ++j) {
+            const int pr = 8 * (8 * j + wave) + lrow;              // W tile row
+            const int wv = pr / WTN, wi = pr % WTN;
+            int nl = wi;
+            if (wi < 32 * NPAIR) {                                  // paired 16-blocks: i -> 8 (i >> 2) + 4 half + (i & 3)
+                const int i = wi & 15;
+                nl = (wi & ~31) + 8 * (i >> 2) + 4 * ((wi >> 4) & 1) + (i & 3);
+            }
+            const int n = n0 + wv * WTN + nl;
+            woff[j] = n < p.N ? (unsigned)((long)n * p.ldw * 2) + chunk * 16u : OOB;
         }
-        const int n = n0 + wv * WTN + nl;
-        woff[j] = n < p.N ? (unsigned)((long)n * p.ldw * 2) + chunk * 16u : OOB;
-    }
+    };
 
     const int ctiles = CONV ? (p.Cin + 63) / 64 : 0;
     const int nk = CONV ? p.KH * p.KW * ctiles : p.K / 64;
@@ -153,22 +164,26 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
             }
             const int kw0 = (tap * p.Cin + c0) * 2;
 #pragma unroll
-            for (int j = 0; j < LPT - LA; ++j)
-                dma16(base + (LA + j) * 8192, cok ? woff[j] : OOB, rsW, kw0);
+            for (int j = 0; j < LPT - LA; ++j) dma16(base + (LA + j) * 8192, cok ? woff[j] : OOB, rsW, kw0);
         } else {
             const int k0 = kt * 64;
             if (k0 < p.K1) {
 #pragma unroll
-                for (int j = 0; j < LA; ++j)
-                    dma16(base + j * 8192, arow[j], rsA, k0 * 2);
+                for (int j = 0; j < LA; ++j) dma16(base + j * 8192, arow[j], rsA, k0 * 2);
             } else {
 #pragma unroll
-                for (int j = 0; j < LA; ++j)
-                    dma16(base + j * 8192, arow2[j], rsA2, (k0 - p.K1) * 2);
+                for (int j = 0; j < LA; ++j) dma16(base + j * 8192, arow2[j], rsA2, (k0 - p.K1) * 2);
             }
 #pragma unroll
-            for (int j = 0; j < LPT - LA; ++j)
-                dma16(base + (LA + j) * 8192, woff[j], rsW, k0 * 2);
+            for (int j = 0; j < LPT - LA; ++j) dma16(base + (LA + j) * 8192, woff[j], rsW, k0 * 2);
+        }
+    };
+    int it_i = 0, it_k = 0;          // (tile, K tile) of the next step to issue
+    auto issue_next = [&](int stage) {
+        issue(it_k, stage);
+        if (++it_k == nk) {
+            it_k = 0;
+            if (++it_i < rounds) setup(tile_of(it_i));
         }
     };
 
@@ -187,116 +202,129 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
 
     auto compute = [&](int stage) {
         const char* sb = smem + stage * STAGE;
+        constexpr int AH = TM > 4 ? 4 : TM;          // A fragments live at a time (register budget of the 128-row wave tiles)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            uint4 af[TM], wf[TN];
+            uint4 wf[TN];
 #pragma unroll
             for (int b = 0; b < TN; ++b) wf[b] = *reinterpret_cast<const uint4*>(sb + w_base + b * 2048 + loff[ks]);
 #pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = *reinterpret_cast<const uint4*>(sb + a_base + a * 2048 + loff[ks]);
+            for (int a0 = 0; a0 < TM; a0 += AH) {
+                uint4 af[AH];
 #pragma unroll
-            for (int a = 0; a < TM; ++a)
+                for (int a = 0; a < AH; ++a) af[a] = *reinterpret_cast<const uint4*>(sb + a_base + (a0 + a) * 2048 + loff[ks]);
 #pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]),
-                                                                        __builtin_bit_cast(bf16x8, af[a]), acc[a][b], 0, 0, 0);
+                for (int a = 0; a < AH; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a0 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            __builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, af[a]), acc[a0 + a][b], 0, 0, 0);
+            }
         }
     };
 
-    issue(0, 0);
-    if (NST == 3 && nk > 1) issue(1, 1);
-    int st = 0;        // stage of tile kt
-    for (int kt = 0; kt < nk; ++kt) {
+    const int total = rounds * nk;
+    setup(tile_of(0));
+    issue_next(0);
+    if (NST == 3 && total > 1) issue_next(1);
+    int st = 0, kt = 0, ci = 0;
+    for (int s = 0; s < total; ++s) {
         if (NST == 3) {
-            if (kt + 1 < nk) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+            // the counted wait leaves the LPT youngest operations in flight: the loads of step s+1 -- or, right behind an
+            // epilogue, its stores, which only makes the wait more conservative (never less)
+            if (s + 1 < total) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + 2 < nk) issue(kt + 2, st >= 1 ? st - 1 : 2);        // (st + 2) % 3
+            if (s + 2 < total) issue_next(st >= 1 ? st - 1 : 2);        // stage (st + 2) % 3: read in step s-1, all past it
             compute(st);
             st = st == 2 ? 0 : st + 1;
         } else {
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (kt + 1 < nk) issue(kt + 1, st ^ 1);     // stage st^1 was read in iteration kt-1: every wave is past it
+            if (s + 1 < total) issue_next(st ^ 1);     // stage st^1 was read in step s-1: every wave is past it
             compute(st);
             st ^= 1;
         }
-    }
+        if (++kt < nk) continue;
+        kt = 0;
+        const int t = tile_of(ci++);
+        const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
 
-    // ---- epilogue: registers -> HBM, 16 B per lane --------------------------------------------------------------
-    const int nb = n0 + wn * WTN;
-    const bool gelu = p.act == EMIP_ACT_GELU, relu = p.act == EMIP_ACT_RELU;
-    const float invK = 1.f / (float)p.K;
-    const bool vec_ok = ((p.ldc & 7) == 0) && (!p.R || (p.ldr & 7) == 0);
-    float bv[NPAIR > 0 ? NPAIR : 1][8], cs[NPAIR > 0 ? NPAIR : 1][8];     // this lane's 8 channels of every 32-column block
+        // ---- epilogue: registers -> HBM, 16 B per lane (32-column blocks outermost: 16 live bias / colsum registers) ----
+        const int nb = n0 + wn * WTN;
+        const bool gelu = p.act == EMIP_ACT_GELU, relu = p.act == EMIP_ACT_RELU;
+        const float invK = 1.f / (float)p.K;
+        const bool vec_ok = ((p.ldc & 7) == 0) && (!p.R || (p.ldr & 7) == 0);
+        float rsv[TM], mrsv[TM], st1[TM], st2[TM];
 #pragma unroll
-    for (int pb = 0; pb < NPAIR; ++pb) {
-        const int n = nb + 32 * pb + 8 * fq;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int nc = min(n + j, p.N - 1);
-            bv[pb][j] = p.bias ? p.bias[nc] : 0.f;
-            cs[pb][j] = p.lne_stats ? p.lne_colsum[nc] : 0.f;
+        for (int a = 0; a < TM; ++a) {
+            rsv[a] = 1.f;
+            mrsv[a] = st1[a] = st2[a] = 0.f;
+            if (p.lne_stats) {
+                const int m = min(m0 + wm * WTM + 16 * a + fr, p.M - 1);
+                const float2 s2 = *reinterpret_cast<const float2*>(p.lne_stats + 2 * (long)m);
+                const float mu = s2.x * invK;
+                rsv[a] = rsqrtf(fmaxf(s2.y * invK - mu * mu, 0.f) + p.lne_eps);
+                mrsv[a] = mu * rsv[a];
+            }
         }
-    }
-#pragma unroll
-    for (int a = 0; a < TM; ++a) {
-        const int m = m0 + wm * WTM + 16 * a + fr;
-        const bool mok = m < p.M;
-        float rs = 1.f, mrs = 0.f;
-        if (p.lne_stats) {
-            const float2 s2 = *reinterpret_cast<const float2*>(p.lne_stats + 2 * (long)min(m, p.M - 1));
-            const float mu = s2.x * invK;
-            rs = rsqrtf(fmaxf(s2.y * invK - mu * mu, 0.f) + p.lne_eps);
-            mrs = mu * rs;
-        }
-        float st1 = 0.f, st2 = 0.f;
 #pragma unroll
         for (int pb = 0; pb < NPAIR; ++pb) {
             const int n = nb + 32 * pb + 8 * fq;
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = acc[a][2 * pb][j];
-                v[4 + j] = acc[a][2 * pb + 1][j];
-            }
+            float bv[8], cs[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float x = fmaf(v[j], rs, fmaf(-mrs, cs[pb][j], bv[pb][j]));
-                if (gelu) x = gelu_t<bf16_t>(x);
-                else if (relu) x = fmaxf(x, 0.f);
-                v[j] = x;
+                const int nc = min(n + j, p.N - 1);
+                bv[j] = p.bias ? p.bias[nc] : 0.f;
+                cs[j] = p.lne_stats ? p.lne_colsum[nc] : 0.f;
             }
-            if (mok && n < p.N) {
-                bf16_t* cp = p.C + (long)m * p.ldc + n;
-                if (vec_ok && n + 8 <= p.N) {
-                    if (p.R) {
-                        const uint4 rr = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
-                        const bf16_t* rv = reinterpret_cast<const bf16_t*>(&rr);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
-                    }
-                    uint4 ov;
-                    bf16_t* o = reinterpret_cast<bf16_t*>(&ov);
+            for (int a = 0; a < TM; ++a) {
+                const int m = m0 + wm * WTM + 16 * a + fr;
+                float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        o[j] = (bf16_t)v[j];
-                        const float q = (float)o[j];
-                        st1 += q;
-                        st2 += q * q;
-                    }
-                    *reinterpret_cast<uint4*>(cp) = ov;
-                } else {
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[a][2 * pb][j];
+                    v[4 + j] = acc[a][2 * pb + 1][j];
+                }
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        if (n + j < p.N) {
-                            float x = v[j];
-                            if (p.R) x += (float)p.R[(long)m * p.ldr + n + j];
-                            const bf16_t o = (bf16_t)x;
-                            cp[j] = o;
-                            st1 += (float)o;
-                            st2 += (float)o * (float)o;
+                for (int j = 0; j < 8; ++j) {
+                    float x = fmaf(v[j], rsv[a], fmaf(-mrsv[a], cs[j], bv[j]));
+                    if (gelu) x = gelu_t<bf16_t>(x);
+                    else if (relu) x = fmaxf(x, 0.f);
+                    v[j] = x;
+                }
+                if (m < p.M && n < p.N) {
+                    bf16_t* cp = p.C + (long)m * p.ldc + n;
+                    if (vec_ok && n + 8 <= p.N) {
+                        if (p.R) {
+                            const uint4 rr = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
+                            const bf16_t* rv = reinterpret_cast<const bf16_t*>(&rr);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+                        }
+                        uint4 ov;
+                        bf16_t* o = reinterpret_cast<bf16_t*>(&ov);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            o[j] = (bf16_t)v[j];
+                            const float q = (float)o[j];
+                            st1[a] += q;
+                            st2[a] += q * q;
+                        }
+                        *reinterpret_cast<uint4*>(cp) = ov;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            if (n + j < p.N) {
+                                float x = v[j];
+                                if (p.R) x += (float)p.R[(long)m * p.ldr + n + j];
+                                const bf16_t o = (bf16_t)x;
+                                cp[j] = o;
+                                st1[a] += (float)o;
+                                st2[a] += (float)o * (float)o;
+                            }
                         }
                     }
                 }
@@ -304,34 +332,47 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
         }
         if (TN & 1) {          // unpaired last 16-block: 4 channels (8 B) per lane
             const int n = nb + 32 * NPAIR + 4 * fq;
-            if (n < p.N && mok) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (n + j < p.N) {
-                        float x = fmaf(acc[a][TN - 1][j], rs, fmaf(-mrs, p.lne_stats ? p.lne_colsum[n + j] : 0.f,
-                                                                    p.bias ? p.bias[n + j] : 0.f));
-                        if (gelu) x = gelu_t<bf16_t>(x);
-                        else if (relu) x = fmaxf(x, 0.f);
-                        if (p.R) x += (float)p.R[(long)m * p.ldr + n + j];
-                        const bf16_t o = (bf16_t)x;
-                        p.C[(long)m * p.ldc + n + j] = o;
-                        st1 += (float)o;
-                        st2 += (float)o * (float)o;
+            for (int a = 0; a < TM; ++a) {
+                const int m = m0 + wm * WTM + 16 * a + fr;
+                if (n < p.N && m < p.M) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (n + j < p.N) {
+                            float x = fmaf(acc[a][TN - 1][j], rsv[a], fmaf(-mrsv[a], p.lne_stats ? p.lne_colsum[n + j] : 0.f,
+                                                                            p.bias ? p.bias[n + j] : 0.f));
+                            if (gelu) x = gelu_t<bf16_t>(x);
+                            else if (relu) x = fmaxf(x, 0.f);
+                            if (p.R) x += (float)p.R[(long)m * p.ldr + n + j];
+                            const bf16_t o = (bf16_t)x;
+                            p.C[(long)m * p.ldc + n + j] = o;
+                            st1[a] += (float)o;
+                            st2[a] += (float)o * (float)o;
+                        }
                     }
                 }
             }
         }
         if (p.out_stats) {      // the 4 lanes fr, fr+16, fr+32, fr+48 hold the same row
-            st1 += __shfl_xor(st1, 16);
-            st2 += __shfl_xor(st2, 16);
-            st1 += __shfl_xor(st1, 32);
-            st2 += __shfl_xor(st2, 32);
-            if (fq == 0 && mok) {
-                atomicAdd(p.out_stats + 2 * (long)m, st1);
-                atomicAdd(p.out_stats + 2 * (long)m + 1, st2);
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int m = m0 + wm * WTM + 16 * a + fr;
+                float s1 = st1[a], s2 = st2[a];
+                s1 += __shfl_xor(s1, 16);
+                s2 += __shfl_xor(s2, 16);
+                s1 += __shfl_xor(s1, 32);
+                s2 += __shfl_xor(s2, 32);
+                if (fq == 0 && m < p.M) {
+                    atomicAdd(p.out_stats + 2 * (long)m, s1);
+                    atomicAdd(p.out_stats + 2 * (long)m + 1, s2);
+                }
             }
         }
-    }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }   // steps
 }
 
 struct Cfg {
@@ -344,15 +385,15 @@ struct Cfg {
     {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>}
 
 const Cfg g_cfg[] = {
-    G8_CFG(256, 128, 4, 2, 3),   // 1: wave 64 x 64
-    G8_CFG(128, 256, 2, 4, 3),   // 2: wave 64 x 64
-    G8_CFG(128, 128, 2, 4, 3),   // 3: wave 64 x 32
-    G8_CFG(128, 320, 2, 4, 2),   // 4: wave 64 x 80 (N = 320 in one tile)
-    G8_CFG(64, 320, 2, 4, 3),    // 5: wave 32 x 80
-    G8_CFG(256, 64, 4, 2, 3),    // 6: wave 64 x 32
-    G8_CFG(256, 256, 2, 4, 2),   // 7: wave 128 x 64
-    G8_CFG(128, 64, 4, 2, 3),    // 8: wave 32 x 32
-    G8_CFG(64, 128, 2, 4, 3),    // 9: wave 32 x 32
+    G8_CFG(256, 128, 4, 2, 3),   // 1: wave 64 x 64, 144 KB
+    G8_CFG(128, 256, 2, 4, 3),   // 2: wave 64 x 64, 144 KB
+    G8_CFG(128, 128, 2, 4, 2),   // 3: wave 64 x 32, 64 KB (2 workgroups per CU)
+    G8_CFG(128, 320, 2, 4, 2),   // 4: wave 64 x 80 (N = 320 in one tile), 112 KB
+    G8_CFG(64, 320, 2, 4, 3),    // 5: wave 32 x 80, 144 KB
+    G8_CFG(256, 64, 4, 2, 2),    // 6: wave 64 x 32, 80 KB (2 per CU)
+    G8_CFG(256, 256, 2, 4, 2),   // 7: wave 128 x 64, 128 KB
+    G8_CFG(128, 64, 4, 2, 3),    // 8: wave 32 x 32, 72 KB (2 per CU)
+    G8_CFG(64, 128, 2, 4, 3),    // 9: wave 32 x 32, 72 KB (2 per CU)
 };
 constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
 
@@ -388,7 +429,11 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
             return EMIP_E_LAUNCH;
         attr_done[cfg - 1][conv] = true;
     }
-    hipLaunchKernelGGL(fn, dim3(a.tiles_m * a.tiles_n), dim3(512), lds, s, a);
+    // persistent grid: one workgroup per CU, two where LDS (<= 80 KB) and registers (<= 128, true of those tiles) allow
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a);
     return emip_launch_status();
 }
 

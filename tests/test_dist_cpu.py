@@ -105,3 +105,34 @@ def test_grad_reducer_two_ranks_mean_and_unused_params():
     assert nb >= 3 and da and db                                   # dead parameter: skipped, no gradient invented
     for a, b, x, y in zip(la, lb, ra, rb):
         assert np.allclose(x, (a + b) / 2, atol=1e-6) and np.array_equal(x, y)
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+    from tests.conftest import ROOT
+    e = dict(os.environ, EMIP_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, env=e,
+                       timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no launcher environment must itself start 2 ranks (as fresh child processes) and
+    rank 0 must print ONE JSON line with n_gpus = 2; the slowest rank defines the step time (dry run: no GPU)"""
+    r, recs = _bench("--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(recs) == 1 and recs[0]["n_gpus"] == 2 and recs[0]["steps"] == 4
+    assert recs[0]["ms_per_step"] >= 3.9            # rank 1 sleeps 4 ms per step, rank 0 only 2
+    r1, recs1 = _bench("--steps", "4", "--warmup", "1", "--dry-run")
+    assert r1.returncode == 0 and len(recs1) == 1 and recs1[0]["n_gpus"] == 1
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    r, recs = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and not recs
