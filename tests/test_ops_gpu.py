@@ -339,14 +339,20 @@ def test_flow_warp_and_occlusion(golden):
 
 
 def test_warp_indices_bit_exact(golden):
+    """int64 corner indices == the tensor the REFERENCE handed to scatter_add_ (tests/golden/warp_indices_captured.npz,
+    captured by oracle/make_golden_warp_capture.py inside loss/warp_utils.py:62-76), corner weights to 1 ulp-level, masks"""
     from emip_amd import ops
-    g = golden("warp_indices_352.npz")
-    fl = torch.from_numpy(np.random.RandomState(11).normal(0, 6.0, (1, 2, 352, 352)).astype(np.float32)).to(dev())
-    idx, _ = ops.occ_corners(fl)
-    assert idx.dtype == torch.int64
-    assert np.array_equal(idx.cpu().numpy().astype(np.int32), g["indices"])
-    occ = ops.occ_mask_backward(fl)
-    assert (occ.cpu().numpy().astype(np.uint8) != g["occ"]).mean() < 1e-4
+    g = golden("warp_indices_captured.npz")
+    flows = {"a": torch.from_numpy(np.random.RandomState(11).normal(0, 6.0, (1, 2, 352, 352)).astype(np.float32)),
+             "b": torch.from_numpy(np.random.RandomState(12).normal(0, 40.0, (2, 2, 352, 352)).astype(np.float32))}
+    for name, fl in flows.items():
+        idx, val = ops.occ_corners(fl.to(dev()))
+        assert idx.dtype == torch.int64
+        keep = slice(None) if name == "a" else slice(1, 2)
+        assert np.array_equal(idx.cpu().numpy().astype(np.int32)[keep], g[name + "_indices"])
+        assert np.abs(val.cpu().numpy()[:, ::61] - g[name + "_weights_sample"]).max() < 1e-6
+        occ = ops.occ_mask_backward(fl.to(dev()))
+        assert (occ.cpu().numpy().astype(np.uint8) != g[name + "_occ"]).mean() < 1e-4
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])

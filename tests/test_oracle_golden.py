@@ -82,12 +82,22 @@ def test_loss_micro(golden):
     assert abs(O.unflow_loss(flows4, torch.cat((x, y), 1)).item() - float(g["unflow"])) < 1e-5
 
 
+def _captured_flows():
+    a = torch.from_numpy(np.random.RandomState(11).normal(0, 6.0, (1, 2, 352, 352)).astype(np.float32))
+    b = torch.from_numpy(np.random.RandomState(12).normal(0, 40.0, (2, 2, 352, 352)).astype(np.float32))
+    return a, b
+
+
 def test_warp_indices_bit_exact(golden):
-    g = golden("warp_indices_352.npz")
-    fl = torch.from_numpy(np.random.RandomState(11).normal(0, 6.0, (1, 2, 352, 352)).astype(np.float32))
-    idx, _ = O.corresponding_indices(O.mesh_grid(1, 352, 352).type_as(fl) + fl)
-    assert np.array_equal(idx.numpy().astype(np.int32), g["indices"])
-    assert np.array_equal(O.occu_mask_backward(fl).numpy().astype(np.uint8), g["occ"])
+    """against the tensors the reference itself passed to scatter_add_ (oracle/make_golden_warp_capture.py)"""
+    g = golden("warp_indices_captured.npz")
+    for name, fl in zip("ab", _captured_flows()):
+        idx, val = O.corresponding_indices(O.mesh_grid(fl.shape[0], 352, 352).type_as(fl) + fl)
+        keep = slice(None) if name == "a" else slice(1, 2)
+        assert np.array_equal(idx.numpy().astype(np.int32)[keep], g[name + "_indices"])
+        assert np.array_equal(val.numpy()[:, ::61], g[name + "_weights_sample"])
+        assert np.allclose(val.double().sum(1).numpy(), g[name + "_weights_sum"], rtol=1e-12)
+        assert np.array_equal(O.occu_mask_backward(fl).numpy().astype(np.uint8), g[name + "_occ"])
 
 
 def test_long_stream(golden, long_sd):
