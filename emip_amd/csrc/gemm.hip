@@ -764,6 +764,16 @@ extern "C" int emip_conv2d_splitk(const void*, const void*, void*, const float*,
                                   int, int, int, long, long, int, void*, long, const float*, float, float*, float*, long, int,
                                   int, void*);
 
+// the 8-wave LDS-DMA body (gemm8.hip) takes the large bf16 launches; 0 = not eligible
+extern "C" int emip_gemm8(const void*, const void*, const void*, void*, const float*, const void*, int, int, int, int, long,
+                          long, long, long, long, int, const float*, const float*, float, float*, void*, long, int, void*);
+extern "C" int emip_conv8(const void*, const void*, void*, const float*, const void*, int, int, int, int, long, int, int, int,
+                          int, int, long, long, int, float*, void*, long, int, void*);
+namespace emip_internal {
+int gemm8_choice(int M, int N, long K, long lda, long ldw, int K1, bool has_a2, long lda2);
+int conv8_choice(int M, int Cout, int Cin, int KH, int KW, long a_elems);
+}
+
 // head strides handed from emip_gemm_heads to the shared entry body below (host-side, set and cleared around the call)
 static thread_local long t_hsA = 0, t_hsW = 0, t_hsC = 0;
 static thread_local int t_heads = 1;
@@ -834,6 +844,15 @@ extern "C" int emip_gemm_ln(const void* A, const void* A2, const void* W, void* 
     }
     if (R) EMIP_REQUIRE(ldr >= N);
     EMIP_REQUIRE(act >= EMIP_ACT_NONE && act <= EMIP_ACT_GELU);
+    if (dtype == EMIP_BF16 && batch == 1 && t_heads == 1 && ln_stats == nullptr && aligned16(C) && (R == nullptr || aligned16(R))) {
+        const int cfg = emip_internal::gemm8_choice(M, N, K, lda, ldw, K1, A2 != nullptr, lda2);
+        if (cfg > 0) {
+            if (zero_ptr) EMIP_REQUIRE(zero_bytes > 0 && (zero_bytes & 3) == 0);
+            if (t_lne_stats) EMIP_REQUIRE(ln_eps > 0.f);
+            return emip_gemm8(A, A2, W, C, bias, R, M, N, K, K1, lda, lda2, ldw, ldc, ldr, act, t_lne_stats, t_lne_colsum, ln_eps,
+                              out_stats, zero_ptr, zero_bytes, cfg, stream);
+        }
+    }
     GemmArgs a{};
     a.A = A; a.A2 = A2; a.W = W; a.C = C; a.bias = bias; a.R = R;
     a.M = M; a.N = N; a.K = K; a.K1 = K1;
@@ -897,6 +916,12 @@ extern "C" int emip_conv2d_splitk(const void* X, const void* W, void* Y, const f
     EMIP_REQUIRE((long)B * Ho * Wo < 2147483647L && (long)KH * KW * Cin < 2147483647L && (long)H * Wd * ldx < 2147483647L);
     if (R) EMIP_REQUIRE(ldr >= Cout);
     EMIP_REQUIRE(act >= EMIP_ACT_NONE && act <= EMIP_ACT_GELU);
+    if (dtype == EMIP_BF16 && ksplit == 1 && ln_stats == nullptr && aligned16(Y) && (R == nullptr || aligned16(R))) {
+        const int cfg = emip_internal::conv8_choice(B * Ho * Wo, Cout, Cin, KH, KW, ((long)B * H * Wd - 1) * ldx + Cin);
+        if (cfg > 0)
+            return emip_conv8(X, W, Y, bias, R, B, H, Wd, Cin, ldx, Cout, KH, KW, stride, pad, ldy, ldr, act, out_stats,
+                              zero_ptr, zero_bytes, cfg, stream);
+    }
     GemmArgs a{};
     a.A = X; a.W = W; a.C = Y; a.bias = bias; a.R = R;
     a.M = B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin; a.K1 = a.K;

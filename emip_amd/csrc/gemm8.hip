@@ -18,6 +18,7 @@
 //     consecutive channels: the epilogue stores 16 B per lane straight from registers (no LDS bounce), with bias /
 //     output-side LayerNorm / GELU / ReLU / residual / row statistics fused.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -397,22 +398,16 @@ const Cfg g_cfg[] = {
 };
 constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
 
+// Tile choice, from the per-shape sweep of tools/gemm8_bench.py on MI355X (profiles/r02_gemm8_sweep.txt):
+//   * long K x wide N (conv_corr, big GEMMs): 256 x 256, the only tile whose L2 -> LDS bytes per MAC keep the MFMA fed;
+//   * fewer than ~1.5 tiles of 128 x 128 per CU: 64 x 128 / 128 x 64 (two workgroups per CU overlap their fill / drain);
+//   * N = 64 (mod 128): 256 x 64; else 128 x 128 with two workgroups per CU.
 int pick_cfg(int M, int N, long K) {
-    // fewest padded MACs among the tiles that give at least ~one workgroup per CU, larger tiles first on ties
-    int best = 3;
-    double best_cost = 1e30;
-    for (int c = 1; c <= NCFG; ++c) {
-        const Cfg& g = g_cfg[c - 1];
-        const long tm = (M + g.bm - 1) / g.bm, tn = (N + g.bn - 1) / g.bn;
-        const long tiles = tm * tn;
-        const long rounds = (tiles + 255) / 256;
-        // time model: rounds x (tile MACs / CU rate + fixed per-tile cost), small tiles pay more LDS traffic per MAC
-        const double tile_macs = (double)g.bm * g.bn * (double)K;
-        const double eff = 1.0 / (1.0 + 48.0 * (1.0 / g.bm + 1.0 / g.bn));     // operand bytes per MAC penalty
-        const double cost = rounds * (tile_macs / eff + 3.0e6);
-        if (cost < best_cost) { best_cost = cost; best = c; }
-    }
-    return best;
+    if ((double)K * N >= 4.0e6 && M >= 8192) return 7;
+    const long tiles3 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    if (tiles3 < 384) return N <= 64 ? 8 : 9;
+    if (N % 128 == 64 || N <= 64) return 6;
+    return 3;
 }
 
 int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
@@ -440,6 +435,30 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
 }  // namespace
 
 extern "C" int emip_gemm8_auto_cfg(int M, int N, int K) { return pick_cfg(M, N, K); }
+
+// ---- dispatch hooks of emip_gemm_ln / emip_conv2d_splitk (gemm.hip): > 0 = not eligible, the 4-wave body runs -----------
+static int g8_enabled() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("EMIP_GEMM8");      // EMIP_GEMM8=0: A/B against the 4-wave bodies in one process tree
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v;
+}
+namespace emip_internal {
+int gemm8_choice(int M, int N, long K, long lda, long ldw, int K1, bool has_a2, long lda2) {
+    if (!g8_enabled() || M < 2048 || N < 64 || (K % 64) != 0 || (lda % 8) != 0 || (ldw % 8) != 0) return 0;
+    if (has_a2 && ((K1 % 64) != 0 || (lda2 % 8) != 0)) return 0;
+    if (((long)(M - 1) * lda + K) * 2 >= (1L << 31) || ((long)(N - 1) * ldw + K) * 2 >= (1L << 31)) return 0;
+    return pick_cfg(M, N, K);
+}
+int conv8_choice(int M, int Cout, int Cin, int KH, int KW, long a_elems) {
+    if (!g8_enabled() || M < 2048 || Cout < 64 || Cin < 96 || (Cin % 8) != 0 || a_elems * 2 >= (1L << 31) ||
+        (long)Cout * KH * KW * Cin * 2 >= (1L << 31))
+        return 0;
+    return pick_cfg(M, Cout, (long)KH * KW * Cin);
+}
+}  // namespace emip_internal
 
 extern "C" int emip_gemm8(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M,
                           int N, int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act,
