@@ -768,7 +768,7 @@ extern "C" int emip_conv2d_splitk(const void*, const void*, void*, const float*,
 extern "C" int emip_gemm8(const void*, const void*, const void*, void*, const float*, const void*, int, int, int, int, long,
                           long, long, long, long, int, const float*, const float*, float, float*, void*, long, int, void*);
 extern "C" int emip_conv8(const void*, const void*, void*, const float*, const void*, int, int, int, int, long, int, int, int,
-                          int, int, long, long, int, float*, void*, long, int, void*);
+                          int, int, long, long, int, const float*, const float*, float, float*, void*, long, int, void*);
 namespace emip_internal {
 int gemm8_choice(int M, int N, long K, long lda, long ldw, int K1, bool has_a2, long lda2);
 int conv8_choice(int M, int Cout, int Cin, int KH, int KW, long a_elems);
@@ -919,8 +919,8 @@ extern "C" int emip_conv2d_splitk(const void* X, const void* W, void* Y, const f
     if (dtype == EMIP_BF16 && ksplit == 1 && ln_stats == nullptr && aligned16(Y) && (R == nullptr || aligned16(R))) {
         const int cfg = emip_internal::conv8_choice(B * Ho * Wo, Cout, Cin, KH, KW, ((long)B * H * Wd - 1) * ldx + Cin);
         if (cfg > 0)
-            return emip_conv8(X, W, Y, bias, R, B, H, Wd, Cin, ldx, Cout, KH, KW, stride, pad, ldy, ldr, act, out_stats,
-                              zero_ptr, zero_bytes, cfg, stream);
+            return emip_conv8(X, W, Y, bias, R, B, H, Wd, Cin, ldx, Cout, KH, KW, stride, pad, ldy, ldr, act, nullptr, nullptr,
+                              0.f, out_stats, zero_ptr, zero_bytes, cfg, stream);
     }
     GemmArgs a{};
     a.A = X; a.W = W; a.C = Y; a.bias = bias; a.R = R;

@@ -60,28 +60,47 @@ struct G8Args {
     unsigned* zero_ptr;
     long zero_words;
     int H, Wd, Cin, KH, KW, stride, pad, Ho, Wo;   // conv geometry (CONV instances)
+    // LNT instances (patch convs behind a folded LayerNorm, lib/pvt_v2.py:106-108): ln_stats f32 [B*H*Wd][2] = (sum, sum of
+    // squares) over the Cin channels of every INPUT pixel, tapsum f32 [KH*KW][N] = sum over the channels of a tap of W.
+    //   y = sum_tap rstd_tap (W_tap . x_tap - mean_tap tapsum_tap) + bias      (pad == 0: every tap lies inside the image)
+    const float* ln_stats;
+    const float* tapsum;
+    float ln_eps;
+    unsigned s_bytes;
     unsigned a_bytes, a2_bytes, w_bytes;            // descriptor extents (< 2^31)
     int tiles_m, tiles_n;
 };
 
 constexpr unsigned OOB = 0x80000000u;   // beyond every descriptor extent: the load returns zeros
 
+// the 4-byte form: lane l lands at lds_dst + 4 l
+__device__ __forceinline__ void dma4(unsigned lds_dst, unsigned voff, i32x4 rs, int soff) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_dst), "v"(voff), "s"(rs), "s"(soff)
+        : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, bool CONV>
+template <int BM, int BN, int WGM, int WGN, int NST, bool CONV, bool LNT = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;      // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16;        // 16x16 accumulators per wave
     constexpr int NPAIR = TN / 2;                      // 32-column blocks stored 16 B per lane
     constexpr int R = BM + BN;                         // tile rows per stage (128 B each)
-    constexpr int LPT = R / 64;                        // LDS-DMA instructions per wave per stage
+    constexpr int LPR = R / 64;                        // 16-byte LDS-DMA instructions per wave per stage
+    constexpr int LPT = LPR + (LNT ? 1 : 0);           // ... plus one 4-byte one for the row statistics of the tap (LNT)
     constexpr int LA = BM / 64;                        // ... of which the first LA move A rows
-    constexpr int STAGE = R * 128;
+    constexpr int STAGE = R * 128 + (LNT ? 2048 : 0);  // LNT: [BM][2] f32 statistics behind the operand rows
     static_assert(WGM * WGN == 8 && WTM % 16 == 0 && WTN % 16 == 0 && BM % 64 == 0 && BN % 64 == 0, "tile shape");
     static_assert(NST * STAGE <= 160 * 1024, "LDS");
+    static_assert(!LNT || (CONV && BM <= 256), "per-tap LayerNorm is a conv mode");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -113,9 +132,21 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     unsigned arow[LA];        // dense: byte offset of the row in A (or OOB); conv: 0 = valid output pixel, OOB = beyond M
     unsigned arow2[LA];
     int a_oy[LA], a_ox[LA], a_img[LA];
-    unsigned woff[LPT - LA];
+    unsigned woff[LPR - LA];
+    const int sidx = wave * 64 + lane;                 // LNT: this lane moves component sidx & 1 of tile row sidx >> 1
+    int s_oy = 0, s_ox = 0, s_img = 0;
+    bool s_ok = false;
+    const i32x4 rsS = make_rsrc(LNT ? (const void*)p.ln_stats : (const void*)p.A, LNT ? p.s_bytes : 0u);
     auto setup = [&](int t) {
         const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+        if (LNT) {
+            const int m = m0 + (sidx >> 1), hw = p.Ho * p.Wo;
+            const int b = m / hw, rem = m - b * hw;
+            s_oy = (rem / p.Wo) * p.stride;
+            s_ox = (rem % p.Wo) * p.stride;
+            s_img = b * p.H;
+            s_ok = (sidx >> 1) < BM && m < p.M;
+        }
 #pragma unroll
         for (int j = 0; j < LA; ++j) {
             const int m = m0 + 8 * (8 * j + wave) + lrow;
@@ -134,7 +165,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < LPT - LA; ++j) {
+        for (int j = 0; j < LPR - LA; ++j) {
             const int pr = 8 * (8 * j + wave) + lrow;              // W tile row
             const int wv = pr / WTN, wi = pr % WTN;
             int nl = wi;
@@ -165,7 +196,11 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
             }
             const int kw0 = (tap * p.Cin + c0) * 2;
 #pragma unroll
-            for (int j = 0; j < LPT - LA; ++j) dma16(base + (LA + j) * 8192, cok ? woff[j] : OOB, rsW, kw0);
+            for (int j = 0; j < LPR - LA; ++j) dma16(base + (LA + j) * 8192, cok ? woff[j] : OOB, rsW, kw0);
+            if (LNT) {      // (sum, sum of squares) of the tap's input pixel of tile row sidx >> 1, component sidx & 1
+                const unsigned off = s_ok ? (unsigned)((((long)(s_img + s_oy + ky) * p.Wd + s_ox + kx) * 2 + (sidx & 1)) * 4) : OOB;
+                dma4(lds0 + stage * STAGE + R * 128 + wave * 256, off, rsS, 0);
+            }
         } else {
             const int k0 = kt * 64;
             if (k0 < p.K1) {
@@ -176,7 +211,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                 for (int j = 0; j < LA; ++j) dma16(base + j * 8192, arow2[j], rsA2, (k0 - p.K1) * 2);
             }
 #pragma unroll
-            for (int j = 0; j < LPT - LA; ++j) dma16(base + (LA + j) * 8192, woff[j], rsW, k0 * 2);
+            for (int j = 0; j < LPR - LA; ++j) dma16(base + (LA + j) * 8192, woff[j], rsW, k0 * 2);
         }
     };
     int it_i = 0, it_k = 0;          // (tile, K tile) of the next step to issue
@@ -190,10 +225,15 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
 
     // ---- main loop ------------------------------------------------------------------------------------------------
     f32x4 acc[TM][TN];
+    f32x4 part[LNT ? TM : 1][LNT ? TN : 1];            // LNT: the running tap's partial products
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < (LNT ? TM : 1); ++a)
+#pragma unroll
+        for (int b = 0; b < (LNT ? TN : 1); ++b) part[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fq = lane >> 4;
     int loff[2];
@@ -217,9 +257,44 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
 #pragma unroll
                 for (int a = 0; a < AH; ++a)
 #pragma unroll
-                    for (int b = 0; b < TN; ++b)
-                        acc[a0 + a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            __builtin_bit_cast(bf16x8, wf[b]), __builtin_bit_cast(bf16x8, af[a]), acc[a0 + a][b], 0, 0, 0);
+                    for (int b = 0; b < TN; ++b) {
+                        f32x4& d = LNT ? part[LNT ? a0 + a : 0][LNT ? b : 0] : acc[a0 + a][b];
+                        d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf[b]),
+                                                                    __builtin_bit_cast(bf16x8, af[a]), d, 0, 0, 0);
+                    }
+            }
+        }
+    };
+
+    // LNT: the tile's slice of tapsum in LDS, [tap][BN]; such launches give every workgroup exactly one tile
+    float* ts_lds = reinterpret_cast<float*>(smem + NST * STAGE);
+    if (LNT) {
+        const int t0 = tile_of(0), n0 = (t0 % p.tiles_n) * BN, taps = p.KH * p.KW;
+        for (int i = tid; i < taps * BN; i += 512) {
+            const int tp = i / BN, c = i - tp * BN;
+            ts_lds[i] = n0 + c < p.N ? p.tapsum[(long)tp * p.N + n0 + c] : 0.f;
+        }
+        __syncthreads();
+    }
+    auto merge_tap = [&](int stage, int tap) {
+        const float invC = 1.f / (float)p.Cin;
+        const float* sp = reinterpret_cast<const float*>(smem + stage * STAGE + R * 128);
+#pragma unroll
+        for (int a = 0; a < (LNT ? TM : 0); ++a) {
+            const float2 s2 = *reinterpret_cast<const float2*>(sp + 2 * (wm * WTM + 16 * a + fr));
+            const float mu = s2.x * invC;
+            const float rs = rsqrtf(fmaxf(s2.y * invC - mu * mu, 0.f) + p.ln_eps);
+#pragma unroll
+            for (int b = 0; b < (LNT ? TN : 0); ++b) {
+                // channels of accumulator b, element j: the epilogue's map (paired blocks hold 8 q + 4 (b & 1) + j)
+                const int c = wn * WTN + (b < 2 * NPAIR ? 32 * (b >> 1) + 8 * fq + 4 * (b & 1) : 16 * b + 4 * fq);
+                const float4 t4 = *reinterpret_cast<const float4*>(ts_lds + tap * BN + c);
+                f32x4& pp = part[LNT ? a : 0][LNT ? b : 0];
+                acc[a][b][0] = fmaf(rs, fmaf(-mu, t4.x, pp[0]), acc[a][b][0]);
+                acc[a][b][1] = fmaf(rs, fmaf(-mu, t4.y, pp[1]), acc[a][b][1]);
+                acc[a][b][2] = fmaf(rs, fmaf(-mu, t4.z, pp[2]), acc[a][b][2]);
+                acc[a][b][3] = fmaf(rs, fmaf(-mu, t4.w, pp[3]), acc[a][b][3]);
+                pp = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
@@ -238,6 +313,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
             __builtin_amdgcn_sched_barrier(0);
             if (s + 2 < total) issue_next(st >= 1 ? st - 1 : 2);        // stage (st + 2) % 3: read in step s-1, all past it
             compute(st);
+            if (LNT && (kt + 1) % ctiles == 0) merge_tap(st, kt / ctiles);
             st = st == 2 ? 0 : st + 1;
         } else {
             wait_vmcnt<0>();
@@ -245,6 +321,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
             __builtin_amdgcn_sched_barrier(0);
             if (s + 1 < total) issue_next(st ^ 1);     // stage st^1 was read in step s-1: every wave is past it
             compute(st);
+            if (LNT && (kt + 1) % ctiles == 0) merge_tap(st, kt / ctiles);
             st ^= 1;
         }
         if (++kt < nk) continue;
@@ -380,21 +457,25 @@ struct Cfg {
     int bm, bn, nst;
     void (*dense)(const G8Args);
     void (*conv)(const G8Args);
+    void (*lnt)(const G8Args);      // conv with the per-tap LayerNorm (small tiles only)
 };
 
 #define G8_CFG(BM, BN, WGM, WGN, NST) \
-    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>}
+    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr}
+#define G8_CFG_LNT(BM, BN, WGM, WGN, NST)                                                             \
+    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, \
+     gemm8_kernel<BM, BN, WGM, WGN, NST, true, true>}
 
 const Cfg g_cfg[] = {
-    G8_CFG(256, 128, 4, 2, 3),   // 1: wave 64 x 64, 144 KB
-    G8_CFG(128, 256, 2, 4, 3),   // 2: wave 64 x 64, 144 KB
-    G8_CFG(128, 128, 2, 4, 2),   // 3: wave 64 x 32, 64 KB (2 workgroups per CU)
-    G8_CFG(128, 320, 2, 4, 2),   // 4: wave 64 x 80 (N = 320 in one tile), 112 KB
-    G8_CFG(64, 320, 2, 4, 3),    // 5: wave 32 x 80, 144 KB
-    G8_CFG(256, 64, 4, 2, 2),    // 6: wave 64 x 32, 80 KB (2 per CU)
-    G8_CFG(256, 256, 2, 4, 2),   // 7: wave 128 x 64, 128 KB
-    G8_CFG(128, 64, 4, 2, 3),    // 8: wave 32 x 32, 72 KB (2 per CU)
-    G8_CFG(64, 128, 2, 4, 3),    // 9: wave 32 x 32, 72 KB (2 per CU)
+    G8_CFG(256, 128, 4, 2, 3),       // 1: wave 64 x 64, 144 KB
+    G8_CFG(128, 256, 2, 4, 3),       // 2: wave 64 x 64, 144 KB
+    G8_CFG(128, 128, 2, 4, 2),       // 3: wave 64 x 32, 64 KB (2 workgroups per CU)
+    G8_CFG(128, 320, 2, 4, 2),       // 4: wave 64 x 80 (N = 320 in one tile), 112 KB
+    G8_CFG(64, 320, 2, 4, 3),        // 5: wave 32 x 80, 144 KB
+    G8_CFG(256, 64, 4, 2, 2),        // 6: wave 64 x 32, 80 KB (2 per CU)
+    G8_CFG(256, 256, 2, 4, 2),       // 7: wave 128 x 64, 128 KB
+    G8_CFG_LNT(128, 64, 4, 2, 3),    // 8: wave 32 x 32, 72 KB (2 per CU)
+    G8_CFG_LNT(64, 128, 2, 4, 3),    // 9: wave 32 x 32, 72 KB (2 per CU)
 };
 constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
 
@@ -412,22 +493,28 @@ int pick_cfg(int M, int N, long K) {
 
 int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     G8Args a = a0;
+    const bool lnt = a.ln_stats != nullptr;
     if (cfg <= 0 || cfg > NCFG) cfg = pick_cfg(a.M, a.N, conv ? (long)a.KH * a.KW * a.Cin : a.K);
+    if (lnt && !g_cfg[cfg - 1].lnt) cfg = a.N <= 64 ? 8 : 9;
     const Cfg& g = g_cfg[cfg - 1];
     a.tiles_m = (a.M + g.bm - 1) / g.bm;
     a.tiles_n = (a.N + g.bn - 1) / g.bn;
-    const size_t lds = (size_t)g.nst * (g.bm + g.bn) * 128;
-    auto fn = conv ? g.conv : g.dense;
-    static bool attr_done[NCFG][2];
-    if (!attr_done[cfg - 1][conv]) {
+    size_t lds = (size_t)g.nst * (g.bm + g.bn) * 128;
+    if (lnt) lds = (size_t)g.nst * ((g.bm + g.bn) * 128 + 2048) + (size_t)a.KH * a.KW * g.bn * 4;
+    if (lds > 160 * 1024) return EMIP_E_INVALID;
+    auto fn = lnt ? g.lnt : (conv ? g.conv : g.dense);
+    const int which = lnt ? 2 : (conv ? 1 : 0);
+    static size_t attr_done[NCFG][3];
+    if (attr_done[cfg - 1][which] < lds) {
         if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return EMIP_E_LAUNCH;
-        attr_done[cfg - 1][conv] = true;
+        attr_done[cfg - 1][which] = lds;
     }
     // persistent grid: one workgroup per CU, two where LDS (<= 80 KB) and registers (<= 128, true of those tiles) allow
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
     const int tiles = a.tiles_m * a.tiles_n;
     const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
+    if (lnt && grid != tiles) return EMIP_E_INVALID;          // the tapsum slice in LDS belongs to ONE tile
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a);
     return emip_launch_status();
 }
@@ -485,7 +572,8 @@ extern "C" int emip_gemm8(const void* A, const void* A2, const void* W, void* C,
 
 extern "C" int emip_conv8(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd,
                           int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act,
-                          float* out_stats, void* zero_ptr, long zero_bytes, int cfg, void* stream) {
+                          const float* ln_stats, const float* tapsum, float ln_eps, float* out_stats, void* zero_ptr,
+                          long zero_bytes, int cfg, void* stream) {
     EMIP_REQUIRE(X && W && Y && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0);
     EMIP_REQUIRE((Cin % 8) == 0 && (ldx % 8) == 0 && ldx >= Cin && aligned16(X) && aligned16(W) && aligned16(Y) && ldy >= Cout);
     EMIP_REQUIRE(!R || (aligned16(R) && ldr >= Cout));
@@ -494,6 +582,11 @@ extern "C" int emip_conv8(const void* X, const void* W, void* Y, const float* bi
     EMIP_REQUIRE(Ho > 0 && Wo > 0);
     const long ab = (((long)B * H * Wd - 1) * ldx + Cin) * 2, wb = (long)Cout * KH * KW * Cin * 2;
     EMIP_REQUIRE(ab < (1L << 31) && wb < (1L << 31) && (long)B * Ho * Wo < (1L << 31));
+    if (ln_stats) {     // per-tap LayerNorm: every tap inside the image, 16-byte aligned tapsum rows, tiles of one round
+        EMIP_REQUIRE(tapsum && pad == 0 && ln_eps > 0.f && (Cout % 4) == 0 && (long)B * H * Wd * 8 < (1L << 31) &&
+                     (reinterpret_cast<uintptr_t>(tapsum) & 15u) == 0 && (reinterpret_cast<uintptr_t>(ln_stats) & 7u) == 0 &&
+                     (Ho - 1) * stride + KH <= H && (Wo - 1) * stride + KW <= Wd);
+    }
     G8Args a = {};
     a.A = (const bf16_t*)X; a.W = (const bf16_t*)W; a.C = (bf16_t*)Y; a.bias = bias; a.R = (const bf16_t*)R;
     a.M = B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin; a.K1 = a.K; a.lda = ldx; a.ldw = (long)KH * KW * Cin; a.ldc = ldy;
@@ -501,5 +594,6 @@ extern "C" int emip_conv8(const void* X, const void* W, void* Y, const float* bi
     a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad; a.Ho = Ho; a.Wo = Wo;
     a.a_bytes = (unsigned)ab; a.w_bytes = (unsigned)wb;
+    a.ln_stats = ln_stats; a.tapsum = tapsum; a.ln_eps = ln_eps; a.s_bytes = ln_stats ? (unsigned)((long)B * H * Wd * 8) : 0u;
     return launch(a, cfg, true, (hipStream_t)stream);
 }

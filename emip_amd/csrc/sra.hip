@@ -1,0 +1,189 @@
+// PVTv2 spatial-reduction attention for gfx950 (bf16):  O = softmax(q k^T * scale) v  with head_dim 64 and at most 128 keys
+// (/root/reference/lib/pvt_v2.py:113-125: 121 keys in every stage of pvt_v2_b5).
+//
+// What is special about this attention is that the whole key / value set of an (image, head) pair is tiny (121 x 64) while
+// the queries are many (121 ... 7744 per image).  So the key side is made RESIDENT per wave and the queries are streamed:
+//   * K lives in REGISTERS for the whole kernel, already in MFMA A-operand form (4 key blocks x 4 k-steps = 64 VGPRs):
+//     S^T = K Q^T needs no LDS read at all;
+//   * V lives in LDS (16 KB, swizzled for ds_read_b64_tr_b16), written once per workgroup, read as V^T fragments;
+//   * a wave walks its 32-query blocks on its own: no barrier and no LDS write inside the loop, the next block's Q rows are
+//     in flight while the current block is multiplied; the softmax is ONE pass over all 128 key slots (no online rescale);
+//   * the scores of a query sit in one lane pair (lane, lane ^ 32): one cross-lane exchange per row statistic, and the
+//     exponentiated accumulators are the B operand of O^T += V^T P as they stand;
+//   * the output row is widened to 16-byte stores with v_permlane32_swap.
+// Queries in, outputs out, K/V read once per workgroup: the kernel is bound by the Q/O stream (HBM / Infinity Cache).
+#include "common.h"
+
+namespace {
+
+struct SraArgs {
+    const bf16_t* Q;     // [B, Lq, C]   head hd at columns hd*64
+    const bf16_t* KV;    // [B, Lk, 2C]  k at columns hd*64, v at C + hd*64
+    bf16_t* O;           // [B, Lq, C]
+    int Lq, Lk, C, splits;
+    float scale;
+};
+
+// byte offset of 16-B chunk c of row `row` in the V tile (128-B rows), conflict-free for the transposed reads
+__device__ __forceinline__ int v_off128(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) * 16); }
+
+__global__ __launch_bounds__(256) void sra_kernel(const SraArgs p) {
+    __shared__ __attribute__((aligned(16))) char vt_[128 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lq = lane & 31, h = lane >> 5;
+    const int split = blockIdx.x, head = blockIdx.y;
+    const long batch = blockIdx.z;
+    const bf16_t* __restrict__ Qp = p.Q + batch * p.Lq * p.C + head * 64;
+    const bf16_t* __restrict__ Kp = p.KV + batch * p.Lk * 2 * p.C + head * 64;
+    const bf16_t* __restrict__ Vp = Kp + p.C;
+    bf16_t* __restrict__ Op = p.O + batch * p.Lq * p.C + head * 64;
+    const long ldk = 2 * p.C;
+
+    // ---- K -> registers (A operand: key 32 kt + lq on the MFMA row, this lane's 8 of the 16 d of k-step i)
+    uint4 kf[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const int key = 32 * kt + lq;
+        const long kr = min(key, p.Lk - 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            kf[kt][i] = mask4(*reinterpret_cast<const uint4*>(Kp + kr * ldk + (2 * i + h) * 8), key < p.Lk);
+    }
+    // ---- V -> LDS (rows >= Lk are zero: their probabilities are zero as well, but 0 * garbage could be NaN)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int id = tid + 256 * i, r = id >> 3, c = id & 7;
+        const long vr = min(r, p.Lk - 1);
+        *reinterpret_cast<uint4*>(vt_ + v_off128(r, c)) = mask4(*reinterpret_cast<const uint4*>(Vp + vr * ldk + c * 8), r < p.Lk);
+    }
+    __syncthreads();
+
+    const int nblk = (p.Lq + 31) >> 5;
+    const int b_lo = (int)((long)split * nblk / p.splits), b_hi = (int)((long)(split + 1) * nblk / p.splits);
+    const float sc2 = p.scale * 1.4426950408889634f;      // scores in log2 units
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+
+    auto load_q = [&](int blk, uint4 (&qf)[4]) {
+        const int q = blk * 32 + lq;
+        const long qr = min(q, p.Lq - 1);                  // clamped: rows beyond Lq are computed and never stored
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qf[i] = *reinterpret_cast<const uint4*>(Qp + qr * p.C + (2 * i + h) * 8);
+    };
+    uint4 qf[4], qn[4];
+    int blk = b_lo + wave;
+    if (blk < b_hi) load_q(blk, qf);
+    for (; blk < b_hi; blk += 4) {
+        const bool more = blk + 4 < b_hi;                  // wave-uniform
+        if (more) load_q(blk + 4, qn);
+        // ---- S^T = K Q^T (keys on the rows, this lane's query on the column)
+        f32x16 s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf[kt][i]),
+                                                                __builtin_bit_cast(bf16x8, qf[i]), s[kt], 0, 0, 0);
+        }
+        // ---- one-pass softmax over the 128 key slots (register r of block kt = key 32 kt + 8 (r >> 2) + 4 h + (r & 3))
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = s[kt][r] * sc2;
+                if (kt == 3 && 96 + 8 * (r >> 2) + 4 * h + (r & 3) >= p.Lk) v = -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - mx);
+                s[kt][r] = e;
+                psum += e;
+            }
+        psum += __shfl_xor(psum, 32);
+        // ---- O^T = V^T P
+        f32x16 oacc[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                bf16x8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[kt][8 * sp + j];
+                const int base0 = 32 * kt + 16 * sp + 4 * h + (i16 >> 2);
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    const int col = 32 * d + 16 * g16 + 4 * (i16 & 3);
+                    const int c = col >> 3, half = (col >> 2) & 1;
+                    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt_ + v_off128(base0, c) + 8 * half));
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt_ + v_off128(base0 + 8, c) + 8 * half));
+                    bf16x8 vf;
+                    const bf16x4 b0 = __builtin_bit_cast(bf16x4, v0), b1 = __builtin_bit_cast(bf16x4, v1);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        vf[j] = b0[j];
+                        vf[4 + j] = b1[j];
+                    }
+                    oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+                }
+            }
+        }
+        // ---- normalise, pack, widen to 16 B per lane, store
+        const float inv = 1.0f / psum;
+        const int q = blk * 32 + lq;
+        bf16_t* orow = Op + (long)q * p.C;
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                // this lane: channels 32 d + 8 g + 4 h + (0..3) in registers 4g.., and 8 (g+1) + 4 h + (0..3) in 4(g+1)..
+                bf16x4 ta, tb;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    ta[j] = (bf16_t)(oacc[d][4 * g + j] * inv);
+                    tb[j] = (bf16_t)(oacc[d][4 * (g + 1) + j] * inv);
+                }
+                uint2 a = __builtin_bit_cast(uint2, ta), b = __builtin_bit_cast(uint2, tb);
+                // lower half keeps its group g and receives the upper half's group g; upper half: group g+1
+                auto r0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
+                auto r1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
+                if (q < p.Lq)
+                    *reinterpret_cast<uint4*>(orow + 32 * d + 8 * (g + h)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+            }
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qf[i] = qn[i];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int emip_sra_attention(const void* Q, const void* KV, void* O, int batch, int heads, int Lq, int Lk, int C,
+                                  float scale, void* stream) {
+    EMIP_REQUIRE(Q && KV && O && batch > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lk <= 128 && C == heads * 64);
+    EMIP_REQUIRE(batch < 65536 && heads < 65536 && aligned16(Q) && aligned16(KV) && aligned16(O));
+    SraArgs a{};
+    a.Q = (const bf16_t*)Q; a.KV = (const bf16_t*)KV; a.O = (bf16_t*)O;
+    a.Lq = Lq; a.Lk = Lk; a.C = C; a.scale = scale;
+    // about one workgroup per CU, and at least 4 query blocks (one per wave) in each
+    const int nblk = (Lq + 31) / 32, pairs = batch * heads;
+    int splits = (256 + pairs - 1) / pairs;
+    if (splits > nblk / 4) splits = nblk / 4;
+    if (splits < 1) splits = 1;
+    a.splits = splits;
+    hipLaunchKernelGGL(sra_kernel, dim3(splits, heads, batch), dim3(256), 0, (hipStream_t)stream, a);
+    return emip_launch_status();
+}

@@ -47,6 +47,9 @@ PAIR_KSPLIT = int(os.environ.get("EMIP_PAIR_KSPLIT", "0"))        # 0 = off, n =
 # LN(x) W^T = rstd (x W^T) - rstd mean colsum(W).  The operand loader no longer normalises every staged element once per
 # N tile (10x per element for fc1), and the main loop becomes the LDS-DMA one.
 LN_EPILOGUE = os.environ.get("EMIP_LN_EPILOGUE", "1") != "0"
+# bf16: q projection and spatial-reduction conv as two launches of the 8-wave body (emip_gemm8 / emip_conv8 with the per-tap
+# output-side LayerNorm) instead of the pair launch of the 4-wave bodies
+SR_CONV8 = os.environ.get("EMIP_SR_CONV8", "1") != "0"
 
 
 def _lin_packs(w, dt):
@@ -215,6 +218,8 @@ class Block(EmipModule):
             # column sums of the packed (rounded) weights: the output-side form of the folded LayerNorm (emip_gemm_lne)
             for k in ("q", "kv", "w1"):
                 out["s" + k] = out[k].float().sum(1).contiguous()
+            if sr > 1:      # ... and per tap for the spatial-reduction conv (emip_conv8 with ln_stats): [sr*sr, C]
+                out["tsr"] = out["sr"].float().view(out["sr"].shape[0], sr * sr, -1).sum(2).t().contiguous()
             return out
         params = (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, a.q.weight, a.q.bias,
                   a.kv.weight, a.kv.bias, a.proj.weight, a.proj.bias, m.fc1.weight, m.fc1.bias,
@@ -252,7 +257,16 @@ class Block(EmipModule):
         o = Ms * C if (sr > 1 and SPLITK_SR) else 0
         acc_sr = buf[:o].view(Ms, C) if o else None
         st_sr, st1, st2 = buf[o:o + 2 * Ms], buf[o + 2 * Ms:o + 2 * Ms + 2 * M], buf[o + 2 * Ms + 2 * M:]
-        if sr > 1 and PAIR_Q_SR and not SPLITK_SR:
+        use_conv8 = sr > 1 and SR_CONV8 and dt == torch.bfloat16 and LN_EPILOGUE and ops.gemm8_enabled() and not SPLITK_SR
+        use_pair = sr > 1 and PAIR_Q_SR and not SPLITK_SR and not use_conv8
+        if use_conv8:
+            # both on the 8-wave LDS-DMA body with the LayerNorm on the output side: q over the raw tokens (column sums),
+            # the spatial-reduction conv over the raw patches (per-tap sums; the statistics ride the operand ring)
+            q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["sq"])
+            s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
+                          out_stats=st_sr)
+            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"])
+        elif use_pair:
             # q projection (as a 1x1 conv over the tokens) and the spatial-reduction conv in ONE launch
             q = torch.empty((B, H, W, C), dtype=dt, device=x.device)
             s = torch.empty((B, H // sr, W // sr, C), dtype=dt, device=x.device)
@@ -269,7 +283,7 @@ class Block(EmipModule):
             kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"] if LN_EPILOGUE else None)
         else:
             q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["sq"] if LN_EPILOGUE else None)
-        if sr > 1 and PAIR_Q_SR and not SPLITK_SR:
+        if use_conv8 or use_pair:
             pass
         elif sr > 1:
             # 121 output tokens per image against K = sr*sr*C: split K over workgroups (about 256 in total), f32 atomics

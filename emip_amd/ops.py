@@ -88,6 +88,12 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=No
     return out
 
 
+def gemm8_enabled():
+    """False when EMIP_GEMM8=0 keeps every launch on the 4-wave bodies (A/B calibration)"""
+    import os
+    return os.environ.get("EMIP_GEMM8", "1") != "0"
+
+
 def gemm8(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=None, ln_eps=0.0, colsum=None,
           out_stats=None, zero=None, cfg=0):
     """emip_gemm8: the 8-wave bf16 body (same arithmetic and hooks as `gemm`; the LayerNorm hook is the output-side form)"""
@@ -117,8 +123,10 @@ def gemm8(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=N
     return out
 
 
-def conv8(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None, zero=None, out_stats=None, cfg=0):
-    """emip_conv8: implicit-GEMM conv on the 8-wave bf16 body; x [B,H,W,Cin] channels-last, w packed [Cout, kh*kw*Cin]"""
+def conv8(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None, zero=None, out_stats=None, cfg=0,
+          ln_stats=None, tapsum=None, ln_eps=0.0):
+    """emip_conv8: implicit-GEMM conv on the 8-wave bf16 body; x [B,H,W,Cin] channels-last, w packed [Cout, kh*kw*Cin];
+    ln_stats f32 [B*H*W, 2] + tapsum f32 [kh*kw, Cout]: LayerNorm of the input pixels applied on the output side, per tap"""
     _dev(x)
     B, H, W, Cin = x.shape
     assert x.stride(-1) == 1 and x.stride(1) == W * x.stride(2) and (B == 1 or x.stride(0) == H * x.stride(1))
@@ -135,8 +143,11 @@ def conv8(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=
     if res is not None:
         Mr, Nr, ldr = rows(res)
         assert Mr == Mo and Nr == Cout
+    if ln_stats is not None:
+        assert ln_stats.dtype == torch.float32 and ln_stats.numel() == 2 * B * H * W and ln_stats.is_contiguous()
+        assert tapsum.dtype == torch.float32 and tuple(tapsum.shape) == (kh * kw, Cout) and tapsum.is_contiguous()
     _lib.call("emip_conv8", _p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, ldx, Cout, kh, kw, stride, pad, ldy,
-              ldr, act, _p(out_stats), _p(zero), _nbytes(zero), int(cfg), _stream())
+              ldr, act, _p(ln_stats), _p(tapsum), float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), int(cfg), _stream())
     return out
 
 

@@ -85,9 +85,15 @@ int emip_gemm8(const void* A, const void* A2, const void* W, void* C, const floa
                int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, const float* ln_stats,
                const float* colsum, float ln_eps, float* out_stats, void* zero_ptr, long zero_bytes, int cfg,
                void* stream);
+/* emip_conv8 with ln_stats != NULL: a pad-0 patch conv behind a folded LayerNorm (the spatial-reduction conv of
+ * lib/pvt_v2.py:106-108 reading norm1(x)) with the LayerNorm on the OUTPUT side, tap by tap:
+ *   y = sum_tap rstd_tap (W_tap . x_tap - mean_tap tapsum_tap) + bias,
+ * ln_stats f32 [B*H*Wd][2] = (sum, sum of squares) over the Cin channels of every input pixel, tapsum f32 [KH*KW][Cout] =
+ * channel sums of the packed weights per tap.  The operand tiles stay raw (LDS-DMA), the statistics ride the same ring. */
 int emip_conv8(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd, int Cin,
-               long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act, float* out_stats,
-               void* zero_ptr, long zero_bytes, int cfg, void* stream);
+               long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act,
+               const float* ln_stats, const float* tapsum, float ln_eps, float* out_stats, void* zero_ptr,
+               long zero_bytes, int cfg, void* stream);
 int emip_gemm8_auto_cfg(int M, int N, int K);
 
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */

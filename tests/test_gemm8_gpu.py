@@ -1,0 +1,130 @@
+"""emip_gemm8 / emip_conv8 (the 8-wave LDS-DMA body) against plain PyTorch f32 references of the same op, through the
+C ABI: every tile configuration on ragged shapes, every epilogue hook, the two-source K loop, implicit-GEMM convs with
+channel tails / strides / padding, and the per-tap output-side LayerNorm of the spatial-reduction conv
+(/root/reference/lib/pvt_v2.py:101-129: q = Linear(norm1(x)), x_ = sr(norm1(x)))."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+NCFG = 9
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _rand(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(*shape, device=dev(), generator=g) * scale
+
+
+@pytest.mark.parametrize("cfg", range(1, NCFG + 1))
+@pytest.mark.parametrize("M,N,K", [(333, 72, 64), (1000, 200, 128), (129, 320, 192), (64, 64, 64), (700, 328, 320)])
+def test_dense_every_tile_on_ragged_shapes(cfg, M, N, K):
+    from emip_amd import ops
+    a = _rand(M, K, seed=1).to(torch.bfloat16)
+    w = _rand(N, K, scale=K ** -0.5, seed=2).to(torch.bfloat16)
+    bias = _rand(N, seed=3)
+    out = torch.full((M + 2, N), 7.0, device=dev(), dtype=torch.bfloat16)     # guard rows: nothing beyond M may be written
+    ops.gemm8(a, w, bias=bias, out=out[:M], cfg=cfg)
+    ref = a.float() @ w.float().t() + bias
+    assert (out[:M].float() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+    assert (out[M:] == 7.0).all()
+
+
+@pytest.mark.parametrize("cfg", [0, 3, 5, 6, 9])
+def test_dense_hooks_gelu_residual_stats_and_output_side_layernorm(cfg):
+    from emip_amd import ops
+    M, N, K = 1500, 320, 256
+    x = (_rand(M, K, seed=4) * 2 + 30.0).to(torch.bfloat16)          # row means far from zero: the hard case of the lne form
+    w = _rand(N, K, scale=K ** -0.5, seed=5).to(torch.bfloat16)
+    bias, res = _rand(N, seed=6), _rand(M, N, seed=7).to(torch.bfloat16)
+    xf = x.float()
+    stats = torch.stack([xf.sum(1), (xf * xf).sum(1)], 1).contiguous()
+    colsum = w.float().sum(1).contiguous()
+    eps = 1e-6
+    ln = (xf - xf.mean(1, keepdim=True)) * torch.rsqrt(xf.var(1, unbiased=False, keepdim=True) + eps)
+    ref = F.gelu(ln @ w.float().t() + bias) + res.float()
+    out = torch.empty(M, N, device=dev(), dtype=torch.bfloat16)
+    ost = torch.zeros(M, 2, device=dev())
+    scratch = torch.ones(1000, device=dev())
+    ops.gemm8(x, w, bias=bias, res=res, act=ops.ACT_GELU, out=out, ln_stats=stats, ln_eps=eps, colsum=colsum, out_stats=ost,
+              zero=scratch, cfg=cfg)
+    assert (out.float() - ref).abs().max().item() < 4e-2
+    of = out.float()
+    assert (ost[:, 0] - of.sum(1)).abs().max().item() < 2e-2 and (ost[:, 1] - (of * of).sum(1)).abs().max().item() < 0.3
+    assert (scratch == 0).all()
+    # in-place residual update (C aliases R), as the PVT blocks use it
+    acc = res.clone()
+    ops.gemm8(x, w, bias=bias, res=acc, act=ops.ACT_GELU, out=acc, ln_stats=stats, ln_eps=eps, colsum=colsum, cfg=cfg)
+    assert torch.equal(acc, out)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 3, 7])
+def test_dense_two_source_k_loop(cfg):
+    """gmflow/transformer.py:187-189: mlp(cat([source, message])) without materialising the concat"""
+    from emip_amd import ops
+    M, N, K1, K2 = 2100, 1024, 128, 128
+    a1, a2 = _rand(M, K1, seed=8).to(torch.bfloat16), _rand(M, K2, seed=9).to(torch.bfloat16)
+    w = _rand(N, K1 + K2, scale=(K1 + K2) ** -0.5, seed=10).to(torch.bfloat16)
+    out = ops.gemm8(a1, w, a2=a2, act=ops.ACT_GELU, cfg=cfg)
+    ref = F.gelu(torch.cat([a1, a2], 1).float() @ w.float().t())
+    assert (out.float() - ref).abs().max().item() < 3e-2
+
+
+def _conv_ref(x, wp, bias, k, stride, pad):
+    Cout, Cin = wp.shape[0], x.shape[-1]
+    return F.conv2d(x.float().permute(0, 3, 1, 2), wp.float().view(Cout, k, k, Cin).permute(0, 3, 1, 2), bias, stride=stride,
+                    padding=pad).permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 3, 7, 9])
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", [(2, 20, 20, 72, 40, 3, 1, 1), (1, 44, 44, 80, 136, 3, 1, 1),
+                                                          (3, 22, 22, 128, 320, 3, 2, 1), (2, 16, 24, 64, 64, 2, 2, 0),
+                                                          (1, 9, 11, 200, 96, 1, 1, 0)])
+def test_conv_implicit_gemm(cfg, B, H, W, Cin, Cout, k, stride, pad):
+    from emip_amd import ops
+    x = _rand(B, H, W, Cin, seed=11).to(torch.bfloat16)
+    wp = _rand(Cout, k * k * Cin, scale=(k * k * Cin) ** -0.5, seed=12).to(torch.bfloat16)
+    bias = _rand(Cout, seed=13)
+    ref = torch.relu(_conv_ref(x, wp, bias, k, stride, pad))
+    out = ops.conv8(x, wp, k, k, stride, pad, bias=bias, act=ops.ACT_RELU, cfg=cfg)
+    assert out.shape == ref.shape
+    assert (out.float() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B,H,C,sr", [(4, 22, 320, 2), (3, 44, 128, 4), (2, 88, 64, 8), (1, 22, 320, 2)])
+def test_spatial_reduction_conv_with_per_tap_layernorm(B, H, C, sr):
+    """x_ = sr(norm1(x)) with gamma / beta folded into the weights: raw patches in, LayerNorm applied per tap on the output"""
+    from emip_amd import ops
+    x = (_rand(B, H, H, C, seed=14) * 1.5 + _rand(B, H, H, 1, seed=15) * 4).to(torch.bfloat16)
+    wp = _rand(C, sr * sr * C, scale=(sr * sr * C) ** -0.5, seed=16).to(torch.bfloat16)
+    bias = _rand(C, seed=17)
+    xf = x.float()
+    stats = torch.stack([xf.sum(-1), (xf * xf).sum(-1)], -1).reshape(-1, 2).contiguous()
+    tapsum = wp.float().view(C, sr * sr, C).sum(2).t().contiguous()
+    eps = 1e-6
+    ln = (xf - xf.mean(-1, keepdim=True)) * torch.rsqrt(xf.var(-1, unbiased=False, keepdim=True) + eps)
+    ref = _conv_ref(ln, wp, bias, sr, sr, 0)
+    ost = torch.zeros(ref.numel() // C, 2, device=dev())
+    out = ops.conv8(x, wp, sr, sr, sr, 0, bias=bias, ln_stats=stats, tapsum=tapsum, ln_eps=eps, out_stats=ost)
+    assert (out.float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item())
+    of = out.float().reshape(-1, C)
+    assert (ost[:, 0] - of.sum(1)).abs().max().item() < 2e-2 * max(1.0, of.sum(1).abs().max().item())
+
+
+def test_dispatch_routes_large_bf16_launches_to_the_same_arithmetic():
+    """ops.gemm / ops.conv2d (the entry points the modules call) agree with the explicit 8-wave entry on a large launch and
+    keep working on launches the 8-wave body does not take (K % 64 != 0, f32)"""
+    from emip_amd import ops
+    a = _rand(4096, 320, seed=18).to(torch.bfloat16)
+    w = _rand(640, 320, scale=320 ** -0.5, seed=19).to(torch.bfloat16)
+    bias = _rand(640, seed=20)
+    assert torch.equal(ops.gemm(a, w, bias=bias), ops.gemm8(a, w, bias=bias))
+    a2 = _rand(4096, 344, seed=21).to(torch.bfloat16)
+    w2 = _rand(128, 344, scale=344 ** -0.5, seed=22).to(torch.bfloat16)
+    ref = a2.float() @ w2.float().t()
+    assert (ops.gemm(a2, w2).float() - ref).abs().max().item() < 3e-2
+    a3, w3 = _rand(4096, 320, seed=23), _rand(64, 320, scale=320 ** -0.5, seed=24)
+    assert (ops.gemm(a3, w3) - a3 @ w3.t()).abs().max().item() < 1e-3
