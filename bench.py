@@ -42,6 +42,10 @@ def _algo_flops(name, a):
         if a[4]:                                            # raw scores (the correlation volume) written out
             byt += 2.0 * z * Lq * Lk
         return 2.0 * z * Lq * Lk * (D + dv), ("attn", D, DV, bkv, "+scores" if a[4] else ""), byt
+    if name == "emip_sra_attention":      # (Q, KV, O, batch, heads, Lq, Lk, C, scale, stream)
+        batch, heads, Lq, Lk = a[3], a[4], a[5], a[6]
+        z = batch * heads
+        return 4.0 * z * Lq * Lk * 64, ("sra",), 2.0 * z * (2 * Lq * 64 + 2 * Lk * 64)
     if name in ("emip_gemm", "emip_gemm_ln"):
         M, N, K, batch = a[6], a[7], a[8], a[16]
         ln = name == "emip_gemm_ln" and a[21] is not None     # normalising loader: the register-staged loop
@@ -91,7 +95,9 @@ def kernel_breakdown(net, im1, im2, splits=1):
         ms = s.elapsed_time(e)
         fl, tile, byt = _algo_flops(name, a)
         key = name
-        if tile is not None and tile[0] == "attn":
+        if tile is not None and tile[0] == "sra":
+            key = "sra_kernel"
+        elif tile is not None and tile[0] == "attn":
             key = "attn_kernel<bf16,%d,%d,%d>%s" % tile[1:]
         elif tile is not None:
             t = lib.emip_gemm_tile(tile[0], tile[1], tile[2], tile[5])
@@ -562,7 +568,7 @@ def main():
                          "same_kernel_unsplit_batch_TFLOPs": (round(whole[1] / (whole[0] * 1e-3) / 1e12, 2)
                                                               if whole else None)})
         out["roofline_named"] = {
-            "sra": named_roofline(agg, "attn_kernel<bf16,64,64,64>",
+            "sra": named_roofline(agg, "sra_kernel" if "sra_kernel" in agg else "attn_kernel<bf16,64,64,64>",
                                   "PVTv2 spatial-reduction attention softmax(q k^T / 8) v, lib/pvt_v2.py:113-125"),
             "correlation": named_roofline(agg, "attn_kernel<bf16,128,32,64>+scores",
                                           "GMFlow all-pairs correlation + softmax expectation, raw correlation "

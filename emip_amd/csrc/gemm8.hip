@@ -69,7 +69,17 @@ struct G8Args {
     unsigned s_bytes;
     unsigned a_bytes, a2_bytes, w_bytes;            // descriptor extents (< 2^31)
     int tiles_m, tiles_n;
+#ifdef EMIP_TUNING
+    int dbg;      // ablations (tuning library only): 1 = no epilogue stores, 2 = no MFMA, 4 = no operand loads
+#endif
 };
+
+#ifdef EMIP_TUNING
+int g8_dbg = 0;
+#define G8_DBG(p, bit) ((p).dbg & (bit))
+#else
+#define G8_DBG(p, bit) false
+#endif
 
 constexpr unsigned OOB = 0x80000000u;   // beyond every descriptor extent: the load returns zeros
 
@@ -99,7 +109,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     constexpr int LA = BM / 64;                        // ... of which the first LA move A rows
     constexpr int STAGE = R * 128 + (LNT ? 2048 : 0);  // LNT: [BM][2] f32 statistics behind the operand rows
     static_assert(WGM * WGN == 8 && WTM % 16 == 0 && WTN % 16 == 0 && BM % 64 == 0 && BN % 64 == 0, "tile shape");
-    static_assert(NST * STAGE <= 160 * 1024, "LDS");
+    static_assert(NST * STAGE <= 160 * 1024 && NST >= 2 && NST <= 5 && 3 * LPT < 64, "LDS / ring depth");
     static_assert(!LNT || (CONV && BM <= 256), "per-tap LayerNorm is a conv mode");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 
@@ -182,6 +192,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     const int nk = CONV ? p.KH * p.KW * ctiles : p.K / 64;
 
     auto issue = [&](int kt, int stage) {
+        if (G8_DBG(p, 4)) return;
         const unsigned base = lds0 + stage * STAGE + wave * 1024;
         if (CONV) {
             const int tap = kt / ctiles, c0 = (kt - tap * ctiles) * 64;
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     const int a_base = wm * WTM * 128, w_base = (BM + wn * WTN) * 128;
 
     auto compute = [&](int stage) {
+        if (G8_DBG(p, 2)) return;
         const char* sb = smem + stage * STAGE;
         constexpr int AH = TM > 4 ? 4 : TM;          // A fragments live at a time (register budget of the 128-row wave tiles)
 #pragma unroll
@@ -301,20 +313,26 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
 
     const int total = rounds * nk;
     setup(tile_of(0));
-    issue_next(0);
-    if (NST == 3 && total > 1) issue_next(1);
+    // ring of NST stages: NST - 1 tiles are issued ahead (NST == 2: one, behind the barrier of the previous step)
+#pragma unroll
+    for (int i = 0; i < (NST >= 3 ? NST - 1 : 1); ++i)
+        if (i < total) issue_next(i);
     int st = 0, kt = 0, ci = 0;
     for (int s = 0; s < total; ++s) {
-        if (NST == 3) {
-            // the counted wait leaves the LPT youngest operations in flight: the loads of step s+1 -- or, right behind an
-            // epilogue, its stores, which only makes the wait more conservative (never less)
-            if (s + 1 < total) wait_vmcnt<LPT>(); else wait_vmcnt<0>();
+        if (NST >= 3) {
+            // the counted wait leaves the loads of the NST - 2 tiles behind tile s in flight (fewer at the tail) -- or, right
+            // behind an epilogue, its stores, which only makes the wait more conservative (never less)
+            const int ahead = min(NST - 2, total - 1 - s);
+            if (ahead >= 3) wait_vmcnt<3 * LPT>();
+            else if (ahead == 2) wait_vmcnt<2 * LPT>();
+            else if (ahead == 1) wait_vmcnt<LPT>();
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (s + 2 < total) issue_next(st >= 1 ? st - 1 : 2);        // stage (st + 2) % 3: read in step s-1, all past it
+            if (s + NST - 1 < total) issue_next(st == 0 ? NST - 1 : st - 1);   // stage (st - 1) mod NST: read in step s-1
             compute(st);
             if (LNT && (kt + 1) % ctiles == 0) merge_tap(st, kt / ctiles);
-            st = st == 2 ? 0 : st + 1;
+            st = st == NST - 1 ? 0 : st + 1;
         } else {
             wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
@@ -330,6 +348,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
         const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
 
         // ---- epilogue: registers -> HBM, 16 B per lane (32-column blocks outermost: 16 live bias / colsum registers) ----
+        if (G8_DBG(p, 1) && acc[0][0][0] != 123456.f) {          // tuning build: skip the stores, keep the accumulators live
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+            continue;
+        }
         const int nb = n0 + wn * WTN;
         const bool gelu = p.act == EMIP_ACT_GELU, relu = p.act == EMIP_ACT_RELU;
         const float invK = 1.f / (float)p.K;
@@ -462,9 +487,11 @@ struct Cfg {
 
 #define G8_CFG(BM, BN, WGM, WGN, NST) \
     {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr}
+// the per-tap LayerNorm instances serve 31..183 workgroups walking 20..64 K tiles each: a 5-deep ring (4 tiles in flight)
+constexpr int NST_LNT = 5;
 #define G8_CFG_LNT(BM, BN, WGM, WGN, NST)                                                             \
     {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, \
-     gemm8_kernel<BM, BN, WGM, WGN, NST, true, true>}
+     gemm8_kernel<BM, BN, WGM, WGN, NST_LNT, true, true>}
 
 const Cfg g_cfg[] = {
     G8_CFG(256, 128, 4, 2, 3),       // 1: wave 64 x 64, 144 KB
@@ -493,6 +520,9 @@ int pick_cfg(int M, int N, long K) {
 
 int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     G8Args a = a0;
+#ifdef EMIP_TUNING
+    a.dbg = g8_dbg;
+#endif
     const bool lnt = a.ln_stats != nullptr;
     if (cfg <= 0 || cfg > NCFG) cfg = pick_cfg(a.M, a.N, conv ? (long)a.KH * a.KW * a.Cin : a.K);
     if (lnt && !g_cfg[cfg - 1].lnt) cfg = a.N <= 64 ? 8 : 9;
@@ -500,7 +530,7 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     a.tiles_m = (a.M + g.bm - 1) / g.bm;
     a.tiles_n = (a.N + g.bn - 1) / g.bn;
     size_t lds = (size_t)g.nst * (g.bm + g.bn) * 128;
-    if (lnt) lds = (size_t)g.nst * ((g.bm + g.bn) * 128 + 2048) + (size_t)a.KH * a.KW * g.bn * 4;
+    if (lnt) lds = (size_t)NST_LNT * ((g.bm + g.bn) * 128 + 2048) + (size_t)a.KH * a.KW * g.bn * 4;
     if (lds > 160 * 1024) return EMIP_E_INVALID;
     auto fn = lnt ? g.lnt : (conv ? g.conv : g.dense);
     const int which = lnt ? 2 : (conv ? 1 : 0);
@@ -522,6 +552,9 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
 }  // namespace
 
 extern "C" int emip_gemm8_auto_cfg(int M, int N, int K) { return pick_cfg(M, N, K); }
+#ifdef EMIP_TUNING
+extern "C" int emip_tuning_gemm8_dbg(int v) { g8_dbg = v; return 0; }
+#endif
 
 // ---- dispatch hooks of emip_gemm_ln / emip_conv2d_splitk (gemm.hip): > 0 = not eligible, the 4-wave body runs -----------
 static int g8_enabled() {

@@ -4,13 +4,15 @@
 // What is special about this attention is that the whole key / value set of an (image, head) pair is tiny (121 x 64) while
 // the queries are many (121 ... 7744 per image).  So the key side is made RESIDENT per wave and the queries are streamed:
 //   * K lives in REGISTERS for the whole kernel, already in MFMA A-operand form (4 key blocks x 4 k-steps = 64 VGPRs):
-//     S^T = K Q^T needs no LDS read at all;
+//     S^T = K Q^T reads no key from LDS inside the loop;
 //   * V lives in LDS (16 KB, swizzled for ds_read_b64_tr_b16), written once per workgroup, read as V^T fragments;
-//   * a wave walks its 32-query blocks on its own: no barrier and no LDS write inside the loop, the next block's Q rows are
-//     in flight while the current block is multiplied; the softmax is ONE pass over all 128 key slots (no online rescale);
+//   * a wave walks its 32-query blocks on its own: no workgroup barrier inside the loop, the next block's Q rows are in
+//     flight while the current block is multiplied; the softmax is ONE pass over all 128 key slots (no online rescale);
 //   * the scores of a query sit in one lane pair (lane, lane ^ 32): one cross-lane exchange per row statistic, and the
 //     exponentiated accumulators are the B operand of O^T += V^T P as they stand;
-//   * the output row is widened to 16-byte stores with v_permlane32_swap.
+//   * every global access is a full 128-byte line: K / V / Q rows are loaded 16 B per lane along the row and take their
+//     fragment shape through LDS (fragment-shaped global loads touch 32 lines per wave instruction and made the first
+//     version of this kernel address-path bound), the O rows are packed into the wave's staging image and stored row-wise.
 // Queries in, outputs out, K/V read once per workgroup: the kernel is bound by the Q/O stream (HBM / Infinity Cache).
 #include "common.h"
 
@@ -27,10 +29,18 @@ struct SraArgs {
 // byte offset of 16-B chunk c of row `row` in the V tile (128-B rows), conflict-free for the transposed reads
 __device__ __forceinline__ int v_off128(int row, int c) { return row * 128 + ((c ^ (((row >> 1) & 1) << 2)) * 16); }
 
+// 16-B chunk c of row `row` in a [rows][128 B] image read row-wise with ds_read_b128 (K as the MFMA A operand, Q as B)
+__device__ __forceinline__ int r_off128(int row, int c) { return row * 128 + ((c ^ (row & 7)) * 16); }
+
 __global__ __launch_bounds__(256) void sra_kernel(const SraArgs p) {
-    __shared__ __attribute__((aligned(16))) char vt_[128 * 128];
+    // V tile | K tile | per wave: one 32-row staging image (the block's Q rows, later its O rows)
+    __shared__ __attribute__((aligned(16))) char smem[128 * 128 + 128 * 128 + 4 * 32 * 128];
+    char* vt_ = smem;
+    char* kt_ = smem + 128 * 128;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    char* st_ = smem + 2 * 128 * 128 + wave * 32 * 128;
     const int lq = lane & 31, h = lane >> 5;
+    const int srow = lane >> 3, sch = lane & 7;            // staging: lane moves chunk sch of rows srow + 8 j (full 128-B lines)
     const int split = blockIdx.x, head = blockIdx.y;
     const long batch = blockIdx.z;
     const bf16_t* __restrict__ Qp = p.Q + batch * p.Lq * p.C + head * 64;
@@ -39,42 +49,44 @@ __global__ __launch_bounds__(256) void sra_kernel(const SraArgs p) {
     bf16_t* __restrict__ Op = p.O + batch * p.Lq * p.C + head * 64;
     const long ldk = 2 * p.C;
 
-    // ---- K -> registers (A operand: key 32 kt + lq on the MFMA row, this lane's 8 of the 16 d of k-step i)
-    uint4 kf[4][4];
+    const int nblk = (p.Lq + 31) >> 5;
+    const int b_lo = (int)((long)split * nblk / p.splits), b_hi = (int)((long)(split + 1) * nblk / p.splits);
+    auto load_q = [&](int blk, uint4 (&qs)[4]) {           // rows beyond Lq: clamped (computed, never stored)
 #pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        const int key = 32 * kt + lq;
-        const long kr = min(key, p.Lk - 1);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            kf[kt][i] = mask4(*reinterpret_cast<const uint4*>(Kp + kr * ldk + (2 * i + h) * 8), key < p.Lk);
-    }
-    // ---- V -> LDS (rows >= Lk are zero: their probabilities are zero as well, but 0 * garbage could be NaN)
+        for (int j = 0; j < 4; ++j) {
+            const long qr = min(blk * 32 + srow + 8 * j, p.Lq - 1);
+            qs[j] = *reinterpret_cast<const uint4*>(Qp + qr * p.C + sch * 8);
+        }
+    };
+    uint4 qs[4];
+    int blk = b_lo + wave;
+    if (blk < b_hi) load_q(blk, qs);                       // in flight while K / V are staged
+
+    // ---- K, V -> LDS in full 128-byte lines (rows >= Lk are zero), then K -> registers in MFMA A-operand form
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int id = tid + 256 * i, r = id >> 3, c = id & 7;
-        const long vr = min(r, p.Lk - 1);
-        *reinterpret_cast<uint4*>(vt_ + v_off128(r, c)) = mask4(*reinterpret_cast<const uint4*>(Vp + vr * ldk + c * 8), r < p.Lk);
+        const long kr = min(r, p.Lk - 1);
+        *reinterpret_cast<uint4*>(kt_ + r_off128(r, c)) = mask4(*reinterpret_cast<const uint4*>(Kp + kr * ldk + c * 8), r < p.Lk);
+        *reinterpret_cast<uint4*>(vt_ + v_off128(r, c)) = mask4(*reinterpret_cast<const uint4*>(Vp + kr * ldk + c * 8), r < p.Lk);
     }
     __syncthreads();
+    uint4 kf[4][4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) kf[kt][i] = *reinterpret_cast<const uint4*>(kt_ + r_off128(32 * kt + lq, 2 * i + h));
 
-    const int nblk = (p.Lq + 31) >> 5;
-    const int b_lo = (int)((long)split * nblk / p.splits), b_hi = (int)((long)(split + 1) * nblk / p.splits);
     const float sc2 = p.scale * 1.4426950408889634f;      // scores in log2 units
     const int i16 = lane & 15, g16 = (lane >> 4) & 1;
-
-    auto load_q = [&](int blk, uint4 (&qf)[4]) {
-        const int q = blk * 32 + lq;
-        const long qr = min(q, p.Lq - 1);                  // clamped: rows beyond Lq are computed and never stored
-#pragma unroll
-        for (int i = 0; i < 4; ++i) qf[i] = *reinterpret_cast<const uint4*>(Qp + qr * p.C + (2 * i + h) * 8);
-    };
-    uint4 qf[4], qn[4];
-    int blk = b_lo + wave;
-    if (blk < b_hi) load_q(blk, qf);
     for (; blk < b_hi; blk += 4) {
-        const bool more = blk + 4 < b_hi;                  // wave-uniform
-        if (more) load_q(blk + 4, qn);
+        // ---- this block's Q rows: registers -> the wave's staging image -> B-operand fragments; next block's rows in flight
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(st_ + r_off128(srow + 8 * j, sch)) = qs[j];
+        if (blk + 4 < b_hi) load_q(blk + 4, qs);
+        uint4 qf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qf[i] = *reinterpret_cast<const uint4*>(st_ + r_off128(lq, 2 * i + h));
         // ---- S^T = K Q^T (keys on the rows, this lane's query on the column)
         f32x16 s[4];
 #pragma unroll
@@ -89,14 +101,16 @@ __global__ __launch_bounds__(256) void sra_kernel(const SraArgs p) {
         // ---- one-pass softmax over the 128 key slots (register r of block kt = key 32 kt + 8 (r >> 2) + 4 h + (r & 3))
         float mx = -INFINITY;
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+        for (int kt = 0; kt < 4; ++kt) {
+            const bool edge = 32 * kt + 31 >= p.Lk;        // wave-uniform: only such blocks hold key slots >= Lk
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float v = s[kt][r] * sc2;
-                if (kt == 3 && 96 + 8 * (r >> 2) + 4 * h + (r & 3) >= p.Lk) v = -INFINITY;
+                if (edge && 32 * kt + 8 * (r >> 2) + 4 * h + (r & 3) >= p.Lk) v = -INFINITY;
                 s[kt][r] = v;
                 mx = fmaxf(mx, v);
             }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float psum = 0.f;
 #pragma unroll
@@ -140,31 +154,22 @@ __global__ __launch_bounds__(256) void sra_kernel(const SraArgs p) {
                 }
             }
         }
-        // ---- normalise, pack, widen to 16 B per lane, store
+        // ---- normalise, pack, through the staging image (its Q fragments are in registers), store whole 128-byte rows
         const float inv = 1.0f / psum;
-        const int q = blk * 32 + lq;
-        bf16_t* orow = Op + (long)q * p.C;
 #pragma unroll
         for (int d = 0; d < 2; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; g += 2) {
-                // this lane: channels 32 d + 8 g + 4 h + (0..3) in registers 4g.., and 8 (g+1) + 4 h + (0..3) in 4(g+1)..
-                bf16x4 ta, tb;
+            for (int g = 0; g < 4; ++g) {     // registers 4 g .. 4 g + 3 = channels 32 d + 8 g + 4 h + (0..3) of query lq
+                bf16x4 t;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    ta[j] = (bf16_t)(oacc[d][4 * g + j] * inv);
-                    tb[j] = (bf16_t)(oacc[d][4 * (g + 1) + j] * inv);
-                }
-                uint2 a = __builtin_bit_cast(uint2, ta), b = __builtin_bit_cast(uint2, tb);
-                // lower half keeps its group g and receives the upper half's group g; upper half: group g+1
-                auto r0 = __builtin_amdgcn_permlane32_swap(a.x, b.x, false, false);
-                auto r1 = __builtin_amdgcn_permlane32_swap(a.y, b.y, false, false);
-                if (q < p.Lq)
-                    *reinterpret_cast<uint4*>(orow + 32 * d + 8 * (g + h)) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+                for (int j = 0; j < 4; ++j) t[j] = (bf16_t)(oacc[d][4 * g + j] * inv);
+                *reinterpret_cast<uint2*>(st_ + r_off128(lq, 4 * d + g) + 8 * h) = __builtin_bit_cast(uint2, t);
             }
-        if (more) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) qf[i] = qn[i];
+        for (int j = 0; j < 4; ++j) {
+            const int q = blk * 32 + srow + 8 * j;
+            const uint4 v = *reinterpret_cast<const uint4*>(st_ + r_off128(srow + 8 * j, sch));
+            if (q < p.Lq) *reinterpret_cast<uint4*>(Op + (long)q * p.C + sch * 8) = v;
         }
     }
 }

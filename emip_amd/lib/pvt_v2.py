@@ -50,6 +50,8 @@ LN_EPILOGUE = os.environ.get("EMIP_LN_EPILOGUE", "1") != "0"
 # bf16: q projection and spatial-reduction conv as two launches of the 8-wave body (emip_gemm8 / emip_conv8 with the per-tap
 # output-side LayerNorm) instead of the pair launch of the 4-wave bodies
 SR_CONV8 = os.environ.get("EMIP_SR_CONV8", "1") != "0"
+# bf16 inference: the dedicated spatial-reduction attention kernel (emip_sra_attention) instead of the generic flash kernel
+SRA_KERNEL = os.environ.get("EMIP_SRA_KERNEL", "1") != "0"
 
 
 def _lin_packs(w, dt):
@@ -166,9 +168,12 @@ class Attention(EmipModule):
         kv = ops.gemm(s, wkv, bias=bkv)                      # [B,h,w,2C]: k = [:C], v = [C:], head hd at hd*64
         N = H * W
         a = torch.empty((B, H, W, C), dtype=dt, device=h.device)
-        ops.attention(q, kv, kv[..., C:], a, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
-                      k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
-                      k_hs=64, v_hs=64, o_hs=64, scale=self.scale)
+        if dt == torch.bfloat16 and Lk <= 128 and SRA_KERNEL:
+            ops.sra_attention(q, kv, a, B, heads, N, Lk, self.scale)
+        else:
+            ops.attention(q, kv, kv[..., C:], a, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
+                          k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
+                          k_hs=64, v_hs=64, o_hs=64, scale=self.scale)
         return ops.gemm(a, wp, bias=bp, res=residual, out=residual)
 
 
@@ -303,9 +308,12 @@ class Block(EmipModule):
             kv = ops.gemm(x, w["kv"], bias=w["bkv"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["skv"] if LN_EPILOGUE else None)
         Lk = s.shape[1] * s.shape[2]
         att = torch.empty((B, H, W, C), dtype=dt, device=x.device)
-        ops.attention(q, kv, kv[..., C:], att, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
-                      k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
-                      k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
+        if dt == torch.bfloat16 and Lk <= 128 and SRA_KERNEL:
+            ops.sra_attention(q, kv, att, B, heads, N, Lk, a.scale)      # keys resident in registers, queries streamed
+        else:
+            ops.attention(q, kv, kv[..., C:], att, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
+                          k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
+                          k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
         ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)                          # x += proj(attn)
         t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, colsum=w["sw1"] if LN_EPILOGUE else None)
         t = ops.dwconv3x3(t, w["wd"], w["bd"], act=ops.ACT_GELU)

@@ -288,6 +288,16 @@ def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_
     return out
 
 
+def sra_attention(q, kv, out, batch, heads, Lq, Lk, scale):
+    """emip_sra_attention (bf16): q [B,Lq,C], kv [B,Lk,2C] (k | v), out [B,Lq,C], C = heads * 64, Lk <= 128"""
+    _dev(q)
+    C = heads * 64
+    assert q.dtype == kv.dtype == out.dtype == torch.bfloat16 and q.is_contiguous() and kv.is_contiguous() and out.is_contiguous()
+    assert q.numel() == batch * Lq * C and kv.numel() == batch * Lk * 2 * C and out.numel() == q.numel()
+    _lib.call("emip_sra_attention", _p(q), _p(kv), _p(out), batch, heads, Lq, Lk, C, float(scale), _stream())
+    return out
+
+
 def mdta_attn(q, kv_k, temperature, B, heads, P):
     """q [B,P,ldq] view, kv_k [B,P,ldk] view (the k half) -> attn [B,heads,64,64]."""
     _dev(q)

@@ -96,6 +96,13 @@ int emip_conv8(const void* X, const void* W, void* Y, const float* bias, const v
                long zero_bytes, int cfg, void* stream);
 int emip_gemm8_auto_cfg(int M, int N, int K);
 
+/* PVTv2 spatial-reduction attention, bf16, head_dim 64, Lk <= 128 keys (lib/pvt_v2.py:113-125: attn = softmax(q k^T * scale),
+ * x = attn v, all heads of all images in one launch).  Q [batch][Lq][C] with head hd at columns hd*64, KV [batch][Lk][2C]
+ * as the kv Linear leaves it (k at hd*64, v at C + hd*64), O [batch][Lq][C]; C = heads*64.  The keys of an (image, head)
+ * pair stay in registers and the values in LDS while a wave streams 32-query blocks (sra.hip). */
+int emip_sra_attention(const void* Q, const void* KV, void* O, int batch, int heads, int Lq, int Lk, int C, float scale,
+                       void* stream);
+
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
 int emip_gemm_tile(long M, long N, long batch, long K);
 
