@@ -2,6 +2,7 @@
 import os
 import socket
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -59,7 +60,7 @@ def test_shard_range_properties():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _dp_worker(rank, world, port, out):
+def _dp_worker(rank, world, port, out, algo, comm):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
                       LOCAL_RANK=str(rank))
     import torch.distributed as dist
@@ -71,40 +72,65 @@ def _dp_worker(rank, world, port, out):
     broadcast_parameters(net)
     w0 = net[0].weight.detach().clone()
     params = list(net.parameters()) + [dead]
-    red = GradReducer(params, bucket_bytes=300)  # tiny buckets: several buckets, one of them incomplete
+    red = GradReducer(params, bucket_bytes=300, algo=algo,            # tiny buckets: several buckets, one incomplete
+                      comm_dtype=torch.bfloat16 if comm == "bf16" else None)
     g = torch.Generator().manual_seed(100 + rank)
     x = torch.randn(5, 8, generator=g)
     net(x).pow(2).sum().backward()
     local = [p.grad.clone() for p in net.parameters()]
-    red.finish()
-    out.put((rank, w0.numpy(), [t.numpy() for t in local], [p.grad.clone().numpy() for p in net.parameters()],
-             dead.grad is None, len(red.buckets)))   # numpy: tensors in a Queue are shared-memory handles
-    # a second step must work after the reset
+    red.finish()                                 # step 1 = calibration: ready order logged, dead parameters found
+    first = [p.grad.clone().numpy() for p in net.parameters()]
+    assert red.calibrated and [id(p) for p in red.dead] == [id(dead)]
+    assert all(id(p) != id(dead) for b in red.buckets for p in b.params)
+    # gradient-ready order of this graph: last layer first (bias before weight is autograd's accumulation order per layer)
+    order_names = [red.ready_order[i] for i in range(len(red.ready_order))]
+    # a second step on the calibrated buckets: buckets complete and launch in index order, identically on every rank
     for p in net.parameters():
         p.grad = None
+    red.begin_step()
     net(x * 0.5).pow(2).sum().backward()
+    local2 = [p.grad.clone() for p in net.parameters()]
+    launched_during_backward = list(red.launch_log)
     red.finish()
+    out.put((rank, w0.numpy(), [t.numpy() for t in local], first, dead.grad is None, len(red.buckets), order_names,
+             launched_during_backward, list(red.launch_log), [t.numpy() for t in local2],
+             [p.grad.clone().numpy() for p in net.parameters()]))   # numpy: tensors in a Queue are shared-memory handles
+    # a parameter that was dead in the calibration step gets a gradient later: reduced in a trailing bucket, still the mean
+    for p in params:
+        p.grad = None
+    (net(x).pow(2).sum() + (dead * (rank + 1.0)).sum()).backward()
+    red.finish()
+    assert torch.allclose(dead.grad, torch.full((3,), 1.5)), dead.grad
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_grad_reducer_two_ranks_mean_and_unused_params():
+@pytest.mark.parametrize("algo,comm", [("allreduce", "f32"), ("direct", "f32"), ("direct", "bf16")])
+def test_grad_reducer_two_ranks_mean_and_unused_params(algo, comm):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, algo, comm)) for r in range(2)]
     for p in ps:
         p.start()
     res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
-    (_, w0a, la, ra, da, nb), (_, w0b, lb, rb, db, _) = res
+    (_, w0a, la, ra, da, nb, oa, lda, lfa, l2a, r2a), (_, w0b, lb, rb, db, _, ob, ldb, lfb, l2b, r2b) = res
     import numpy as np
+    tol = 1e-6 if comm == "f32" else 2e-2                          # bf16 transport: 8-bit mantissa on the wire, f32 sums
     assert np.array_equal(w0a, w0b)                                # broadcast equalised the replicas
     assert nb >= 3 and da and db                                   # dead parameter: skipped, no gradient invented
     for a, b, x, y in zip(la, lb, ra, rb):
-        assert np.allclose(x, (a + b) / 2, atol=1e-6) and np.array_equal(x, y)
+        assert np.allclose(x, (a + b) / 2, atol=tol * max(1.0, np.abs(a).max())) and np.array_equal(x, y)
+    for a, b, x, y in zip(l2a, l2b, r2a, r2b):
+        assert np.allclose(x, (a + b) / 2, atol=tol * max(1.0, np.abs(a).max())) and np.array_equal(x, y)
+    # calibration: both ranks hold the same ready order (the last layer's parameters first) and the same bucket order;
+    # after it, every bucket but possibly the last was launched from inside backward, in index order, on both ranks
+    assert oa == ob and oa[0] in (4, 5) and oa[-1] in (0, 1)
+    assert lda == ldb and lfa == lfb == list(range(nb))
+    assert lda == list(range(len(lda))) and len(lda) >= nb - 1
 
 
 def _bench(*argv, env=None):
