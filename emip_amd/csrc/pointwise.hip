@@ -8,11 +8,6 @@
 extern "C" int emip_dwconv3x3_dual(const void*, long, void*, long, void*, long, const float*, const float*, int, int, int, int,
                                    int, int, void*);
 
-namespace emip_internal {
-int dwconv_tiled_try(const void* X, long ldx, void* Y, long ldy, const float* Wt, const float* bias, int B, int H, int Wd,
-                     int C, int act, hipStream_t s);     // dwconv.hip: the LDS-tiled bf16 kernel; > 0 = not eligible
-}
-
 namespace {
 
 constexpr int kMaxBlocks = 256 * 16;  // memory-bound grids: cap and grid-stride
@@ -1095,10 +1090,6 @@ extern "C" int emip_dwconv3x3_dual(const void* X, long ldx, void* Y, long ldy, v
     EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
     const int nv = dtype == EMIP_F32 ? 4 : 8;
     EMIP_REQUIRE(act >= EMIP_ACT_NONE && act <= EMIP_ACT_GELU);
-    if (dtype == EMIP_BF16 && Z == nullptr) {
-        const int rc = emip_internal::dwconv_tiled_try(X, ldx, Y, ldy, Wt, bias, B, H, Wd, C, act, (hipStream_t)stream);
-        if (rc <= 0) return rc;
-    }
     if (C % nv == 0 && ldx % nv == 0 && ldy % nv == 0 && aligned16(X) && aligned16(Y)) {
         const long total = (long)B * H * ((Wd + 3) / 4) * (C / nv);
         if (Z) EMIP_REQUIRE(ldz % nv == 0 && ldz >= C && aligned16(Z));
