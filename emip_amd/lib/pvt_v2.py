@@ -17,12 +17,6 @@ from ..autograd import DropPathAddFn, ConvFn, DwConvFn, LayerNormFn, LinearFn, S
 from ..nn_base import EmipModule, f32, pack_conv, pack_dw, pack_linear, to_cl, to_planar
 
 
-# emip_mlp_tail (dwconv3x3 + GELU + fc2 in one kernel, hidden tensor kept on chip) is parity-tested but measured SLOWER
-# than emip_dwconv3x3 + emip_gemm on MI355X (stage 3, 8 images: 54 us vs 29 us; its K loop is bound by the latency of
-# the per-chunk weight / neighbour loads; end to end 801 vs 894 pairs/s at 16 pairs, 960 vs 1024 at 64 pairs in flight),
-# so the two-kernel path stays the default.
-FUSED_MLP_TAIL = False
-
 # LayerNorm elimination on the inference path: the three LayerNorms of a block (norm1, norm2 and the one
 # behind the spatial-reduction conv) are not launched at all.  The producer of the residual stream (proj / fc2 GEMM, the sr
 # conv, the patch-embed LayerNorm) accumulates per-row (sum, sum of squares) in its epilogue, gamma is folded into the
@@ -104,9 +98,6 @@ class Mlp(EmipModule):
                     self.fc2.weight, self.fc2.bias),
             lambda a, b, c, d, e, f: (pack_linear(a, dt), f32(b), pack_dw(c), f32(d), pack_linear(e, dt), f32(f)))
         t = ops.gemm(h, w1, bias=b1)
-        if FUSED_MLP_TAIL and w2.shape[0] in (64, 128, 320, 512):
-            # depthwise 3x3 + GELU + fc2 + residual in one kernel: the activated hidden tensor never reaches HBM
-            return ops.mlp_tail(t, wd, bd, w2, b2, residual, out=residual)
         t = ops.dwconv3x3(t, wd, bd, act=ops.ACT_GELU)
         return ops.gemm(t, w2, bias=b2, res=residual, out=residual)
 

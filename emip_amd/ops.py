@@ -790,39 +790,6 @@ def flow_warp_bwd(x, flow, dy):
     return df
 
 
-def mlp_tail(h, wt, bdw, w2, b2, res, out=None):
-    """h [B,H,W,Ch] (fc1 output) -> res + b2 + GELU(dwconv3x3(h) + bdw) w2^T as [B,H,W,N]; the activated hidden tensor
-    stays on chip.  w2 [N, Ch] packed like a Linear weight."""
-    _dev(h)
-    B, H, W, Ch = h.shape
-    N = w2.shape[0]
-    assert w2.shape[1] == Ch and w2.is_contiguous() and w2.dtype == h.dtype
-    _, _, ldh = rows(h)
-    if out is None:
-        out = torch.empty((B, H, W, N), dtype=h.dtype, device=h.device)
-    _, _, ldy = rows(out)
-    ldr = rows(res)[2] if res is not None else 0
-    _lib.call("emip_mlp_tail", _p(h), ldh, _p(wt), _p(bdw), _p(w2), Ch, _p(b2), _p(res), ldr, _p(out), ldy, B, H, W, Ch,
-              N, dt_code(h.dtype), _stream())
-    return out
-
-
-def mlp_head(x, w1, b1, wt, bdw, out=None):
-    """x [B,H,W,C] (normed tokens) -> GELU(dwconv3x3(x w1^T + b1) + bdw) as [B,H,W,Ch]; the fc1 output stays in LDS.
-    w1 [Ch, C] packed like a Linear weight, wt depthwise weights [9, Ch] f32."""
-    _dev(x)
-    B, H, W, C = x.shape
-    Ch = w1.shape[0]
-    assert w1.shape[1] == C and w1.is_contiguous() and w1.dtype == x.dtype
-    _, _, ldx = rows(x)
-    if out is None:
-        out = torch.empty((B, H, W, Ch), dtype=x.dtype, device=x.device)
-    _, _, ldg = rows(out)
-    _lib.call("emip_mlp_head", _p(x), ldx, _p(w1), _p(b1), _p(wt), _p(bdw), _p(out), ldg, B, H, W, C, Ch,
-              dt_code(x.dtype), _stream())
-    return out
-
-
 def gemm_heads(a, w, out, batch, heads, M, N, K, lda, ldw, ldc, bsA, hsA, bsW, hsW, bsC, hsC):
     """per (b, h): out = a w^T on raw views; operand of (b, h) at b * bs + h * hs (batch = B * heads)"""
     _dev(a)

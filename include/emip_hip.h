@@ -108,7 +108,6 @@ int emip_gemm_tile(long M, long N, long batch, long K);
 
 /* Tuning knob for experiments (not part of the drop-in contract): key 0 = LDS buffers of the GEMM main loop. */
 int emip_debug_set(int key, int value);
-int emip_debug_set_head(int variant);           /* emip_mlp_head tiling: 0 row bands, 2 8x8 patches, 4 14x14 patches */
 int emip_debug_set_tn(int target_workgroups);   /* 0 = heuristic split count of emip_gemm_tn (tuning only) */
 
 /* NHWC convolution as implicit GEMM, weights packed [Cout][KH][KW][Cin], same epilogue.
@@ -369,19 +368,6 @@ int emip_colscale_add(const void* A, long lda, const void* Bp, long ldb, const f
 int emip_mdta_bwd_small(const float* G, const float* nq2, const float* nk2, const float* temperature, const void* A,
                         const float* dA, void* dG, void* dGT, float* sq, float* sk, float* dtau, int B, int heads,
                         int dtype, void* stream);
-
-/* Fused tail of the PVTv2 Mlp (lib/pvt_v2.py:45-54): Y = R + b2 + GELU(dwconv3x3(H) + bdw) W2^T with H the fc1 output
- * [B][Hh][Ww][Ch] channels-last, Wt the depthwise weights [9][Ch] (f32), W2 [N][Ch]; N in {64,128,320,512}.  The
- * activated hidden tensor never reaches HBM.  R may alias Y. */
-int emip_mlp_tail(const void* H, long ldh, const float* Wt, const float* bdw, const void* W2, long ldw, const float* b2,
-                  const void* R, long ldr, void* Y, long ldy, int B, int Hh, int Ww, int Ch, int N, int dtype,
-                  void* stream);
-
-/* Fused head of the PVTv2 Mlp (lib/pvt_v2.py:45-54,316-327): G = GELU(dwconv3x3(X W1^T + b1) + bdw), X [B][H][W][C]
- * channels-last (the LayerNorm-ed tokens), W1 [Ch][C], Wt the depthwise weights [9][Ch] (f32), G [B][H][W][Ch].
- * The fc1 output stays in LDS (band of image rows x 128-byte channel slab per workgroup); fc2 reads G via emip_gemm. */
-int emip_mlp_head(const void* X, long ldx, const void* W1, const float* b1, const float* Wt, const float* bdw, void* G,
-                  long ldg, int B, int H, int W, int C, int Ch, int dtype, void* stream);
 
 /* Backward of the swin window split / merge (gmflow/utils.py:5-51, transformer.py:76-101).
  * Window gather (scatter != 0: the inverse): dst[(b*nwin+win)*Lp + t] = src[b][table[win][t]], t < L <= Lp -- the
