@@ -30,42 +30,70 @@ F_ALG_PAIR_GFLOP = 270.63      # algorithmic forward FLO
 PEAK_HBM_TBS = 8.0             # HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def _algo_flops(name, a):
-    """algorithmic FLOPs and algorithmic HBM bytes (every operand read once, every result written once, bf16 = 2 B) of
-    one emip_gemm / emip_conv2d / emip_attention launch; zero-padded channels are not counted"""
-    if name == "emip_attention":
-        batch, heads, nwin, Lq, Lk, D, DV = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
-        dv = 2 if DV == 32 else DV                          # DV=32 carries a 2-channel value (flow / pixel grid)
-        bkv = 64
-        z = batch * heads * nwin
-        byt = 2.0 * z * (Lq * D + Lk * D + Lk * dv) + (4.0 if a[-3] else 2.0) * z * Lq * dv
-        if a[4]:                                            # raw scores (the correlation volume) written out
-            byt += 2.0 * z * Lq * Lk
-        return 2.0 * z * Lq * Lk * (D + dv), ("attn", D, DV, bkv, "+scores" if a[4] else ""), byt
+WAVES = {(256, 128): (4, 2), (128, 256): (2, 4), (128, 128): (2, 4), (128, 320): (2, 4), (64, 320): (2, 4), (256, 64): (4, 2),
+         (256, 256): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4)}
+
+
+def _g8_key(lib, cfg, conv, lnt):
+    """kernel symbol of a gemm8 configuration, as rocprofv3 prints it"""
+    t = lib.emip_gemm8_cfg_tile(cfg)
+    bm, bn = t // 1000, t % 1000
+    wm, wn = WAVES[(bm, bn)]
+    return "gemm8_kernel<%d, %d, %d, %d, %d, %s, %s>" % (bm, bn, wm, wn, lib.emip_gemm8_cfg_stages(cfg, 1 if lnt else 0),
+                                                          "true" if conv else "false", "true" if lnt else "false")
+
+
+def _launch_info(lib, name, a):
+    """(algorithmic FLOPs, kernel symbol, algorithmic HBM bytes) of one C-ABI launch: every operand read once and every
+    result written once, bf16 = 2 B; zero-padded channels are not counted; None for launches without a contraction"""
     if name == "emip_sra_attention":      # (Q, KV, O, batch, heads, Lq, Lk, C, scale, stream)
         batch, heads, Lq, Lk = a[3], a[4], a[5], a[6]
         z = batch * heads
-        return 4.0 * z * Lq * Lk * 64, ("sra",), 2.0 * z * (2 * Lq * 64 + 2 * Lk * 64)
-    if name in ("emip_gemm", "emip_gemm_ln"):
-        M, N, K, batch = a[6], a[7], a[8], a[16]
-        ln = name == "emip_gemm_ln" and a[21] is not None     # normalising loader: the register-staged loop
-        lds_dma = (K % 64 == 0) and (a[9] % 64 == 0) and not ln   # bf16: dense GEMMs with whole K tiles use LDS-DMA
-        K = {344: 340}.get(K, K)
-        byt = 2.0 * batch * (M * K + N * K + M * N * (2 if a[5] else 1))
-        return 2.0 * M * N * K * batch, (M, N, batch, False, ("1,ln" if ln else (3 if lds_dma else 1)), a[8]), byt
-    if name == "emip_gemm_lne":      # (A, W, C, bias, R, M, N, K, ...): dense LDS-DMA loop, LayerNorm on the output side
-        M, N, K = a[5], a[6], a[7]
-        byt = 2.0 * (M * K + N * K + M * N * (2 if a[4] else 1))
-        return 2.0 * M * N * K, (M, N, 1, False, 3 if K % 64 == 0 else 1, K), byt
-    if name in ("emip_conv2d", "emip_conv2d_ln"):
-        B, H, W, Cin, Cout, KH, KW, s, p = a[5], a[6], a[7], a[8], a[10], a[11], a[12], a[13], a[14]
+        return 4.0 * z * Lq * Lk * 64, "sra_kernel", 2.0 * z * (2 * Lq * 64 + 2 * Lk * 64)
+    if name in ("emip_attention", "emip_attention_splitkv"):      # splitkv: the same arguments + (ksplit, workspace)
+        batch, heads, nwin, Lq, Lk, D, DV = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
+        dv = 2 if DV == 32 else DV                          # DV=32 carries a 2-channel value (flow / pixel grid)
+        z = batch * heads * nwin
+        o_f32 = a[-3] if name == "emip_attention" else a[-5]
+        byt = 2.0 * z * (Lq * D + Lk * D + Lk * dv) + (4.0 if o_f32 else 2.0) * z * Lq * dv
+        if a[4]:                                            # raw scores (the correlation volume) written out
+            byt += 2.0 * z * Lq * Lk
+        return 2.0 * z * Lq * Lk * (D + dv), "attn_kernel<bf16,%d,%d,64>%s" % (D, DV, "+scores" if a[4] else ""), byt
+    if name in ("emip_gemm", "emip_gemm_ln", "emip_gemm_lne"):
+        if name == "emip_gemm_lne":      # (A, W, C, bias, R, M, N, K, lda, ldw, ...)
+            M, N, K, lda, ldw, K1, batch, a2, res, ln = a[5], a[6], a[7], a[8], a[9], a[7], 1, None, a[4], None
+        else:                            # (A, A2, W, C, bias, R, M, N, K, K1, lda, lda2, ldw, ldc, ldr, act, batch, ...)
+            M, N, K, K1, lda, lda2, ldw, batch, a2, res = a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[16], a[1], a[5]
+            ln = a[21] if name == "emip_gemm_ln" else None
+        cfg = 0
+        if batch == 1 and ln is None:
+            cfg = lib.emip_gemm8_dispatch(M, N, K, lda, ldw, K1, 1 if a2 else 0, a[11] if a2 else 0)
+        if cfg:
+            key = _g8_key(lib, cfg, False, False)
+        else:
+            t = lib.emip_gemm_tile(M, N, batch, K)
+            key = "gemm_kernel<bf16,%d,%d,dense>" % (t // 1000, t % 1000)
+        Kr = {344: 340}.get(K, K)
+        return 2.0 * M * N * Kr * batch, key, 2.0 * batch * (M * Kr + N * Kr + M * N * (2 if res else 1))
+    if name in ("emip_conv2d", "emip_conv2d_ln", "emip_conv8"):
+        B, H, W, Cin, ldx, Cout, KH, KW, s, p = a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14]
         Ho, Wo = (H + 2 * p - KH) // s + 1, (W + 2 * p - KW) // s + 1
         cin = {8: 3, 136: 130}.get(Cin, Cin)
         byt = 2.0 * (B * H * W * cin + Cout * KH * KW * cin + B * Ho * Wo * Cout * (2 if a[4] else 1))
-        ln = name == "emip_conv2d_ln" and a[20] is not None
-        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin, (B * Ho * Wo, Cout, 1, True, "1,ln" if ln else 1,
-                                                          KH * KW * Cin), byt
-    return 0.0, None, 0.0
+        if name == "emip_conv8":         # explicit 8-wave entry; a[18] = ln_stats (per-tap LayerNorm)
+            lnt = a[18] is not None
+            cfg = a[-2] or ((8 if Cout <= 64 else 9) if lnt else lib.emip_gemm8_auto_cfg(B * Ho * Wo, Cout, KH * KW * Cin))
+            key = _g8_key(lib, cfg, True, lnt)
+        else:
+            ln = name == "emip_conv2d_ln" and a[20] is not None
+            cfg = 0 if ln else lib.emip_conv8_dispatch(B * Ho * Wo, Cout, Cin, KH, KW, (B * H * W - 1) * ldx + Cin)
+            if cfg:
+                key = _g8_key(lib, cfg, True, False)
+            else:
+                t = lib.emip_gemm_tile(B * Ho * Wo, Cout, 1, KH * KW * Cin)
+                key = "gemm_kernel<bf16,%d,%d,conv>" % (t // 1000, t % 1000)
+        return 2.0 * B * Ho * Wo * Cout * KH * KW * cin, key, byt
+    return None
 
 
 def kernel_breakdown(net, im1, im2, splits=1):
@@ -78,13 +106,12 @@ def kernel_breakdown(net, im1, im2, splits=1):
     rec = []
     n = im1.shape[0] // splits
     # A long blocker GEMM is queued in front of every pass so that the host runs AHEAD of the GPU: the event / kernel /
-    # event packets then execute back to back and an event pair brackets the kernel only (measured without it: +3.8 us
-    # of dispatch latency per launch on an idle queue, which is a third of a 10 us kernel).
+    # event packets then execute back to back and an event pair brackets the kernel only.
     ba = torch.randn(8192, 8192, device=im1.device).to(torch.bfloat16)
     bo = torch.empty_like(ba)
     with torch.no_grad():
         for i in range(splits):
-            for _ in range(40):                      # ~1.3 ms each
+            for _ in range(40):                      # ~1 ms each
                 ops.gemm(ba, ba, out=bo)
             _lib.profile(rec)
             net.run(im1[i * n:(i + 1) * n], im2[i * n:(i + 1) * n])
@@ -93,15 +120,8 @@ def kernel_breakdown(net, im1, im2, splits=1):
     agg = {}
     for name, a, s, e in rec:
         ms = s.elapsed_time(e)
-        fl, tile, byt = _algo_flops(name, a)
-        key = name
-        if tile is not None and tile[0] == "sra":
-            key = "sra_kernel"
-        elif tile is not None and tile[0] == "attn":
-            key = "attn_kernel<bf16,%d,%d,%d>%s" % tile[1:]
-        elif tile is not None:
-            t = lib.emip_gemm_tile(tile[0], tile[1], tile[2], tile[5])
-            key = "gemm_kernel<bf16,%d,%d,%s,%s>" % (t // 1000, t % 1000, "conv" if tile[3] else "dense", tile[4])
+        info = _launch_info(lib, name, a)
+        fl, key, byt = info if info is not None else (0.0, name, 0.0)
         d = agg.setdefault(key, [0.0, 0.0, 0, 0.0])
         d[0] += ms
         d[1] += fl
@@ -110,27 +130,32 @@ def kernel_breakdown(net, im1, im2, splits=1):
     return agg
 
 
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv")
+
+
 def rocprof_avg(key):
-    """average kernel-only duration of the same symbol in the committed rocprofv3 --kernel-trace --stats summary of this
-    command (profiles/r01_bench_kernel_stats_final.csv); a HIP-event pair additionally sees ~2 us of marker latency"""
+    """average kernel duration of the same symbol in the committed rocprofv3 --kernel-trace --stats summary of this
+    command (profiles/r02_bench_kernel_stats.csv); a HIP-event pair additionally sees the marker latency"""
     import csv
     import re
-    path = os.path.join(ROOT, "profiles", "r01_bench_kernel_stats_final.csv")
-    if not os.path.exists(path):
+    if not os.path.exists(PROFILE_CSV):
         return None
-    m = re.match(r"(gemm|attn)_kernel<bf16,(.*)>", key.replace("+scores", ""))
-    if not m:
-        return None
-    f = m.group(2).split(",")
-    if m.group(1) == "gemm":
-        pat = "gemm_kernelIDF16bLi%sELi%sELb%dELi%sELb%dEE" % (f[0], f[1], 1 if f[2] == "conv" else 0, f[3],
-                                                              1 if len(f) > 4 and f[4] == "ln" else 0)
+    key = key.replace("+scores", "")
+    m = re.match(r"(gemm|attn)_kernel<bf16,(.*)>", key)
+    if m:        # 4-wave bodies: mangled names in the summary
+        f = m.group(2).split(",")
+        if m.group(1) == "gemm":
+            pats = ["gemm_kernelIDF16bLi%sELi%sELb%dE" % (f[0], f[1], 1 if f[2] == "conv" else 0)]
+        else:
+            pats = ["attn_kernelIDF16bLi%sELi%sELi%sEE" % (f[0], f[1], f[2])]
     else:
-        pat = "attn_kernelIDF16bLi%sELi%sELi%sEE" % (f[0], f[1], f[2])
-    for r in csv.DictReader(open(path)):
-        if pat in r["Name"]:
-            return round(float(r["AverageNs"]) / 1e3, 2)
-    return None
+        pats = [key]
+    tot = calls = 0.0
+    for r in csv.DictReader(open(PROFILE_CSV)):
+        if any(p in r["Name"] for p in pats):
+            tot += float(r["TotalDurationNs"])
+            calls += float(r["Calls"])
+    return round(tot / calls / 1e3, 2) if calls else None
 
 
 def named_roofline(agg, key, what):
@@ -444,7 +469,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=4, help="sub-batches replayed concurrently on separate HIP streams")
+    ap.add_argument("--streams", type=int, default=2, help="sub-batches replayed concurrently on separate HIP streams")
     ap.add_argument("--no-sub", action="store_true", help="skip the train / long / f32 sub-records of the default run")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the N-rank launch and timing plumbing only")
     args = ap.parse_args()
@@ -472,12 +497,9 @@ def main():
     from emip_amd.graph import GraphedShort
     from emip_amd.model.EMIP_short.model import CoUpdater
     _lib.load()
-    if os.environ.get("EMIP_TILE_SHARE"):
-        _lib.call("emip_debug_set", 4, int(os.environ["EMIP_TILE_SHARE"]))
-    if os.environ.get("EMIP_PAIR_TWO"):
-        _lib.call("emip_debug_set", 8, int(os.environ["EMIP_PAIR_TWO"]))
-    if os.environ.get("EMIP_GEMM_NBUF"):
-        _lib.call("emip_debug_set", 0, int(os.environ["EMIP_GEMM_NBUF"]))
+    lib = _lib.load()
+    for sym in ("emip_debug_set", "emip_debug_set_tn", "emip_debug_set_lnb", "emip_debug_set_dww", "emip_tuning_gemm8_dbg"):
+        assert not hasattr(lib, sym), "bench.py must run on the product library (no calibration / work-skipping switches): " + sym
     g = os.path.join(ROOT, "tests", "golden")
     margs = json.load(open(os.path.join(g, "model_args.json")))
     sd = state_dict_from_manifest(json.load(open(os.path.join(g, "short_state_manifest.json"))), 0)
@@ -523,7 +545,7 @@ def main():
         value = pairs / dt
         nsplit = nsub if args.no_graph else runner.splits
         agg = kernel_breakdown(net, im1, im2, nsplit)
-        kernels = {k: v for k, v in agg.items() if v[1] > 0}
+        kernels = {k: v for k, v in agg.items() if v[1] > 0 and "blocker" not in k}
         dom = max(kernels, key=lambda k: kernels[k][0])
         ms, fl, cnt, byt = kernels[dom]
         tflops = fl / (ms * 1e-3) / 1e12
@@ -568,7 +590,7 @@ def main():
                          "same_kernel_unsplit_batch_TFLOPs": (round(whole[1] / (whole[0] * 1e-3) / 1e12, 2)
                                                               if whole else None)})
         out["roofline_named"] = {
-            "sra": named_roofline(agg, "sra_kernel" if "sra_kernel" in agg else "attn_kernel<bf16,64,64,64>",
+            "sra": named_roofline(agg, "sra_kernel",
                                   "PVTv2 spatial-reduction attention softmax(q k^T / 8) v, lib/pvt_v2.py:113-125"),
             "correlation": named_roofline(agg, "attn_kernel<bf16,128,32,64>+scores",
                                           "GMFlow all-pairs correlation + softmax expectation, raw correlation "
@@ -586,7 +608,7 @@ def main():
             del runner
         torch.cuda.empty_cache()
         try:
-            sub["train"] = measure_train(32, 5, 2, world, rank, dev, dist, red_dev)
+            sub["train"] = measure_train(32, 6, 4, world, rank, dev, dist, red_dev)
         except Exception as e:                                   # noqa: BLE001
             sub["train"] = {"error": repr(e)[:300]}
         if world == 1:

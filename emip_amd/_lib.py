@@ -10,6 +10,7 @@ import re
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "emip_hip.h")
 LIB_PATH = os.environ.get("EMIP_HIP_LIB") or os.path.join(_HERE, "libemip_hip.so")   # override: A/B calibration of two builds
+TUNING = os.path.basename(LIB_PATH).startswith("libemip_hip_tuning")
 
 _CTYPES = {
     "const void*": ctypes.c_void_p, "void*": ctypes.c_void_p,
@@ -29,6 +30,8 @@ def parse_header(path=HEADER):
     """-> {name: [(ctype_name, arg_name), ...]} for every `int emip_*(...)` prototype."""
     src = open(path).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    if not TUNING:       # the calibration switches exist in libemip_hip_tuning.so only
+        src = re.sub(r"#ifdef EMIP_TUNING.*?#endif", "", src, flags=re.S)
     protos = {}
     for m in re.finditer(r"\bint\s+(emip_\w+)\s*\(([^)]*)\)\s*;", src):
         name, args = m.group(1), m.group(2).strip()

@@ -676,10 +676,12 @@ extern "C" int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy,
 
 // dW f32 [9][C] and db f32 [C] (may be NULL) are ACCUMULATED into
 static int g_dww_chunks = 0;
+#ifdef EMIP_TUNING
 extern "C" int emip_debug_set_dww(int chunks) {
     g_dww_chunks = chunks;
     return EMIP_OK;
 }
+#endif
 
 extern "C" int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, long lddy, float* dW, float* db, int B,
                                     int H, int Wd, int C, int dtype, void* stream) {

@@ -556,6 +556,12 @@ extern "C" int emip_gemm8_auto_cfg(int M, int N, int K) { return pick_cfg(M, N, 
 extern "C" int emip_tuning_gemm8_dbg(int v) { g8_dbg = v; return 0; }
 #endif
 
+// introspection for bench.py: the tile (BM * 1000 + BN) and ring depth of a configuration, 0 for an unknown one
+extern "C" int emip_gemm8_cfg_tile(int cfg) { return cfg >= 1 && cfg <= NCFG ? g_cfg[cfg - 1].bm * 1000 + g_cfg[cfg - 1].bn : 0; }
+extern "C" int emip_gemm8_cfg_stages(int cfg, int lnt) {
+    return cfg >= 1 && cfg <= NCFG ? (lnt ? NST_LNT : g_cfg[cfg - 1].nst) : 0;
+}
+
 // ---- dispatch hooks of emip_gemm_ln / emip_conv2d_splitk (gemm.hip): > 0 = not eligible, the 4-wave body runs -----------
 static int g8_enabled() {
     static int v = -1;
@@ -579,6 +585,15 @@ int conv8_choice(int M, int Cout, int Cin, int KH, int KW, long a_elems) {
     return pick_cfg(M, Cout, (long)KH * KW * Cin);
 }
 }  // namespace emip_internal
+
+// introspection for bench.py: the configuration emip_gemm / emip_gemm_ln(e) / emip_conv2d hand a bf16 launch to (0 = the
+// 4-wave body of gemm.hip runs it)
+extern "C" int emip_gemm8_dispatch(int M, int N, int K, long lda, long ldw, int K1, int has_a2, long lda2) {
+    return emip_internal::gemm8_choice(M, N, K, lda, ldw, K1, has_a2 != 0, lda2);
+}
+extern "C" int emip_conv8_dispatch(int M, int Cout, int Cin, int KH, int KW, long a_elems) {
+    return emip_internal::conv8_choice(M, Cout, Cin, KH, KW, a_elems);
+}
 
 extern "C" int emip_gemm8(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M,
                           int N, int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act,

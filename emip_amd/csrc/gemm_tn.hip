@@ -221,7 +221,9 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
 }  // namespace
 
 int g_tn_target = 0;   // 0 = heuristic; tools/gemm_tn_bench.py overrides it
+#ifdef EMIP_TUNING
 extern "C" int emip_debug_set_tn(int target) { g_tn_target = target > 0 ? target : 0; return EMIP_OK; }
+#endif
 
 namespace {
 template <bool CONV>

@@ -1027,10 +1027,12 @@ extern "C" int emip_rows_finalize(const float* A, long lda, void* Y, long ldy, f
 }
 
 static int g_lnb_wide = 1;
+#ifdef EMIP_TUNING
 extern "C" int emip_debug_set_lnb(int wide) {
     g_lnb_wide = wide;
     return EMIP_OK;
 }
+#endif
 
 // dgamma / dbeta are ACCUMULATED into (the caller zero-fills them, or keeps accumulating across micro-batches)
 extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx,

@@ -80,6 +80,38 @@ def synthetic_pair(batch: int, size: int = 352, seed: int = 1234, shift=(3, -2))
     return ((im1 - mean) / std).contiguous(), ((im2 - mean) / std).contiguous()
 
 
+def flow_conditioned(sd):
+    """The "well-conditioned flow" variant of a filled state dict: with random weights the GMFlow
+    transformer and the camouflage feeder add unit-variance, position-mixing messages to the matching features, the
+    correlation softmax is nearly flat and the flow of the REFERENCE itself moves by 7e-3 px when only its thread count
+    changes.  Here the additive messages are switched off (LayerNorm affine of every GMFlow transformer message = 0, output
+    projections of `injector` = 0) and the CNN features are scaled by 3 (peaked softmax): the reference's flow then repeats to
+    1e-6 px across thread counts, so the matching / propagation / convex-upsampling path can be pinned to 0.05 px.  Every
+    other tensor is the standard filler's."""
+    out = dict(sd)
+    for k, v in sd.items():
+        if k.startswith("GMFlow.transformer.layers.") and k.rsplit(".", 2)[-2] in ("norm1", "norm2"):
+            out[k] = torch.zeros_like(v)
+        elif k.startswith("injector.transformer.") and k.endswith("project_out.weight"):
+            out[k] = torch.zeros_like(v)
+        elif k in ("GMFlow.backbone.conv2.weight", "GMFlow.backbone.conv2.bias"):
+            out[k] = v * 3.0
+    return out
+
+
+def textured_pair(size: int = 352, seed: int = 77, shift=(16, -8)):
+    """White-noise frame pair, image2 = image1 shifted by a multiple of 8 px (exact at the 1/8 feature resolution),
+    ImageNet-normalised: every 8x8 cell is distinctive, unlike the smooth field of synthetic_pair."""
+    rs = np.random.RandomState(seed)
+    img = torch.from_numpy(rs.uniform(0, 1, (1, 3, size + 64, size + 64)).astype(np.float32))
+    dy, dx = shift
+    im1 = img[:, :, 32:32 + size, 32:32 + size]
+    im2 = img[:, :, 32 + dy:32 + dy + size, 32 + dx:32 + dx + size]
+    mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
+    std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    return ((im1 - mean) / std).contiguous(), ((im2 - mean) / std).contiguous()
+
+
 def synthetic_gt(batch: int, size: int = 352, seed: int = 99):
     rs = np.random.RandomState(seed)
     low = torch.from_numpy(rs.uniform(0, 1, (batch, 1, 8, 8)).astype(np.float32))

@@ -199,18 +199,19 @@ class Block(EmipModule):
 
         def build(g1, b1, g2, b2, wq, bq, wkv, bkv, wp, bp, w1, bb1, wd, bd, w2, bb2, *srp):
             f = lambda t: t.detach().float()
+            mv = lambda w_, v_: (w_ * v_).sum(1)      # W @ v as an elementwise product + row sum (no vendor BLAS at pack time)
             g1, b1, g2, b2 = f(g1), f(b1), f(g2), f(b2)
-            out = dict(q=(f(wq) * g1).to(dt).contiguous(), bq=(f(bq) + f(wq) @ b1).contiguous(),
+            out = dict(q=(f(wq) * g1).to(dt).contiguous(), bq=(f(bq) + mv(f(wq), b1)).contiguous(),
                        p=pack_linear(wp, dt), bp=f32(bp),
-                       w1=(f(w1) * g2).to(dt).contiguous(), b1=(f(bb1) + f(w1) @ b2).contiguous(),
+                       w1=(f(w1) * g2).to(dt).contiguous(), b1=(f(bb1) + mv(f(w1), b2)).contiguous(),
                        wd=pack_dw(wd), bd=f32(bd), w2=pack_linear(w2, dt), b2=f32(bb2))
             if sr > 1:
                 wsr, bsr, gs, bs = (f(t) for t in srp)
                 out.update(sr=pack_conv(wsr * g1.view(1, -1, 1, 1), dt),
                            bsr=(bsr + (wsr * b1.view(1, -1, 1, 1)).sum((1, 2, 3))).contiguous(),
-                           kv=(f(wkv) * gs).to(dt).contiguous(), bkv=(f(bkv) + f(wkv) @ bs).contiguous())
+                           kv=(f(wkv) * gs).to(dt).contiguous(), bkv=(f(bkv) + mv(f(wkv), bs)).contiguous())
             else:
-                out.update(kv=(f(wkv) * g1).to(dt).contiguous(), bkv=(f(bkv) + f(wkv) @ b1).contiguous())
+                out.update(kv=(f(wkv) * g1).to(dt).contiguous(), bkv=(f(bkv) + mv(f(wkv), b1)).contiguous())
             # column sums of the packed (rounded) weights: the output-side form of the folded LayerNorm (emip_gemm_lne)
             for k in ("q", "kv", "w1"):
                 out["s" + k] = out[k].float().sum(1).contiguous()

@@ -58,7 +58,9 @@ class Model_long(EmipModule):
     def forward_streams(self, frames0, frames1, index, memory_k, memory_v):
         """frames0/frames1: [S,3,H,W]; memory_k/v: [S,1,128,T,44,44] or None.  Returns (masks [S,1,H,W], keys, values)."""
         if torch.is_grad_enabled() and not self.training and any(p.requires_grad for p in self.parameters()):
-            raise RuntimeError("emip_amd Model_long in eval mode: wrap inference in torch.no_grad()")
+            # eval mode with autograd on: same values as the reference, computed without a graph (see CoUpdater.forward)
+            with torch.no_grad():
+                return self.forward_streams(frames0, frames1, index, memory_k, memory_v)
         st = self.short_term
         S = frames0.shape[0]
         if index == 0:

@@ -22,6 +22,12 @@ from .motion.gmflow.gmflow import GMFlow
 from .motion.PromptInteract import Injector
 
 
+import os as _os
+# inference: GMFlow's CNN encoder on a side stream beside the PVT backbone.  Measured on MI355X (16 pairs, bf16): one graph
+# 1007 -> 1029 pairs/s, two sub-batch graphs 1073 -> 1056: the two-graph replay already fills the idle phases, so it is off
+# by default (EMIP_FORK_CNN=1 turns it on)
+FORK_CNN = _os.environ.get("EMIP_FORK_CNN", "0") != "0"
+
 class CoUpdater(EmipModule):
     def __init__(self, args=None):
         super().__init__()
@@ -77,13 +83,32 @@ class CoUpdater(EmipModule):
             y = ops.conv2d(x, w0, 3, 3, 1, 1, bias=b0, act=ops.ACT_RELU)
         return ops.conv2d(y, w3, 3, 3, 1, 1, bias=b3)
 
+    def _side_stream(self, device):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != device:
+            st = torch.cuda.Stream(device=device)
+            object.__setattr__(self, "_side", st)
+        return st
+
     def run(self, image1, image2):
         """Planar images [B,3,H,W] -> (mask planar f32, flow predictions [2B,2,H,W] list, intermediates)."""
         dt = self.cdtype
         B = image1.shape[0]
         imgs = to_cl(torch.cat((image1, image2), 0), dt, 8)            # [2B,H,W,8]
-        fea = self.backbone.feat_net.run(imgs)                         # stages 2..4 of both frames
-        gm = self.GMFlow.backbone.run(imgs)                            # [2B,44,44,128]
+        if FORK_CNN and not torch.is_grad_enabled() and imgs.is_cuda:
+            # The GMFlow CNN encoder does not depend on the PVT backbone: run it on a side stream next to it (ONE fork / join
+            # per forward -- also inside a captured hipGraph), so that the phases of one chain fill the idle ones of the other
+            cur = torch.cuda.current_stream(imgs.device)
+            side = self._side_stream(imgs.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                gm = self.GMFlow.backbone.run(imgs)                    # [2B,44,44,128]
+            fea = self.backbone.feat_net.run(imgs)                     # stages 2..4 of both frames
+            cur.wait_stream(side)
+            gm.record_stream(cur)
+        else:
+            fea = self.backbone.feat_net.run(imgs)                     # stages 2..4 of both frames
+            gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
         ab = self.injector.run(gm, fea[0])                             # camouflage feeder (shared weights)
         if torch.is_grad_enabled() and ab.requires_grad:
             preds, corr = self.GMFlow.run_train(ab)
@@ -99,12 +124,21 @@ class CoUpdater(EmipModule):
         return mask, preds
 
     def forward(self, image1, image2):
-        if torch.is_grad_enabled() and not self.training and any(p.requires_grad for p in self.parameters()):
-            # gradients are built for the training configuration (batch-statistics BatchNorm, train.py:38); the
-            # reference's inference drivers all run under torch.no_grad() (test.py:21)
-            raise RuntimeError("emip_amd CoUpdater in eval mode: wrap inference in torch.no_grad()")
         B = image1.shape[0]
-        mask, preds = self.run(image1, image2)
+        if torch.is_grad_enabled() and not self.training and any(p.requires_grad for p in self.parameters()):
+            # eval mode with autograd on (the reference allows the call; none of its drivers does it, test.py:21 runs under
+            # no_grad): the values are the reference's, computed by the inference kernels; the backward kernels exist for the
+            # training configuration only (batch-statistics BatchNorm, train.py:38), so the outputs carry no graph and a
+            # .backward() on them fails where the divergence would begin, not here
+            if not getattr(self, "_warned_eval_grad", False):
+                import warnings
+                warnings.warn("emip_amd CoUpdater.eval() called with autograd enabled: outputs are computed without a graph "
+                              "(use .train() for gradients, torch.no_grad() for inference)")
+                object.__setattr__(self, "_warned_eval_grad", True)
+            with torch.no_grad():
+                mask, preds = self.run(image1, image2)
+        else:
+            mask, preds = self.run(image1, image2)
         flow_fw = [p[:B] for p in preds]
         flow_bw = [p[B:] for p in preds]
         return mask, flow_fw, flow_bw

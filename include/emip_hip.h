@@ -95,6 +95,12 @@ int emip_conv8(const void* X, const void* W, void* Y, const float* bias, const v
                const float* ln_stats, const float* tapsum, float ln_eps, float* out_stats, void* zero_ptr,
                long zero_bytes, int cfg, void* stream);
 int emip_gemm8_auto_cfg(int M, int N, int K);
+/* Introspection (bench.py names the kernel symbol a launch ran on): the configuration the dispatcher inside emip_gemm* /
+ * emip_conv2d* hands a bf16 launch to (0 = the 4-wave body), and a configuration's tile BM*1000+BN / ring depth. */
+int emip_gemm8_dispatch(int M, int N, int K, long lda, long ldw, int K1, int has_a2, long lda2);
+int emip_conv8_dispatch(int M, int Cout, int Cin, int KH, int KW, long a_elems);
+int emip_gemm8_cfg_tile(int cfg);
+int emip_gemm8_cfg_stages(int cfg, int lnt);
 
 /* PVTv2 spatial-reduction attention, bf16, head_dim 64, Lk <= 128 keys (lib/pvt_v2.py:113-125: attn = softmax(q k^T * scale),
  * x = attn v, all heads of all images in one launch).  Q [batch][Lq][C] with head hd at columns hd*64, KV [batch][Lk][2C]
@@ -106,9 +112,6 @@ int emip_sra_attention(const void* Q, const void* KV, void* O, int batch, int he
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
 int emip_gemm_tile(long M, long N, long batch, long K);
 
-/* Tuning knob for experiments (not part of the drop-in contract): key 0 = LDS buffers of the GEMM main loop. */
-int emip_debug_set(int key, int value);
-int emip_debug_set_tn(int target_workgroups);   /* 0 = heuristic split count of emip_gemm_tn (tuning only) */
 
 /* NHWC convolution as implicit GEMM, weights packed [Cout][KH][KW][Cin], same epilogue.
  * nn.Conv2d call sites: lib/pvt_v2.py:187-188,208 (patch embed), :75,107 (SR conv);
@@ -302,7 +305,6 @@ int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B, int H, in
 int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx, const float* gamma,
                        float* dgamma, float* dbeta, int nparts, long part_stride, long M, int C, float eps, int dtype,
                        void* stream);
-int emip_debug_set_lnb(int wide);   /* calibration: 0 = the narrow LayerNorm-backward kernel */
 
 /* Backward of the softmax attentions (lib/pvt_v2.py:113-121; gmflow/transformer.py:46-105,503-533; matching.py:8-41).
  * Row softmax of the first L columns (columns L..ld-1 are written as 0): Y = softmax(X*scale + mask), mask = -100
@@ -335,7 +337,6 @@ int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy, void* DZ, 
 /* Depthwise 3x3 weight/bias gradient (lib/pvt_v2.py:316-327; PromptInteract.py q/kv/ffn dwconv), ACCUMULATED into dW f32 [9][C] and db f32 [C] (db may be NULL). */
 int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, long lddy, float* dW, float* db, int B, int H, int Wd,
                          int C, int dtype, void* stream);
-int emip_debug_set_dww(int chunks);   /* calibration: row chunks per image of the depthwise weight gradient (0 = auto) */
 
 /* Train-mode BatchNorm2d (+ReLU when OUT != NULL) backward (ConvBR, create_backbone.py:22-42; conv_corr, model.py:59-62).  X: pre-BN conv output, OUT: the forward output,
  * fsums: the forward's emip_chan_stats (groups = 1); dgamma/dbeta accumulated; ws: f32 [2*C]. */
@@ -470,6 +471,17 @@ int emip_scatter_u8(unsigned char* img, const int* offs, const unsigned char* va
 int emip_clamp_adamw(const void* recs, const void* blockmap, int nblocks, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float clip, int step, void* stream);
 int emip_adamw_chunk(void);
+
+/* ---- calibration switches: libemip_hip_tuning.so ONLY (make -C emip_amd/csrc tuning, -DEMIP_TUNING) ----------------------
+ * Tile / ring-depth overrides and work-skipping ablations (no stores / no MFMA / no loads) for tools/.  The product
+ * library libemip_hip.so does not contain them (bench.py checks), so nothing a benchmark runs can skip work. */
+#ifdef EMIP_TUNING
+int emip_debug_set(int key, int value);
+int emip_debug_set_tn(int target_workgroups);   /* 0 = heuristic split count of emip_gemm_tn */
+int emip_debug_set_lnb(int wide);               /* 0 = the narrow LayerNorm-backward kernel */
+int emip_debug_set_dww(int chunks);             /* row chunks per image of the depthwise weight gradient (0 = auto) */
+int emip_tuning_gemm8_dbg(int flags);           /* gemm8 ablations: 1 no epilogue stores, 2 no MFMA, 4 no operand loads */
+#endif
 
 #ifdef __cplusplus
 }

@@ -54,16 +54,33 @@ def _worker(rank, port, out):
     net = _build()
     broadcast_parameters(net)
     opt = build_optimizer(net, lr=1e-3, weight_decay=0.0, clip=0.5)
-    red = GradReducer(trainable(net))
+    red = GradReducer(trainable(net), record_events=True)
     im1, im2, gt = _data(rank)
     with torch.enable_grad():                     # train.py:43-60 with the reducer in DDP's place
         _loss(net, im1, im2, gt).backward()
-    red.finish()
+    red.finish()                                  # step 1 is the reducer's calibration step
     p = dict(net.named_parameters())
     grads = {n: p[n].grad.detach().cpu().numpy() for n in NAMES}
     opt.step()
     torch.cuda.synchronize()
-    out.put((rank, {n: p[n].detach().cpu().numpy() for n in NAMES}, grads))
+    params_after = {n: p[n].detach().cpu().numpy() for n in NAMES}
+    # step 2 on the calibrated buckets: gradient-ready order, exchanges start while backward is still running
+    names = {id(q): n for n, q in net.named_parameters()}
+    first_bucket = [names[id(q)] for q in red.buckets[0].params]
+    nbytes = [sum(q.numel() for q in b.params) * 4 for b in red.buckets]
+    dead = len(red.dead)
+    for q in net.parameters():
+        q.grad = None
+    red.begin_step()
+    end_bwd = torch.cuda.Event(enable_timing=True)
+    with torch.enable_grad():
+        _loss(net, im1, im2, gt).backward()
+    end_bwd.record()
+    in_bwd = list(red.launch_log)
+    red.finish()
+    torch.cuda.synchronize()
+    lead_ms = [b.t_launch.elapsed_time(end_bwd) for b in red.buckets[:len(in_bwd)]]      # > 0: launched before backward ended
+    out.put((rank, params_after, grads, (first_bucket[:3], nbytes, dead, in_bwd, list(red.launch_log), lead_ms)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,6 +94,17 @@ def test_two_rank_training_step_keeps_replicas_identical():
     res = [q.get(timeout=600) for _ in range(2)]
     got = {r[0]: r[1] for r in res}
     grads = {r[0]: r[2] for r in res}
+    info = {r[0]: r[3] for r in res}
+    # bucket plan after calibration: identical on both ranks, conv_corr.0.weight (67 MB, ready early) leads its own bucket,
+    # the parameters that never receive a gradient are not exchanged, and every bucket but the last left during backward,
+    # in index order, with time to spare before backward ended
+    assert info[0][:5] == info[1][:5], (info[0][:5], info[1][:5])
+    first, nbytes, dead, in_bwd, log, lead = info[0]
+    print("  buckets (MB):", [round(b / 2 ** 20, 1) for b in nbytes], "dead parameters:", dead, "launched inside backward:", in_bwd,
+          "lead over the end of backward (ms):", [round(x, 2) for x in lead])
+    assert dead >= 100 and log == list(range(len(nbytes))) and in_bwd == list(range(len(in_bwd))) and len(in_bwd) >= len(nbytes) - 1
+    assert any(n == "conv_corr.0.weight" for n in first) or nbytes[0] >= 60 * 2 ** 20 or nbytes[1] >= 60 * 2 ** 20
+    assert all(x > 0 for x in lead) and lead[0] > lead[-1]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

@@ -196,3 +196,16 @@ def test_short_training_step_gradients_vs_reference(golden, short_sd):
                                                               or "patch_embed1" in n) else 1e-2)
         assert err < tol and l2 < tol, (n, err, l2)
     print("oracle vs reference gradients, worst relative deviation", worst)
+
+
+def test_short_eval_flow_well_conditioned(golden, short_sd):
+    """flow outputs under the well-conditioned filler (oracle/make_golden_flow.py): the oracle vs the reference's values"""
+    from emip_amd.filler import flow_conditioned, textured_pair
+    g = golden("short_eval_flow.npz")
+    assert float(g["thread_sensitivity_px"]) < 1e-4          # the reference repeats itself: the problem is well-conditioned
+    im1, im2 = textured_pair()
+    with torch.no_grad():
+        m, fw, bw = O.short_forward(im1, im2, flow_conditioned(short_sd))
+    assert (fw[0][:, :, ::4, ::4] - torch.from_numpy(g["fw"])).abs().max().item() < 1e-3
+    assert (bw[0][:, :, ::4, ::4] - torch.from_numpy(g["bw"])).abs().max().item() < 1e-3
+    assert (m[:, :, ::4, ::4] - torch.from_numpy(g["mask"])).abs().max().item() < 1e-3
