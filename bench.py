@@ -170,7 +170,7 @@ def named_roofline(agg, key, what):
     traffic = None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tf):
-        traffic = json.load(open(tf)).get(key, {}).get("hbm_bytes_per_launch")
+        traffic = json.load(open(tf)).get(key.replace("+scores", ""), {}).get("hbm_bytes_per_launch")
     rec = ({"bound": "hbm", "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
             "frac": round(tbs / PEAK_HBM_TBS, 4)} if hbm else
            {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -558,7 +558,7 @@ def main():
         traffic = None                      # HBM bytes per launch from the committed rocprofv3 PMC passes, if any
         tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(dom, {}).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tf)).get(dom.replace("+scores", ""), {}).get("hbm_bytes_per_launch")
         out = {
             "metric": "frame_pairs_per_sec_352x352_emip_short_fwd", "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

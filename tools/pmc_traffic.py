@@ -15,15 +15,19 @@ import sys
 
 
 def bench_key(name):
+    m = re.search(r"(gemm8_kernel<[^>]*>)", name)          # demangled template instance: exactly bench.py's key
+    if m:
+        return m.group(1)
+    if "sra_kernel" in name:
+        return "sra_kernel"
     m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])EE", name)
     if m:
-        return "gemm_kernel<%s,%s,%s,%s,%s%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
-                                                  "conv" if m.group(4) == "1" else "dense", m.group(5),
-                                                  ",ln" if m.group(6) == "1" else "")
+        return "gemm_kernel<%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
+                                             "conv" if m.group(4) == "1" else "dense")
     m = re.search(r"attn_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELi(\d+)EE", name)
     if m:
         return "attn_kernel<%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
-                                             m.group(4))
+                                             m.group(4))      # bench.py appends "+scores" for the correlation launch
     m = re.search(r"N_1\d+(\w+?)_kernelI", name) or re.search(r"(\w+)_kernel", name)
     return ("emip_" + m.group(1)) if m else name[:60]
 
@@ -60,6 +64,8 @@ def main():
         e["WRITE_SIZE_KB_per_launch"] = round(e.pop("WRITE_SIZE_KB") / n, 1)
         e["hbm_bytes_per_launch"] = int((2 * e["FETCH_SIZE_KB_per_launch"] + e["WRITE_SIZE_KB_per_launch"]) * 1024)
         e["note"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts half of wide coalesced reads"
+    total = sum(e["hbm_bytes_per_launch"] * e["launches_profiled"] for e in res.values())
+    res["_total"] = {"hbm_bytes_all_profiled_launches": int(total), "note": "divide by the forwards profiled (warm-up included)"}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out, len(res), "kernels")
 
