@@ -112,6 +112,68 @@ class LayerNormFn(Function):
         return dx, dg, db, None
 
 
+class LayerNormSkipFn(Function):
+    """(LayerNorm(x), x): the pre-norm residual blocks read x twice, for the norm and for the skip connection.  Handing the
+    skip operand out of THIS node makes both gradients arrive here, and the LayerNorm backward kernel adds the skip path's
+    in its store (emip_layernorm_bwd_res) -- otherwise autograd sums them with one add launch per residual branch."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        y = ops.layernorm(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        ctx.set_materialize_grads(False)
+        return y, x                  # an input returned as an output: autograd re-wraps it as an output of this node
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, gamma = ctx.saved_tensors
+        if dy is None:
+            return dskip, None, None, None
+        dx, dg, db = ops.layernorm_bwd_fresh(x, dy.contiguous(), gamma, ctx.eps,
+                                             dres=None if dskip is None else dskip.contiguous())
+        return dx, dg, db, None
+
+
+class QSrFn(Function):
+    """q = h Wq^T + bq and s = sr_conv(h) (k x k, stride k: non-overlapping patches) of the SAME normed tokens h
+    (lib/pvt_v2.py:105-110): one node, so that the two input gradients meet in the residual epilogue of the q-gradient
+    GEMM instead of in an autograd add launch."""
+
+    @staticmethod
+    def forward(ctx, h, wq, bq, wsr, bsr, wq_p, wq_t, wsr_p, wsr_d, k):
+        q = ops.gemm(h, wq_p, bias=bq)
+        s = ops.conv2d(h, wsr_p, k, k, k, 0, bias=bsr)
+        ctx.save_for_backward(h, wq, wsr)
+        ctx.cfg = (wq_t, wsr_d, k, bq is not None, bsr is not None)
+        return q, s
+
+    @staticmethod
+    def backward(ctx, dq, ds):
+        h, wq, wsr = ctx.saved_tensors
+        wq_t, wsr_d, k, has_bq, has_bsr = ctx.cfg
+        dq, ds = dq.contiguous(), ds.contiguous()
+        B, H, W, C = h.shape
+        dh = dwq = dbq = dwsr = dbsr = None
+        if ctx.needs_input_grad[0]:
+            pm = ops.gemm(ds, wsr_d)                                   # [B,Ho,Wo,k*k*C]
+            dh = ops.depatchify(pm.view(-1, k * k * C), B, ds.shape[1], ds.shape[2], k, C)
+            dh = ops.gemm(dq, wq_t, res=dh, out=dh)                    # + dq Wq, added in the epilogue
+        if ctx.needs_input_grad[1]:
+            if has_bq and ctx.needs_input_grad[2]:
+                dwq, dbq = ops.gemm_tn(dq, h, with_colsum=True)
+            else:
+                dwq = ops.gemm_tn(dq, h)
+            dwq = dwq.view_as(wq)
+        elif has_bq and ctx.needs_input_grad[2]:
+            dbq = colsum_f32(dq)
+        if ctx.needs_input_grad[3]:
+            dwsr = unpack_conv_grad(ops.conv2d_wgrad(ds, h, k, k, k, 0), wsr.shape[0], wsr.shape[1], k)
+        if has_bsr and ctx.needs_input_grad[4]:
+            dbsr = colsum_f32(ds)
+        return dh, dwq, dbq, dwsr, dbsr, None, None, None, None, None
+
+
 class DwConvFn(Function):
     """depthwise 3x3 (+ exact GELU).  wt: [9][C] f32 pack, wt_flip: taps reversed (input gradient)."""
 
@@ -135,7 +197,7 @@ class DwConvFn(Function):
         dw = db = None
         if ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2]):
             C = x.shape[-1]
-            acc = torch.zeros((10, C), dtype=torch.float32, device=x.device)      # 9 taps + bias, one fill
+            acc = ops.grad_zeros((10, C), x.device)                              # 9 taps + bias
             dwt, dbt = acc[:9], (acc[9] if has_bias else None)
             ops.dwconv3x3_wgrad(x, dz, dwt, dbt)
             dw = dwt.t().reshape(weight.shape).contiguous()
@@ -209,8 +271,8 @@ class BNReluFn(Function):
     def backward(ctx, dy, _dsums):
         x, y, gamma, sums = ctx.saved_tensors
         eps, relu = ctx.cfg
-        dg = torch.zeros_like(gamma)
-        db = torch.zeros_like(gamma)
+        dg = ops.grad_zeros(gamma.shape, gamma.device)
+        db = ops.grad_zeros(gamma.shape, gamma.device)
         dx = ops.bn_train_bwd(x, dy.contiguous(), y if relu else None, sums, gamma, dg, db, eps)
         return dx, dg, db, None, None
 
@@ -625,23 +687,23 @@ class BcastAddFn(Function):
 
 class DropPathAddFn(Function):
     """residual + scale[b] * branch: stochastic depth on the residual branch (timm DropPath as used by pvt_v2.py:
-    per-sample Bernoulli(keep) / keep).  scale: f32 [B, C] (the per-sample value repeated over channels)."""
+    per-sample Bernoulli(keep) / keep).  scale: f32 [B, C] (the per-sample value repeated over channels), scale_m1 = scale - 1."""
 
     @staticmethod
-    def forward(ctx, residual, branch, scale, rows_per_sample):
+    def forward(ctx, residual, branch, scale, scale_m1, rows_per_sample):
         out = torch.empty_like(residual)
         ops.colscale_add(residual, branch, scale, scale.shape[1], rows_per_sample, out)
-        ctx.save_for_backward(scale)
+        ctx.save_for_backward(scale_m1)
         ctx.rps = rows_per_sample
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        (scale,) = ctx.saved_tensors
+        (scale_m1,) = ctx.saved_tensors
         dy = dy.contiguous()
         db = torch.empty_like(dy)
-        ops.colscale_add(dy, dy, scale - 1.0, scale.shape[1], ctx.rps, db)        # dy + (s - 1) dy = s dy
-        return dy, db, None, None
+        ops.colscale_add(dy, dy, scale_m1, scale_m1.shape[1], ctx.rps, db)        # dy + (s - 1) dy = s dy
+        return dy, db, None, None, None
 
 
 class MemoryReadFn(Function):

@@ -283,6 +283,23 @@ extern "C" int emip_gemm_tn_bias(const void* A, const void* B, float* C, float* 
     return launch_tn<false>(a, batch, dtype, reinterpret_cast<hipStream_t>(stream));
 }
 
+// The same contraction ADDED into C (and db) that the caller has already cleared: the training step clears one arena holding
+// every weight gradient with a single launch instead of one zero launch per weight (emip_amd/ops.py GradArena).
+extern "C" int emip_gemm_tn_into(const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda,
+                                 long ldb, long ldc, int dtype, void* stream) {
+    EMIP_REQUIRE(A && B && C && M > 0 && N > 0 && K > 0);
+    EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= N && ldb >= K && ldc >= K);
+    EMIP_REQUIRE(aligned16(A) && aligned16(B));
+    TnArgs a{};
+    a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.heads = 1;
+    a.db = db;
+    a.prezeroed = 1;
+    return launch_tn<false>(a, 1, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+
 // Two-level batch (batch = B * heads, operand of (b, h) at b * bs + h * hs) and an output that may be a column slice of a
 // wider PRE-ZEROED f32 buffer (ldc > K): results are ADDED with atomics.  dK / dV of all attention heads in one launch,
 // written straight into the [B][keys][2C] gradient of the kv projection.
@@ -301,8 +318,9 @@ extern "C" int emip_gemm_tn_heads(const void* A, const void* B, float* C, long M
 }
 
 // dW[co][ky][kx][ci] = sum_{b,oy,ox} dY[b,oy,ox,co] * X[b, oy*s-p+ky, ox*s-p+kx, ci]   (f32, packed like the forward weights)
-extern "C" int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx,
-                                 int Cout, long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream) {
+namespace {
+int conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout, long lddy, int KH,
+               int KW, int stride, int pad, int dtype, void* stream, int prezeroed) {
     EMIP_REQUIRE(dY && X && dW && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0 && KH > 0 && KW > 0 && stride > 0 &&
                  pad >= 0);
     EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
@@ -316,5 +334,17 @@ extern "C" int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B
     a.lda = lddy; a.ldb = ldx; a.ldc = a.K;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
     a.heads = 1;
+    a.prezeroed = prezeroed;
     return launch_tn<true>(a, 1, dtype, reinterpret_cast<hipStream_t>(stream));
+}
+}  // namespace
+
+extern "C" int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx,
+                                 int Cout, long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream) {
+    return conv_wgrad(dY, X, dW, B, H, Wd, Cin, ldx, Cout, lddy, KH, KW, stride, pad, dtype, stream, 0);
+}
+// ADDED into a dW the caller has cleared (see emip_gemm_tn_into)
+extern "C" int emip_conv2d_wgrad_into(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx,
+                                      int Cout, long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream) {
+    return conv_wgrad(dY, X, dW, B, H, Wd, Cin, ldx, Cout, lddy, KH, KW, stride, pad, dtype, stream, 1);
 }

@@ -59,7 +59,101 @@ __global__ __launch_bounds__(256) void clamp_adamw_kernel(const TensorRec* __res
     }
 }
 
+// ---- packed-weight refresh ------------------------------------------------------------------------------------------------
+// After an optimizer step every kernel-ready copy of a trainable weight (bf16 [N][K], its transpose for the input gradient,
+// conv packs [Cout][KH][KW][Cin_pad], flipped / transposed conv packs, depthwise [9][C]) has to be rebuilt from the f32
+// master.  Done with torch ops that is ~1 300 tiny launches per EMIP-short step (7 ms); here it is ONE launch over a table
+// of generalised permutations: dst (contiguous, up to 4 dims) <- src[base + i0 s0 + i1 s1 + i2 s2 + i3 s3] (strides may be
+// negative: kernel flips), zero where i3 >= valid3 (channel padding), cast to bf16 or kept f32.
+struct RepackRec {
+    const float* src;
+    void* dst;
+    long n;               // dst elements = d0 d1 d2 d3
+    long s0, s1, s2, s3;  // source strides in elements
+    long base;
+    int d1, d2, d3, valid3;
+    int dst_bf16, pad_;
+};
+
+constexpr int RCHUNK = 2048;  // dst elements per workgroup: 256 threads x 8
+
+__global__ __launch_bounds__(256) void repack_kernel(const RepackRec* __restrict__ recs, const int2* __restrict__ blockmap) {
+    const int2 bm = blockmap[blockIdx.x];
+    const RepackRec r = recs[bm.x];
+    const long i = (long)bm.y * RCHUNK + threadIdx.x * 8;
+    if (i >= r.n) return;
+    float v[8];
+    long q = i / r.d3;
+    int i3 = (int)(i - q * r.d3);
+    long q2 = q / r.d2;
+    int i2 = (int)(q - q2 * r.d2);
+    long i0 = q2 / r.d1;
+    int i1 = (int)(q2 - i0 * r.d1);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool in = i + j < r.n;
+        v[j] = (in && i3 < r.valid3) ? r.src[r.base + i0 * r.s0 + i1 * r.s1 + i2 * r.s2 + i3 * r.s3] : 0.f;
+        if (++i3 == r.d3) {
+            i3 = 0;
+            if (++i2 == r.d2) {
+                i2 = 0;
+                if (++i1 == r.d1) { i1 = 0; ++i0; }
+            }
+        }
+    }
+    if (r.dst_bf16) {
+        bf16_t* d = reinterpret_cast<bf16_t*>(r.dst) + i;
+        if (i + 7 < r.n && (reinterpret_cast<uintptr_t>(d) & 15) == 0) {
+            bf16x8 o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (bf16_t)v[j];
+            *reinterpret_cast<bf16x8*>(d) = o;
+        } else {
+            for (int j = 0; j < 8 && i + j < r.n; ++j) d[j] = (bf16_t)v[j];
+        }
+    } else {
+        float* d = reinterpret_cast<float*>(r.dst) + i;
+        for (int j = 0; j < 8 && i + j < r.n; ++j) d[j] = v[j];
+    }
+}
+
+// Train-mode BatchNorm bookkeeping (nn.BatchNorm2d.forward in training: running statistics with the unbiased variance,
+// num_batches_tracked += 1) from the f64 column sums the normalisation itself used: replaces 14 torch launches per layer.
+__global__ __launch_bounds__(256) void bn_running_kernel(const double* __restrict__ sums, float* __restrict__ rmean,
+                                                         float* __restrict__ rvar, long long* __restrict__ tracked, long n,
+                                                         float momentum, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && tracked) *tracked += 1;
+    if (c >= C) return;
+    const double mean = sums[2 * c] / (double)n;
+    double var = sums[2 * c + 1] / (double)n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double unb = var * (double)n / (double)(n > 1 ? n - 1 : 1);
+    rmean[c] = rmean[c] * (1.f - momentum) + (float)mean * momentum;
+    rvar[c] = rvar[c] * (1.f - momentum) + (float)unb * momentum;
+}
+
 }  // namespace
+
+// recs: device array of RepackRec (see above; 88 bytes each), blockmap: device int2 [nblocks] = (record, chunk) with chunks
+// of emip_repack_chunk() dst elements.
+extern "C" int emip_repack(const void* recs, const void* blockmap, int nblocks, void* stream) {
+    EMIP_REQUIRE(recs && blockmap && nblocks > 0);
+    static_assert(sizeof(RepackRec) == 88, "host-side table layout");
+    hipLaunchKernelGGL(repack_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const RepackRec*)recs,
+                       (const int2*)blockmap);
+    return emip_launch_status();
+}
+extern "C" int emip_repack_chunk(void) { return RCHUNK; }
+
+// sums: f64 [C][2] (sum, sum of squares over n values per channel, as emip_chan_stats leaves them for one group)
+extern "C" int emip_bn_running_update(const double* sums, float* running_mean, float* running_var, long long* tracked,
+                                      long n, float momentum, int C, void* stream) {
+    EMIP_REQUIRE(sums && running_mean && running_var && n > 0 && C > 0 && momentum >= 0.f && momentum <= 1.f);
+    hipLaunchKernelGGL(bn_running_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, running_mean,
+                       running_var, tracked, n, momentum, C);
+    return emip_launch_status();
+}
 
 // recs: device array of {p, g, m, v (f32 device pointers), n} records (5 x 8 bytes each); blockmap: device int2
 // [nblocks] = (record index, chunk index) with chunks of 2048 elements.  step >= 1 is the AdamW step count.

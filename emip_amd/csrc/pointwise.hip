@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
                                                             const float* __restrict__ gamma,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             long M, int C, float eps, int lpr_log2, int nparts,
-                                                            long part_stride) {
+                                                            long part_stride, const T* __restrict__ DR, long lddr) {
     extern __shared__ float red[];   // [2][C]
     const int LPR = 1 << lpr_log2;
     const int lane = threadIdx.x & 63;
@@ -246,6 +246,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     o4[j] = rstd * (dy[i][j] * gamma[vi * 4 + j] - mg - x[i][j] * mgx);
+                if (DR) {                     // + the gradient arriving over the skip path of the residual block
+                    float r4[4];
+                    Vec4<T>::load(DR + row * lddr + vi * 4, r4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o4[j] += r4[j];
+                }
                 Vec4<T>::store(DX + row * lddx + vi * 4, o4);
             }
         }
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_wide_kernel(const T* __res
                                                                   const float* __restrict__ gamma,
                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                   long M, int C, float eps, int lpr_log2, int nparts,
-                                                                  long part_stride) {
+                                                                  long part_stride, const T* __restrict__ DR, long lddr) {
     extern __shared__ float red[];   // [2][C]
     const int LPR = 1 << lpr_log2;                       // lanes per row, two 8-channel vectors per lane
     const int lane = threadIdx.x & 63;
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_wide_kernel(const T* __res
     }
     const float invC = 1.f / (float)C;
     for (long row0 = wave_global * rpw * U; row0 < M; row0 += stride) {
-        Raw8<T> rx[U][2], rdy[U][2];
+        Raw8<T> rx[U][2], rdy[U][2], rdr[U][2];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const long row = row0 + u * rpw + rsub;
@@ -369,6 +375,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_wide_kernel(const T* __res
             for (int i = 0; i < 2; ++i) {
                 rx[u][i].load(X + rowc * ldx + vcl[i]);
                 rdy[u][i].load(DY + rowc * lddy + vcl[i]);
+                if (DR) rdr[u][i].load(DR + rowc * lddr + vcl[i]);        // workgroup-uniform
             }
         }
 #pragma unroll
@@ -410,6 +417,12 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_wide_kernel(const T* __res
                     ag[i][j] += dy[i][j] * xh;
                     ab[i][j] += dy[i][j];
                     o8[j] = rstd * (dy[i][j] * gam[i][j] - mg - xh * mgx);
+                }
+                if (DR) {                     // + the gradient arriving over the skip path of the residual block
+                    float r8[8];
+                    rdr[u][i].unpack(r8, 1.f);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o8[j] += r8[j];
                 }
                 if (row < M && act[i]) store8<T>(DX + row * lddx + vcl[i], o8);
             }
@@ -1038,12 +1051,22 @@ extern "C" int emip_debug_set_lnb(int wide) {
 extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx,
                                   const float* gamma, float* dgamma, float* dbeta, int nparts, long part_stride, long M,
                                   int C, float eps, int dtype, void* stream) {
+    return emip_layernorm_bwd_res(X, ldx, DY, lddy, DX, lddx, nullptr, 0, gamma, dgamma, dbeta, nparts, part_stride, M, C,
+                                  eps, dtype, stream);
+}
+
+// The same with DX = LayerNorm backward + DR: in a pre-norm residual block x feeds the LayerNorm AND the skip connection, so
+// the gradient of the skip path (DR, same dtype as DX, may alias DX) is added here instead of by a separate add launch.
+extern "C" int emip_layernorm_bwd_res(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx, const void* DR,
+                                      long lddr, const float* gamma, float* dgamma, float* dbeta, int nparts,
+                                      long part_stride, long M, int C, float eps, int dtype, void* stream) {
     REQ_DT(dtype);
     EMIP_REQUIRE(X && DY && DX && gamma && dgamma && dbeta && M > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
     EMIP_REQUIRE(nparts >= 1 && (nparts == 1 || part_stride >= C));
     EMIP_REQUIRE((ldx & 3) == 0 && (lddy & 3) == 0 && (lddx & 3) == 0 && ldx >= C && lddy >= C && lddx >= C);
+    if (DR) EMIP_REQUIRE((lddr & 3) == 0 && lddr >= C);
     if (g_lnb_wide && (C & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && (lddx & 7) == 0 && aligned16(X) && aligned16(DY) &&
-        aligned16(DX)) {
+        aligned16(DX) && (!DR || ((lddr & 7) == 0 && aligned16(DR)))) {
         const int U = 1;
         const int nv8 = C >> 3;
         int lg = 0;
@@ -1056,11 +1079,13 @@ extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long 
         if (dtype == EMIP_F32) {
             hipLaunchKernelGGL((layernorm_bwd_wide_kernel<float, 1>), dim3((unsigned)blocks), dim3(threads),
                                2 * C * sizeof(float), (hipStream_t)stream, (const float*)X, ldx, (const float*)DY, lddy,
-                               (float*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg, nparts, part_stride);
+                               (float*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg, nparts, part_stride, (const float*)DR,
+                               lddr);
         } else {
             hipLaunchKernelGGL((layernorm_bwd_wide_kernel<bf16_t, 1>), dim3((unsigned)blocks), dim3(threads),
                                2 * C * sizeof(float), (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)DY, lddy,
-                               (bf16_t*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg, nparts, part_stride);
+                               (bf16_t*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg, nparts, part_stride,
+                               (const bf16_t*)DR, lddr);
         }
         return emip_launch_status();
     }
@@ -1075,7 +1100,7 @@ extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long 
     DISPATCH_T(dtype, hipLaunchKernelGGL(layernorm_bwd_kernel<T>, dim3((unsigned)blocks), dim3(256),
                                          2 * C * sizeof(float), (hipStream_t)stream, (const T*)X, ldx, (const T*)DY,
                                          lddy, (T*)DX, lddx, gamma, dgamma, dbeta, M, C, eps, lg, nparts,
-                                         part_stride));
+                                         part_stride, (const T*)DR, lddr));
     return emip_launch_status();
 }
 

@@ -13,8 +13,9 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from ..autograd import DropPathAddFn, ConvFn, DwConvFn, LayerNormFn, LinearFn, SraAttentionFn
-from ..nn_base import EmipModule, f32, pack_conv, pack_dw, pack_linear, to_cl, to_planar
+from ..autograd import (DropPathAddFn, ConvFn, DwConvFn, LayerNormFn, LayerNormSkipFn, LinearFn, QSrFn,
+                        SraAttentionFn)
+from ..nn_base import EmipModule, conv_dgrad_pack, f32, lin_packs, pack_conv, pack_dw, pack_linear, to_cl, to_planar
 
 
 # LayerNorm elimination on the inference path: the three LayerNorms of a block (norm1, norm2 and the one
@@ -48,16 +49,7 @@ SR_CONV8 = os.environ.get("EMIP_SR_CONV8", "1") != "0"
 SRA_KERNEL = os.environ.get("EMIP_SRA_KERNEL", "1") != "0"
 
 
-def _lin_packs(w, dt):
-    """forward pack [N,K] and input-gradient pack [K,N] of a Linear weight"""
-    return pack_linear(w, dt), w.detach().t().to(dt).contiguous()
-
-
-def _conv_dgrad_pack(w, dt, k, s, p):
-    """weights for the input gradient of a conv: W^T for non-overlapping patch convs, else flipped + transposed"""
-    if k == s and p == 0:
-        return pack_conv(w, dt).t().contiguous()                       # [k*k*Cin, Cout]
-    return pack_conv(w.detach().flip(2, 3).permute(1, 0, 2, 3), dt)    # [Cin, k*k*Cout]
+_lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
 
 
 class DWConv(EmipModule):
@@ -84,7 +76,7 @@ class Mlp(EmipModule):
         dw = self.dwconv.dwconv
         (w1, w1t), (w2, w2t), wd, wdf = self.packed(
             "mlp_t", (self.fc1.weight, self.fc2.weight, dw.weight),
-            lambda a, b, c: (_lin_packs(a, dt), _lin_packs(b, dt), pack_dw(c), pack_dw(c.detach().flip(2, 3))))
+            lambda a, b, c: (_lin_packs(a, dt), _lin_packs(b, dt), pack_dw(c), pack_dw(c, flip=True)))
         t = LinearFn.apply(h, self.fc1.weight, self.fc1.bias, None, w1, w1t)
         t = DwConvFn.apply(t, dw.weight, dw.bias, wd, wdf, True)
         return LinearFn.apply(t, self.fc2.weight, self.fc2.bias, residual, w2, w2t)
@@ -123,13 +115,13 @@ class Attention(EmipModule):
         (wq, wqt), (wkv, wkvt), (wp, wpt) = self.packed(
             "lin_t", (self.q.weight, self.kv.weight, self.proj.weight),
             lambda a, b, c: (_lin_packs(a, dt), _lin_packs(b, dt), _lin_packs(c, dt)))
-        q = LinearFn.apply(h, self.q.weight, self.q.bias, None, wq, wqt)
         if sr > 1:
             wsr, wsrd = self.packed("sr_t", (self.sr.weight,),
                                     lambda a: (pack_conv(a, dt), _conv_dgrad_pack(a, dt, sr, sr, 0)))
-            s_ = ConvFn.apply(h, self.sr.weight, self.sr.bias, wsr, wsrd, sr, sr, 0, None)
+            q, s_ = QSrFn.apply(h, self.q.weight, self.q.bias, self.sr.weight, self.sr.bias, wq, wqt, wsr, wsrd, sr)
             s_ = LayerNormFn.apply(s_, self.norm.weight, self.norm.bias, self.norm.eps)
         else:
+            q = LinearFn.apply(h, self.q.weight, self.q.bias, None, wq, wqt)
             s_ = h
         Lk = s_.shape[1] * s_.shape[2]
         kv = LinearFn.apply(s_, self.kv.weight, self.kv.bias, None, wkv, wkvt)
@@ -181,16 +173,21 @@ class Block(EmipModule):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
 
     def _drop_scale(self, x, tag):
-        """per-sample DropPath factor Bernoulli(keep) / keep as f32 [B, C]; `forced_drop` (dict tag -> [B] factors)
-        overrides the draw (parity tests force the same factors on both sides)"""
+        """per-sample DropPath factor Bernoulli(keep) / keep as f32 [B, C], and the same minus one (the backward's
+        coefficient).  `forced_drop` (dict tag -> [B] factors) overrides the draw (parity tests force the same factors on
+        both sides); otherwise the stage drew the factors of all its blocks in one go (`_drop_pre`, see draw_drop_tables)."""
         B, C = x.shape[0], x.shape[-1]
         forced = getattr(self, "forced_drop", None)
+        pre = getattr(self, "_drop_pre", None)
+        if forced is None and pre is not None and pre[tag][0].shape == (B, C) and pre[tag][0].device == x.device:
+            return pre[tag]
         if forced is not None:
             s = forced[tag].to(device=x.device, dtype=torch.float32)
         else:
             keep = 1.0 - self.drop_path_rate
             s = torch.floor(keep + torch.rand(B, device=x.device)) / keep
-        return s.view(B, 1).expand(B, C).contiguous()
+        s = s.view(B, 1).expand(B, C).contiguous()
+        return s, s - 1.0
 
     def _folded(self):
         """packed weights with the block's LayerNorm affines folded in: y = LN(x) W^T + b = xhat (W*gamma)^T + (b + W beta)"""
@@ -321,18 +318,38 @@ class Block(EmipModule):
                 with torch.enable_grad():
                     return self.run(x)
             rps = x.shape[1] * x.shape[2]
-            a = self.attn.run(LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), None)
-            x = DropPathAddFn.apply(x, a, self._drop_scale(x, "attn"), rps)
-            m = self.mlp.run(LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), None)
-            return DropPathAddFn.apply(x, m, self._drop_scale(x, "mlp"), rps)
+            h, xs = LayerNormSkipFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x = DropPathAddFn.apply(xs, self.attn.run(h, None), *self._drop_scale(x, "attn"), rps)
+            h, xs = LayerNormSkipFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return DropPathAddFn.apply(xs, self.mlp.run(h, None), *self._drop_scale(x, "mlp"), rps)
         if torch.is_grad_enabled():
-            x = self.attn.run(LayerNormFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), x)
-            return self.mlp.run(LayerNormFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x)
+            h, xs = LayerNormSkipFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x = self.attn.run(h, xs)
+            h, xs = LayerNormSkipFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return self.mlp.run(h, xs)
         g1, b1, g2, b2 = self.packed("ln", (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias),
                                      lambda a, b, c, d: (f32(a), f32(b), f32(c), f32(d)))
         x = self.attn.run(ops.layernorm(x, g1, b1, self.norm1.eps), x)
         x = self.mlp.run(ops.layernorm(x, g2, b2, self.norm2.eps), x)
         return x
+
+
+def draw_drop_tables(blocks, B, C, device):
+    """Stochastic-depth factors of one stage in a handful of launches instead of six per residual branch (612 per
+    EMIP-short step): one uniform draw [2 n, B] for the n blocks' attention and Mlp branches, floor(keep + u) / keep per
+    row (timm's DropPath as used by pvt_v2.py:167-169), expanded over the C channels the scaling kernel reads."""
+    keeps = []
+    for b in blocks:
+        keeps += [1.0 - b.drop_path_rate] * 2
+    if all(k >= 1.0 for k in keeps):
+        for b in blocks:
+            object.__setattr__(b, "_drop_pre", None)
+        return
+    k = torch.tensor(keeps, dtype=torch.float32).to(device, non_blocking=True).view(-1, 1)
+    s = (torch.floor(k + torch.rand(len(keeps), B, device=device)) / k).view(-1, B, 1).expand(-1, B, C).contiguous()
+    sm1 = s - 1.0
+    for i, b in enumerate(blocks):
+        object.__setattr__(b, "_drop_pre", {"attn": (s[2 * i], sm1[2 * i]), "mlp": (s[2 * i + 1], sm1[2 * i + 1])})
 
 
 class OverlapPatchEmbed(EmipModule):
@@ -403,6 +420,8 @@ class PyramidVisionTransformerV2(EmipModule):
                     x, stats = blk.run_fused(x, stats, scratch[j * per:(j + 1) * per], shared)
             else:
                 x = pe.run(x)
+                if self.training:
+                    draw_drop_tables(blocks, x.shape[0], x.shape[-1], x.device)
                 for blk in blocks:
                     x = blk.run(x)
             norm = getattr(self, f"norm{i + 1}")

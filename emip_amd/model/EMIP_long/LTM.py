@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from ... import ops
 from ...autograd import ConcatFn, ConvFn, MemoryReadFn
-from ...nn_base import EmipModule, f32, fold_bn, pack_conv
+from ...nn_base import EmipModule, f32, conv_dgrad_pack, fold_bn, pack_conv
 from ..EMIP_short.create_backbone import DimensionalReduction, NeighborConnectionDecoder
 
 
@@ -40,7 +40,7 @@ class fusion(EmipModule):
             from ..EMIP_short.create_backbone import conv_bn_relu_autograd
             y = conv_bn_relu_autograd(self, c0, bn, x, 3, 1, 1)
             w3p, w3d = self.packed("c3t", (c3.weight,), lambda a: (
-                pack_conv(a, dt), pack_conv(a.detach().flip(2, 3).permute(1, 0, 2, 3), dt)))
+                pack_conv(a, dt), conv_dgrad_pack(a, dt, 3, 1, 1)))
             return ConvFn.apply(y, c3.weight, c3.bias, w3p, w3d, 3, 1, 1, None)
         if self.training:
             from ..EMIP_short.create_backbone import conv_bn_train
@@ -60,8 +60,8 @@ class KeyValue(EmipModule):
         dt = self.cdtype
         if torch.is_grad_enabled():
             pk, pkd, pv, pvd = self.packed("kvt", (self.Key.weight, self.Value.weight), lambda a, c: (
-                pack_conv(a, dt), pack_conv(a.detach().flip(2, 3).permute(1, 0, 2, 3), dt),
-                pack_conv(c, dt), pack_conv(c.detach().flip(2, 3).permute(1, 0, 2, 3), dt)))
+                pack_conv(a, dt), conv_dgrad_pack(a, dt, 3, 1, 1),
+                pack_conv(c, dt), conv_dgrad_pack(c, dt, 3, 1, 1)))
             return (ConvFn.apply(x, self.Key.weight, self.Key.bias, pk, pkd, 3, 1, 1, None),
                     ConvFn.apply(x, self.Value.weight, self.Value.bias, pv, pvd, 3, 1, 1, None))
         wk, bk, wv, bv = self.packed("kv", (self.Key.weight, self.Key.bias, self.Value.weight, self.Value.bias),

@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from ... import ops
 from ...autograd import BilinearFn, BilinearPlanarFn, BNReluFn, ConcatFn, ConvFn, LinearFn, MulFn
-from ...nn_base import EmipModule, f32, fold_bn, pack_conv, to_cl, to_planar
+from ...nn_base import EmipModule, f32, conv_dgrad_pack, fold_bn, pack_conv, to_cl, to_planar
 
 
 class ConvBR(EmipModule):
@@ -52,32 +52,21 @@ def conv_bn_train(owner, conv, bn, x, k, s, p, out=None, relu=True):
     g, be = owner.packed("bn", (bn.weight, bn.bias), lambda a, c: (f32(a), f32(c)))
     y = ops.conv2d(x, w, k, k, s, p, bias=b)
     sums = ops.chan_stats(y, 1)
-    with torch.no_grad():
-        n = y.shape[0] * y.shape[1] * y.shape[2]
-        mean = (sums[0, :, 0] / n)
-        var = (sums[0, :, 1] / n - mean * mean).clamp_min(0)
-        m = bn.momentum
-        bn.running_mean.mul_(1 - m).add_(mean.float() * m)
-        bn.running_var.mul_(1 - m).add_((var * n / max(n - 1, 1)).float() * m)
-        bn.num_batches_tracked.add_(1)
+    _update_running_stats(bn, sums, y.shape[0] * y.shape[1] * y.shape[2])
     return ops.chan_norm_apply(y, sums, 1, bn.eps, relu_inner=relu, gamma=g, beta=be, out=out if out is not None else y)
 
 
 def _update_running_stats(bn, sums, n):
-    with torch.no_grad():
-        mean = sums[0, :, 0] / n
-        var = (sums[0, :, 1] / n - mean * mean).clamp_min(0)
-        m = bn.momentum
-        bn.running_mean.mul_(1 - m).add_(mean.float() * m)
-        bn.running_var.mul_(1 - m).add_((var * n / max(n - 1, 1)).float() * m)
-        bn.num_batches_tracked.add_(1)
+    """nn.BatchNorm2d's train-mode bookkeeping (momentum update with the unbiased variance, num_batches_tracked += 1) in one
+    launch from the f64 sums the normalisation used"""
+    ops.bn_running_update(sums, bn.running_mean, bn.running_var, bn.num_batches_tracked, n, bn.momentum)
 
 
 def conv_bn_relu_autograd(owner, conv, bn, x, k, s, p, relu=True):
     """differentiable conv + BatchNorm (batch statistics in train mode, running statistics in eval mode) + ReLU"""
     dt = owner.cdtype
     wp, wdg = owner.packed("wag", (conv.weight,), lambda cw: (
-        pack_conv(cw, dt), pack_conv(cw.detach().flip(2, 3).permute(1, 0, 2, 3), dt)))
+        pack_conv(cw, dt), conv_dgrad_pack(cw, dt, k, s, p)))
     y = ConvFn.apply(x, conv.weight, conv.bias, wp, wdg, k, s, p, None)
     if not owner.training:
         raise NotImplementedError("gradients through eval-mode BatchNorm are not built (train.py always calls .train())")

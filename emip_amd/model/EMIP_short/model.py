@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...nn_base import EmipModule, f32, fold_bn, pack_conv, to_cl
+from ...nn_base import EmipModule, f32, conv_dgrad_pack, fold_bn, pack_conv, to_cl
 from .create_backbone import DimensionalReduction, NeighborConnectionDecoder, Network, conv_bn_train
 from .motion.common import LayerNorm2d
 from .motion.gmflow.gmflow import GMFlow
@@ -73,7 +73,7 @@ class CoUpdater(EmipModule):
             from .create_backbone import conv_bn_relu_autograd
             y = conv_bn_relu_autograd(self, c0, bn, x, 3, 1, 1)
             w3p, w3d = self.packed("cc3t", (c3.weight,), lambda a: (
-                pack_conv(a, dt), pack_conv(a.detach().flip(2, 3).permute(1, 0, 2, 3), dt)))
+                pack_conv(a, dt), conv_dgrad_pack(a, dt, 3, 1, 1)))
             return ConvFn.apply(y, c3.weight, c3.bias, w3p, w3d, 3, 1, 1, None)
         if self.training:
             y = conv_bn_train(self, c0, bn, x, 3, 1, 1)

@@ -16,7 +16,7 @@ import torch.nn as nn
 
 from .... import ops
 from ....autograd import DwConvFn, GateFn, LayerNormFn, LinearFn, MdtaFn
-from ....nn_base import EmipModule, f32, pack_dw, pack_linear, to_cl, to_planar
+from ....nn_base import EmipModule, f32, lin_packs, lin_packs_kpad, pack_dw, pack_linear, to_cl, to_planar
 
 
 class WithBias_LayerNorm(nn.Module):
@@ -97,17 +97,14 @@ class TransformerBlock_MDTA(EmipModule):
         hid_pad = (hid + 7) // 8 * 8
 
         def lin(wt):
-            w2 = wt.detach().reshape(wt.shape[0], -1)
-            return pack_linear(w2, dt), w2.t().to(dt).contiguous()
+            return lin_packs(wt.detach().reshape(wt.shape[0], -1), dt)
 
         def build(q, qd, kv, kvd, po, pin, dw, pout):
-            wo = pout.detach().float().reshape(pout.shape[0], hid)
-            wo = torch.cat([wo, wo.new_zeros(wo.shape[0], hid_pad - hid)], 1)
             return dict(q=lin(q), kv=lin(kv), po=lin(po), pin=lin(pin),
-                        pout=(wo.to(dt).contiguous(), wo.t().to(dt).contiguous()),
-                        qd=(pack_dw(qd), pack_dw(qd.detach().flip(2, 3))),
-                        kvd=(pack_dw(kvd), pack_dw(kvd.detach().flip(2, 3))),
-                        dw=(pack_dw(dw), pack_dw(dw.detach().flip(2, 3))))
+                        pout=lin_packs_kpad(pout.detach().reshape(pout.shape[0], hid), dt, hid_pad),
+                        qd=(pack_dw(qd), pack_dw(qd, flip=True)),
+                        kvd=(pack_dw(kvd), pack_dw(kvd, flip=True)),
+                        dw=(pack_dw(dw), pack_dw(dw, flip=True)))
         w = self.packed("wt", (a.q.weight, a.q_dwconv.weight, a.kv.weight, a.kv_dwconv.weight, a.project_out.weight,
                                f.project_in.weight, f.dwconv.weight, f.project_out.weight), build)
         n1, n2, n3 = self.norm1.body, self.norm2.body, self.norm3.body

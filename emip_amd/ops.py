@@ -43,6 +43,52 @@ def rows(t):
     return m, t.shape[-1], ld
 
 
+class GradArena:
+    """The zero-initialised f32 reduction targets of one backward pass (weight / bias / norm gradients: what the kernels
+    accumulate into with atomics and what autograd then hands to the optimizer as .grad) carved from ONE buffer that one
+    fill clears at the start of the step, instead of one clearing launch per tensor (~830 per EMIP-short step).  The
+    buffer is sized by the demand of the previous step; whatever does not fit (first step, changed shapes) falls back
+    to torch.zeros.  Views stay valid until the next begin(): train_step drops the old gradients first."""
+
+    ALIGN = 64            # floats (256 B)
+
+    def __init__(self):
+        self.buf, self.cursor, self.limit, self.need, self.active = None, 0, 0, 0, False
+
+    def begin(self, device):
+        if self.need and (self.buf is None or self.buf.numel() < self.need or self.buf.device != torch.device(device)):
+            self.buf = torch.empty(self.need + (self.need >> 4), dtype=torch.float32, device=device)
+        self.limit = min(self.need, self.buf.numel()) if self.buf is not None else 0
+        if self.limit:
+            self.buf[:self.limit].zero_()
+        self.cursor, self.need, self.active = 0, 0, True
+
+    def end(self):
+        self.active = False
+
+    def zeros(self, shape, device):
+        n = 1
+        for d in shape:
+            n *= d
+        if not self.active:
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        pad = (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.need += pad
+        if self.cursor + pad > self.limit or self.buf.device != torch.device(device):
+            return torch.zeros(shape, dtype=torch.float32, device=device)
+        out = self.buf[self.cursor:self.cursor + n].view(shape)
+        self.cursor += pad
+        return out
+
+
+ARENA = GradArena()
+
+
+def grad_zeros(shape, device):
+    """f32 zeros for a reduction target that becomes a gradient (see GradArena)"""
+    return ARENA.zeros(tuple(shape), device)
+
+
 def _nbytes(t):
     return t.numel() * t.element_size() if t is not None else 0
 
@@ -497,6 +543,11 @@ def gemm_tn(a, b, with_colsum=False):
     M, N, lda = rows(a)
     Mb, K, ldb = rows(b)
     assert M == Mb and a.dtype == b.dtype
+    if ARENA.active:                   # training step: accumulate into slices of the step's pre-cleared gradient arena
+        c = grad_zeros((N, K), a.device)
+        db = grad_zeros((N,), a.device) if with_colsum else None
+        _lib.call("emip_gemm_tn_into", _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, dt_code(a.dtype), _stream())
+        return (c, db) if with_colsum else c
     if not with_colsum:
         c = torch.empty((N, K), dtype=torch.float32, device=a.device)
         _lib.call("emip_gemm_tn", _p(a), _p(b), _p(c), M, N, K, lda, ldb, K, 1, 0, 0, 0, dt_code(a.dtype), _stream())
@@ -524,6 +575,11 @@ def conv2d_wgrad(dy, x, kh, kw, stride, pad):
     Cout = dy.shape[-1]
     _, _, ldx = rows(x)
     _, _, lddy = rows(dy)
+    if ARENA.active:
+        dw = grad_zeros((Cout, kh * kw * Cin), x.device)
+        _lib.call("emip_conv2d_wgrad_into", _p(dy), _p(x), _p(dw), B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad,
+                  dt_code(x.dtype), _stream())
+        return dw
     dw = torch.empty((Cout, kh * kw * Cin), dtype=torch.float32, device=x.device)
     _lib.call("emip_conv2d_wgrad", _p(dy), _p(x), _p(dw), B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad,
               dt_code(x.dtype), _stream())
@@ -540,18 +596,20 @@ def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta):
     return dx
 
 
-def layernorm_bwd_fresh(x, dy, gamma, eps):
-    """dx, dgamma, dbeta (fresh f32 [C] tensors).  The kernel can spread the reduction over `nparts` partial accumulators;
-    measured on MI355X that does not pay (57 us plain vs 71 us + a fill and a column-sum launch at 30976 x 320), so P = 1."""
+def layernorm_bwd_fresh(x, dy, gamma, eps, dres=None):
+    """dx (+ dres: the gradient arriving over the skip path of a pre-norm residual block, added in the same launch), dgamma,
+    dbeta (fresh f32 [C] tensors).  The kernel can spread the reduction over `nparts` partial accumulators; measured on
+    MI355X that does not pay (57 us plain vs 71 us + a fill and a column-sum launch at 30976 x 320), so P = 1."""
     M, C, ldx = rows(x)
     _, _, lddy = rows(dy)
     dx = torch.empty(x.shape, dtype=x.dtype, device=x.device)
-    P = 1
-    acc = torch.zeros((P, 2, C), dtype=torch.float32, device=x.device)
-    _lib.call("emip_layernorm_bwd", _p(x), ldx, _p(dy), lddy, _p(dx), C, _p(gamma), _p(acc), _p(acc[0, 1]), P, 2 * C, M,
-              C, float(eps), dt_code(x.dtype), _stream())
-    if P > 1:
-        acc = colsum(acc.view(P, 2 * C)).view(1, 2, C)
+    lddr = 0
+    if dres is not None:
+        Mr, Cr, lddr = rows(dres)
+        assert (Mr, Cr) == (M, C) and dres.dtype == x.dtype
+    acc = grad_zeros((1, 2, C), x.device)
+    _lib.call("emip_layernorm_bwd_res", _p(x), ldx, _p(dy), lddy, _p(dx), C, _p(dres), lddr, _p(gamma), _p(acc),
+              _p(acc[0, 1]), 1, 2 * C, M, C, float(eps), dt_code(x.dtype), _stream())
     return dx, acc[0, 0], acc[0, 1]
 
 
@@ -647,9 +705,18 @@ def depatchify(p, B, Ho, Wo, k, C):
 def colsum(x):
     """sum over rows of a channels-last tensor -> f32 [C]"""
     M, C, ldx = rows(x)
-    out = torch.zeros(C, dtype=torch.float32, device=x.device)
+    out = grad_zeros((C,), x.device)
     _lib.call("emip_colsum", _p(x), ldx, _p(out), M, C, dt_code(x.dtype), _stream())
     return out
+
+
+def bn_running_update(sums, running_mean, running_var, tracked, n, momentum):
+    """train-mode BatchNorm2d bookkeeping from the f64 sums [1, C, 2] of chan_stats (one group of n values per channel)"""
+    C = running_mean.numel()
+    assert sums.dtype == torch.float64 and sums.numel() == 2 * C and running_mean.dtype == torch.float32
+    assert tracked is None or tracked.dtype == torch.int64
+    _lib.call("emip_bn_running_update", _p(sums), _p(running_mean), _p(running_var), _p(tracked), int(n), float(momentum), C,
+              _stream())
 
 
 def gate_fwd(z, ch, cpad):

@@ -64,6 +64,10 @@ class FusedClampAdamW(torch.optim.Optimizer):
             # The kernel wrote the parameters (and moments) through raw pointers: bump the version counters so every
             # cache keyed on them (EmipModule.packed: bf16 copies, conv / dgrad packs, folded norms) is rebuilt.
             torch.autograd.graph.increment_version(plist)
+        # ... and rewrite the packs that are plain permutations of a master weight in place, with one launch
+        # (nn_base.refresh_packs); everything else is rebuilt on first use because its version moved.
+        from . import nn_base
+        nn_base.refresh_packs()
         return loss
 
     def load_state_dict(self, state_dict):

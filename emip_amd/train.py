@@ -10,6 +10,7 @@ the backward and accumulates parameter gradients, torch.distributed carries the 
 """
 import torch
 
+from . import ops
 from .dp import GradReducer
 from .loss.loss_flow import unFlowLoss
 from .loss.loss_pred import hybrid_e_loss
@@ -39,14 +40,18 @@ _flow_loss = unFlowLoss()
 def train_step(model, optimizer, reducer, image1, image2, gts):
     """train.py:43-62.  Returns (loss, loss_pred, loss_flow) as 0-dim device tensors (no host sync here)."""
     optimizer.zero_grad(set_to_none=True)
-    with torch.enable_grad():
-        preds = model(image1, image2)
-        loss_pred = hybrid_e_loss(preds[0], gts)
-        image_pair = torch.cat((image1, image2), dim=1)
-        flow_pair = [torch.cat((preds[1][i], preds[2][i]), dim=1) for i in range(len(preds[1]))]
-        loss_flow = _flow_loss.compute_loss(flow_pair, image_pair)[0]
-        loss = loss_pred + loss_flow
-        loss.backward()
+    ops.ARENA.begin(image1.device)          # one fill clears every gradient accumulator of this step (ops.GradArena)
+    try:
+        with torch.enable_grad():
+            preds = model(image1, image2)
+            loss_pred = hybrid_e_loss(preds[0], gts)
+            image_pair = torch.cat((image1, image2), dim=1)
+            flow_pair = [torch.cat((preds[1][i], preds[2][i]), dim=1) for i in range(len(preds[1]))]
+            loss_flow = _flow_loss.compute_loss(flow_pair, image_pair)[0]
+            loss = loss_pred + loss_flow
+            loss.backward()
+    finally:
+        ops.ARENA.end()
     if reducer is not None:
         reducer.finish()
     optimizer.step()

@@ -299,12 +299,26 @@ int emip_gemm_tn_bias(const void* A, const void* B, float* C, float* db, long M,
 int emip_conv2d_wgrad(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout,
                       long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream);
 
+/* The two weight-gradient contractions ADDED (f32 atomics) into C / db / dW that the caller has already cleared: the
+ * training step (train.py:52-58 loss.backward()) clears ONE arena holding every parameter gradient with a single launch
+ * instead of one zero launch per weight.  db may be NULL. */
+int emip_gemm_tn_into(const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda, long ldb, long ldc,
+                      int dtype, void* stream);
+int emip_conv2d_wgrad_into(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout,
+                           long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream);
+
 /* LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (f32 atomics).  mean/rstd are recomputed from x.  Workgroup b
  * accumulates into dgamma/dbeta + (b % nparts) * part_stride: nparts > 1 spreads the atomics over partial buffers that
  * the caller sums (nparts = 1: plain accumulation). */
 int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx, const float* gamma,
                        float* dgamma, float* dbeta, int nparts, long part_stride, long M, int C, float eps, int dtype,
                        void* stream);
+/* The same with DX = LayerNorm backward + DR (same dtype as DX, row stride lddr; NULL = plain): in the pre-norm residual
+ * blocks of lib/pvt_v2.py:165-169 x feeds norm1 / norm2 AND the skip connection, so the skip path's gradient is added in
+ * this kernel's store instead of by a separate add launch (torch autograd's accumulation). */
+int emip_layernorm_bwd_res(const void* X, long ldx, const void* DY, long lddy, void* DX, long lddx, const void* DR, long lddr,
+                           const float* gamma, float* dgamma, float* dbeta, int nparts, long part_stride, long M, int C,
+                           float eps, int dtype, void* stream);
 
 /* Backward of the softmax attentions (lib/pvt_v2.py:113-121; gmflow/transformer.py:46-105,503-533; matching.py:8-41).
  * Row softmax of the first L columns (columns L..ld-1 are written as 0): Y = softmax(X*scale + mask), mask = -100
@@ -471,6 +485,21 @@ int emip_scatter_u8(unsigned char* img, const int* offs, const unsigned char* va
 int emip_clamp_adamw(const void* recs, const void* blockmap, int nblocks, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float clip, int step, void* stream);
 int emip_adamw_chunk(void);
+
+/* Refresh of every kernel-ready weight copy after an optimizer step (what nn_base.pack_linear / pack_conv / pack_dw and the
+ * input-gradient packs of lib/pvt_v2.py build with torch ops on first use) in ONE launch.  recs: device array of 88-byte
+ * records {const float* src; void* dst; long n; long s0, s1, s2, s3; long base; int d1, d2, d3, valid3; int dst_bf16, pad;}:
+ * contiguous dst of dims [n/(d1 d2 d3)][d1][d2][d3] <- src[base + i0 s0 + i1 s1 + i2 s2 + i3 s3], zero where i3 >= valid3;
+ * blockmap: device int2[nblocks] = (record, chunk) with chunks of emip_repack_chunk() dst elements.  The reference rebuilds
+ * nothing (its modules read the f32 parameters directly, train.py:61-62); this is bookkeeping of the bf16 mode. */
+int emip_repack(const void* recs, const void* blockmap, int nblocks, void* stream);
+int emip_repack_chunk(void);
+
+/* Train-mode nn.BatchNorm2d bookkeeping (create_backbone.py:18-29 ConvBR in train mode, model.py:59-62): running_mean /
+ * running_var momentum update with the unbiased batch variance and num_batches_tracked += 1 (tracked may be NULL), from the
+ * f64 sums [C][2] of emip_chan_stats over n values per channel. */
+int emip_bn_running_update(const double* sums, float* running_mean, float* running_var, long long* tracked, long n,
+                           float momentum, int C, void* stream);
 
 /* ---- calibration switches: libemip_hip_tuning.so ONLY (make -C emip_amd/csrc tuning, -DEMIP_TUNING) ----------------------
  * Tile / ring-depth overrides and work-skipping ablations (no stores / no MFMA / no loads) for tools/.  The product

@@ -1,0 +1,120 @@
+"""emip_repack / GradArena / emip_bn_running_update on the device: after optimizer steps every refreshable pack equals the
+permutation of its f32 master (bit for bit, after the same bf16 rounding); the arena hands out zeroed accumulators and the
+gradients of a step do not depend on whether it is used; BatchNorm bookkeeping equals nn.BatchNorm2d's."""
+import numpy as np
+import pytest
+import torch
+
+from emip_amd.filler import synthetic_gt, synthetic_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _expected(rec):
+    src, dst, d, st, base, valid3 = rec
+    flat = src.detach().reshape(-1)
+    idx = torch.meshgrid(*[torch.arange(n, device=src.device) for n in d], indexing="ij")
+    off = base + sum(idx[i] * st[i] for i in range(4))
+    ok = idx[3] < valid3
+    vals = torch.where(ok, flat[torch.where(ok, off, torch.zeros_like(off))], torch.zeros((), device=src.device))
+    return vals.reshape(-1).to(dst.dtype)
+
+
+def test_refreshed_packs_equal_the_permuted_masters_after_optimizer_steps(model_args, short_sd):
+    from emip_amd import nn_base
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    from emip_amd.train import build_optimizer, freeze_like_reference, train_step
+    try:
+        nn_base.set_default_dtype(torch.bfloat16)
+        net = CoUpdater(model_args)
+        net.load_state_dict(short_sd)
+        net = freeze_like_reference(net.to("cuda:0").train())
+        opt = build_optimizer(net, lr=1e-3)
+        im1, im2 = synthetic_pair(1, seed=3)
+        gt = synthetic_gt(1, seed=3)
+        im1, im2, gt = im1.cuda(), im2.cuda(), gt.cuda()
+        for _ in range(2):
+            train_step(net, opt, None, im1, im2, gt)
+        torch.cuda.synchronize()
+        live = [e for (c, k, e) in nn_base._REFRESHABLE if c.get(k) is e and any(t.requires_grad for t in e.tensors)]
+        nrec = sum(len(e.recs) for e in live)
+        assert len(live) > 150 and nrec > 700, (len(live), nrec)      # PVT blocks, patch embeds, decoder, injectors
+        bad = 0
+        for e in live:
+            # the entry is current: its signature carries the parameters' present versions
+            assert e.sig[:-2] == tuple((t.data_ptr(), t._version, t.device) for t in e.tensors)
+            for r in e.recs:
+                want = _expected(r)
+                got = r[1].reshape(-1)[:want.numel()]
+                bad += int(not torch.equal(want, got))
+                assert not r[1].reshape(-1)[want.numel():].any()
+        assert bad == 0, bad
+        # a third step builds nothing: every training-mode pack lookup hits
+        before = len(nn_base._REFRESHABLE)
+        train_step(net, opt, None, im1, im2, gt)
+        assert len(nn_base._REFRESHABLE) == before
+    finally:
+        nn_base.set_default_dtype(torch.float32)
+
+
+def test_gradients_do_not_depend_on_the_arena(model_args, short_sd):
+    """f32 mode, DropPath off: the same step with the gradient arena (second step: sized by the first) and without it"""
+    from emip_amd import nn_base, ops
+    from emip_amd.loss.loss_pred import hybrid_e_loss
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    from emip_amd.train import freeze_like_reference
+    nn_base.set_default_dtype(torch.float32)
+    net = CoUpdater(model_args)
+    net.load_state_dict(short_sd)
+    net = freeze_like_reference(net.to("cuda:0").train())
+    for m in net.modules():
+        if hasattr(m, "drop_path_rate"):
+            m.drop_path_rate = 0.0
+    im1, im2 = synthetic_pair(1, seed=5)
+    gt = synthetic_gt(1, seed=5).cuda()
+    im1, im2 = im1.cuda(), im2.cuda()
+
+    def grads(use):
+        net.zero_grad(set_to_none=True)
+        if use:
+            ops.ARENA.begin(im1.device)
+        try:
+            with torch.enable_grad():
+                hybrid_e_loss(net(im1, im2)[0], gt).backward()
+        finally:
+            ops.ARENA.end()
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    ref, ref2 = grads(False), grads(False)
+    grads(True)                      # measures the demand (everything falls back to torch.zeros)
+    got = grads(True)
+    assert ops.ARENA.limit > 20_000_000 and ops.ARENA.cursor > 20_000_000      # the 82 M-parameter PVT alone
+    assert set(ref) == set(got)
+
+    def rel(a, b):
+        return {n: ((a[n] - b[n]).abs().max() / (b[n].abs().max() + 1e-30)).item() for n in b}
+    noise, dev = rel(ref2, ref), rel(got, ref)
+    # some gradients are rounding noise around an exact zero (the key bias of a softmax attention: a shift of every score of
+    # a row), so the yardstick is the run-to-run deviation of the SAME path: f32 atomics order only
+    worst = sorted(((dev[n], noise[n], n) for n in ref), reverse=True)[:3]
+    print("  largest arena-vs-plain deviations (relative, run-to-run noise of the plain path, name):", worst)
+    assert all(dev[n] <= 5.0 * noise[n] + 2e-3 for n in ref), worst
+    # views handed out are zero on arrival even right after a step that filled them
+    ops.ARENA.begin(im1.device)
+    z = ops.grad_zeros((1000, 777), im1.device)
+    ops.ARENA.end()
+    assert z.untyped_storage().data_ptr() == ops.ARENA.buf.untyped_storage().data_ptr() and not z.any()
+
+
+def test_bn_running_update_matches_torch():
+    from emip_amd import ops
+    torch.manual_seed(0)
+    x = torch.randn(4, 9, 7, 24, device="cuda") * 3 + 1.5
+    bn = torch.nn.BatchNorm2d(24, momentum=0.1).cuda().train()
+    bn.running_mean.normal_()
+    bn.running_var.uniform_(0.5, 2.0)
+    rm, rv, nt = bn.running_mean.clone(), bn.running_var.clone(), bn.num_batches_tracked.clone()
+    bn(x.permute(0, 3, 1, 2))
+    sums = ops.chan_stats(x, 1)
+    ops.bn_running_update(sums, rm, rv, nt, 4 * 9 * 7, 0.1)
+    assert torch.allclose(rm, bn.running_mean, atol=1e-6) and torch.allclose(rv, bn.running_var, rtol=1e-5)
+    assert int(nt) == int(bn.num_batches_tracked) == 1
