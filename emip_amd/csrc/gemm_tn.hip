@@ -221,8 +221,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const TnArgs p) {
 }  // namespace
 
 int g_tn_target = 0;   // 0 = heuristic; tools/gemm_tn_bench.py overrides it
+int g_tn_ring = 1;     // eligible bf16 launches go to the LDS-DMA ring body (gemm_tn8.hip)
 #ifdef EMIP_TUNING
-extern "C" int emip_debug_set_tn(int target) { g_tn_target = target > 0 ? target : 0; return EMIP_OK; }
+extern "C" int emip_debug_set_tn(int target) {        // target < 0: the register-staged body for every launch
+    g_tn_ring = target >= 0;
+    g_tn_target = target > 0 ? target : 0;
+    return EMIP_OK;
+}
 #endif
 
 namespace {
@@ -275,6 +280,8 @@ extern "C" int emip_gemm_tn_bias(const void* A, const void* B, float* C, float* 
     const int vec = dtype == EMIP_F32 ? 4 : 8;
     EMIP_REQUIRE(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= N && ldb >= K && ldc >= K);
     EMIP_REQUIRE(bsA % vec == 0 && bsB % vec == 0 && aligned16(A) && aligned16(B));
+    if (g_tn_ring && dtype == EMIP_BF16 && batch == 1 && emip_gemm_tn8_eligible(M, N, K, lda, ldb))
+        return emip_gemm_tn8(A, B, C, db, M, N, K, lda, ldb, ldc, 0, stream);
     TnArgs a{};
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.bsA = bsA; a.bsB = bsB; a.bsC = bsC;
@@ -292,6 +299,8 @@ extern "C" int emip_gemm_tn_into(const void* A, const void* B, float* C, float* 
     const int vec = dtype == EMIP_F32 ? 4 : 8;
     EMIP_REQUIRE(N % vec == 0 && K % vec == 0 && lda % vec == 0 && ldb % vec == 0 && lda >= N && ldb >= K && ldc >= K);
     EMIP_REQUIRE(aligned16(A) && aligned16(B));
+    if (g_tn_ring && dtype == EMIP_BF16 && emip_gemm_tn8_eligible(M, N, K, lda, ldb))
+        return emip_gemm_tn8(A, B, C, db, M, N, K, lda, ldb, ldc, 1, stream);
     TnArgs a{};
     a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = ldb; a.ldc = ldc;
     a.heads = 1;

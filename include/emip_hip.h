@@ -307,6 +307,13 @@ int emip_gemm_tn_into(const void* A, const void* B, float* C, float* db, long M,
 int emip_conv2d_wgrad_into(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout,
                            long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream);
 
+/* The large-launch body of the weight gradients (bf16, dense operands, M >= 2048): the same contraction as emip_gemm_tn on a
+ * ring of LDS-DMA stages (gemm_tn8.hip).  emip_gemm_tn / _bias / _into hand it every eligible launch; this is the explicit
+ * entry.  prezeroed != 0: C / db are clear already and are added into.  db may be NULL. */
+int emip_gemm_tn8(const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda, long ldb, long ldc,
+                  int prezeroed, void* stream);
+int emip_gemm_tn8_eligible(long M, int N, int K, long lda, long ldb);
+
 /* LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (f32 atomics).  mean/rstd are recomputed from x.  Workgroup b
  * accumulates into dgamma/dbeta + (b % nparts) * part_stride: nparts > 1 spreads the atomics over partial buffers that
  * the caller sums (nparts = 1: plain accumulation). */
@@ -509,6 +516,7 @@ int emip_debug_set(int key, int value);
 int emip_debug_set_tn(int target_workgroups);   /* 0 = heuristic split count of emip_gemm_tn */
 int emip_debug_set_lnb(int wide);               /* 0 = the narrow LayerNorm-backward kernel */
 int emip_debug_set_dww(int chunks);             /* row chunks per image of the depthwise weight gradient (0 = auto) */
+int emip_debug_set_tn8(int ring_depth, int target_workgroups);   /* emip_gemm_tn8: 2..4 stages; 0 = heuristic split count */
 int emip_tuning_gemm8_dbg(int flags);           /* gemm8 ablations: 1 no epilogue stores, 2 no MFMA, 4 no operand loads */
 #endif
 
