@@ -104,7 +104,9 @@ def test_two_rank_training_step_keeps_replicas_identical():
           "lead over the end of backward (ms):", [round(x, 2) for x in lead])
     assert dead >= 100 and log == list(range(len(nbytes))) and in_bwd == list(range(len(in_bwd))) and len(in_bwd) >= len(nbytes) - 1
     assert any(n == "conv_corr.0.weight" for n in first) or nbytes[0] >= 60 * 2 ** 20 or nbytes[1] >= 60 * 2 ** 20
-    assert all(x > 0 for x in lead) and lead[0] > lead[-1]
+    # (a bucket that closes with the very last gradient of the step is launched inside backward too, but cannot lead its end)
+    inner = lead if len(in_bwd) < len(nbytes) else lead[:-1]
+    assert all(x > 0 for x in inner) and lead[0] > lead[-1] and lead[-1] > -50.0
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
