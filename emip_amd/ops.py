@@ -303,8 +303,9 @@ def layernorm(x, gamma, beta, eps, out=None, res=None, out_stats=None):
     return out
 
 
-KV_SPLIT = True      # emip_attention_splitkv for >= KV_SPLIT_MIN_KEYS keys on grids of < 256 workgroups
-KV_SPLIT_MIN_KEYS = 1024
+KV_SPLIT = True      # emip_attention_splitkv for >= KV_SPLIT_MIN_KEYS keys on grids of < KV_SPLIT_TARGET workgroups
+KV_SPLIT_MIN_KEYS = int(__import__('os').environ.get('EMIP_KV_MIN', '1024'))
+KV_SPLIT_TARGET = int(__import__('os').environ.get('EMIP_KV_TARGET', '512'))      # workgroups to aim at (two per CU)
 
 
 def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo,
@@ -312,16 +313,18 @@ def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_
               scores=None, s_bs=0, lds=0, ksplit=None):
     _dev(q)
     o_f32 = 1 if (out.dtype == torch.float32 and q.dtype != torch.float32) else 0
-    # long key sets on small grids: split the keys over workgroups (about 256 workgroups in total, >= 4 key tiles each)
+    # long key sets on small grids: split the keys over workgroups (>= 4 key tiles each).  The kernel runs one wave per SIMD
+    # and workgroup, so it wants TWO workgroups per CU to hide its load -> MFMA -> softmax chain: 16 pairs of global matching
+    # (256 workgroups unsplit) take 118 us unsplit and 80 us split in two (tools/corr_bench.py), hence the 512 target
     bkv = 64 if q.dtype == torch.bfloat16 else 32
     ntile = (Lk + bkv - 1) // bkv
     wgs = ((Lq + 127) // 128) * heads * batch * nwin
     if ksplit is not None:
         pass
-    elif not (KV_SPLIT and Lk >= KV_SPLIT_MIN_KEYS and wgs < 256):
+    elif not (KV_SPLIT and Lk >= KV_SPLIT_MIN_KEYS and wgs < KV_SPLIT_TARGET):
         ksplit = 1
     else:
-        ksplit = max(1, min(ntile // 4, (256 + wgs - 1) // wgs, 32))
+        ksplit = max(1, min(ntile // 4, (KV_SPLIT_TARGET + wgs - 1) // wgs, 32))
     if ksplit > 1:
         ws = torch.empty(batch * nwin * heads * ksplit * Lq * (DV + 2), dtype=torch.float32, device=q.device)
         _lib.call("emip_attention_splitkv", _p(q), _p(k), _p(v), _p(out), _p(scores), batch, heads, nwin, Lq, Lk, D, DV,
