@@ -50,6 +50,8 @@ SRA_KERNEL = os.environ.get("EMIP_SRA_KERNEL", "1") != "0"
 
 
 _lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
+# fc1 + depthwise + GELU as one kernel where an image fits one workgroup (stages 3 and 4); EMIP_MLP_FC1DW=0: two launches
+MLP_FC1DW = os.environ.get("EMIP_MLP_FC1DW", "1") != "0"
 
 
 class DWConv(EmipModule):
@@ -304,8 +306,13 @@ class Block(EmipModule):
                           k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
                           k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
         ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)                          # x += proj(attn)
-        t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, colsum=w["sw1"] if LN_EPILOGUE else None)
-        t = ops.dwconv3x3(t, w["wd"], w["bd"], act=ops.ACT_GELU)
+        hid = w["w1"].shape[0]
+        if MLP_FC1DW and dt == torch.bfloat16 and LN_EPILOGUE and ops.mlp_fc1dw_eligible(B, H, W, C, hid):
+            # fc1 + depthwise 3x3 + GELU in one launch, one whole image per workgroup: the fc1 output never leaves the CU
+            t = ops.mlp_fc1dw(x, w["w1"], w["b1"], w["sw1"], st1, self.norm2.eps, w["wd"], w["bd"])
+        else:
+            t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, colsum=w["sw1"] if LN_EPILOGUE else None)
+            t = ops.dwconv3x3(t, w["wd"], w["bd"], act=ops.ACT_GELU)
         ops.gemm(t, w["w2"], bias=w["b2"], res=x, out=x, out_stats=st2)                           # x += mlp(...)
         return x, st2
 

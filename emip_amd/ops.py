@@ -368,6 +368,23 @@ def dwconv3x3(x, wt, bias=None, act=ACT_NONE, out=None):
     return out
 
 
+def mlp_fc1dw_eligible(B, H, W, K, N):
+    return bool(_lib.load().emip_mlp_fc1dw_eligible(B, H, W, K, N))
+
+
+def mlp_fc1dw(x, w1, b1, colsum, ln_stats, eps, wd, bd):
+    """GELU(dwconv3x3(LN(x) w1^T + b1) + bd) for images of <= 512 tokens (bf16): x [B,H,W,K] raw tokens with their row
+    statistics ln_stats [B*H*W, 2], w1 [N,K] with the LayerNorm scale folded in, colsum [N] its row sums -> [B,H,W,N]"""
+    B, H, W, K = x.shape
+    M, _, ldx = rows(x)
+    N = w1.shape[0]
+    assert x.dtype == w1.dtype == torch.bfloat16 and w1.is_contiguous() and w1.shape[1] == K and wd.shape == (9, N)
+    out = torch.empty((B, H, W, N), dtype=x.dtype, device=x.device)
+    _lib.call("emip_mlp_fc1dw", _p(x), ldx, _p(w1), _p(b1), _p(colsum), _p(ln_stats), float(eps), _p(wd), _p(bd), _p(out), N,
+              B, H, W, K, N, _stream())
+    return out
+
+
 def dwconv3x3_dual(x, wt, bias, act):
     """-> (act(dwconv(x)), dwconv(x)): activation output and pre-activation values from one pass"""
     B, H, W, C = x.shape

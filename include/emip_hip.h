@@ -307,6 +307,15 @@ int emip_gemm_tn_into(const void* A, const void* B, float* C, float* db, long M,
 int emip_conv2d_wgrad_into(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout,
                            long lddy, int KH, int KW, int stride, int pad, int dtype, void* stream);
 
+/* PVTv2 Mlp head in ONE launch, bf16 inference (lib/pvt_v2.py:45-54: fc1 -> DWConv -> GELU, norm2 of :165-169 folded into
+ * W1 / b1 and applied on the output side from ln_stats [rows][2] = (sum, sum of squares) of the token rows, colsum [N] = row
+ * sums of the packed W1): G[rows][ldg] = GELU(dwconv3x3(LN(X) W1^T + b1) + bd) for B images of H x Wd <= 512 tokens; the
+ * hidden tensor between fc1 and the depthwise conv never reaches HBM.  K % 32 == 0, N % 64 == 0; Wdw f32 [9][N]. */
+int emip_mlp_fc1dw(const void* X, long ldx, const void* W1, const float* b1, const float* colsum, const float* ln_stats,
+                   float eps, const float* Wdw, const float* bd, void* G, long ldg, int B, int H, int Wd, int K, int N,
+                   void* stream);
+int emip_mlp_fc1dw_eligible(int B, int H, int Wd, int K, int N);
+
 /* The large-launch body of the weight gradients (bf16, dense operands, M >= 2048): the same contraction as emip_gemm_tn on a
  * ring of LDS-DMA stages (gemm_tn8.hip).  emip_gemm_tn / _bias / _into hand it every eligible launch; this is the explicit
  * entry.  prezeroed != 0: C / db are clear already and are added into.  db may be NULL. */
