@@ -50,6 +50,12 @@ def _launch_info(lib, name, a):
         batch, heads, Lq, Lk = a[3], a[4], a[5], a[6]
         z = batch * heads
         return 4.0 * z * Lq * Lk * 64, "sra_kernel", 2.0 * z * (2 * Lq * 64 + 2 * Lk * 64)
+    if name == "emip_mlp_fc1dw":          # (X, ldx, W1, b1, colsum, ln_stats, eps, Wdw, bd, G, ldg, B, H, W, K, N, stream)
+        Bm, H, W, K, N = a[11], a[12], a[13], a[14], a[15]
+        M = Bm * H * W
+        # fc1 as a GEMM + 9 taps per hidden element; tokens in, weights once, activated hidden tensor out (the fc1 output
+        # itself never leaves the CU, so it is not algorithmic traffic of this kernel)
+        return 2.0 * M * N * K + 18.0 * M * N, "mlp_fc1dw_kernel", 2.0 * (M * K + N * K + M * N) + 8.0 * M + 44.0 * N
     if name in ("emip_attention", "emip_attention_splitkv"):      # splitkv: the same arguments + (ksplit, workspace)
         batch, heads, nwin, Lq, Lk, D, DV = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
         dv = 2 if DV == 32 else DV                          # DV=32 carries a 2-channel value (flow / pixel grid)
@@ -130,7 +136,7 @@ def kernel_breakdown(net, im1, im2, splits=1):
     return agg
 
 
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r02_bench_kernel_stats.csv")
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r02b_bench_kernel_stats.csv")
 
 
 def rocprof_avg(key):

@@ -31,7 +31,7 @@ def graph_us(fn, n=10, reps=5):
     return e0.elapsed_time(e1) * 1e3 / (n * reps)
 
 
-for (B, H, K, N) in ((32, 22, 320, 1280), (16, 22, 320, 1280), (32, 11, 512, 2048), (3, 22, 320, 1280)):
+for (B, H, K, N) in ((32, 22, 320, 1280), (16, 22, 320, 1280), (3, 22, 320, 1280)):
     x = (torch.randn(B, H, H, K, device="cuda") * 1.3 + 0.2).to(torch.bfloat16)
     xf = x.float().view(-1, K)
     stats = torch.stack((xf.sum(1), (xf * xf).sum(1)), 1).contiguous()
