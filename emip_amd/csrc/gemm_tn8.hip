@@ -55,20 +55,20 @@ struct Tn8Args {
     int tiles_k, tiles, splits;
     unsigned a_bytes, b_bytes;
     int atomic;           // 1: add into C with atomics (several m splits, or a pre-cleared C that others add into as well)
+    int item0;            // grouped launch: first work item of this problem
 };
 
 constexpr unsigned TN8_OOB = 0x80000000u;
 __device__ __forceinline__ int tn8_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
+// one work item = one (output tile, m split) of problem p; bid = its index inside the problem
 template <int NST>
-__global__ __launch_bounds__(256) void gemm_tn8_kernel(const Tn8Args p) {
+__device__ __forceinline__ void tn8_body(const Tn8Args& p, const int bid, char* smem) {
     constexpr int RB = 256;                    // bytes per stage row (128 bf16)
     constexpr int TILE = 64 * RB;              // one operand of one stage
     constexpr int STAGE = 2 * TILE;
     constexpr int LPT = 8;                     // LDS-DMA instructions per wave and stage (4 per operand)
     static_assert(NST >= 2 && NST <= 4 && NST * STAGE <= 160 * 1024, "ring depth");
-    extern __shared__ __attribute__((aligned(1024))) char smem[];
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = wave & 1, wk = wave >> 1;
@@ -77,12 +77,12 @@ __global__ __launch_bounds__(256) void gemm_tn8_kernel(const Tn8Args p) {
     // that XCD's L2 -- every panel leaves HBM / Infinity Cache once instead of once per tile that multiplies it.
     int tile, split;
     if ((p.splits & 7) == 0) {
-        const int j = blockIdx.x >> 3;
+        const int j = bid >> 3;
         tile = j % p.tiles;
-        split = (blockIdx.x & 7) + 8 * (j / p.tiles);
+        split = (bid & 7) + 8 * (j / p.tiles);
     } else {
-        tile = blockIdx.x % p.tiles;
-        split = blockIdx.x / p.tiles;
+        tile = bid % p.tiles;
+        split = bid / p.tiles;
     }
     const int tile_n = tile / p.tiles_k, tile_k = tile - tile_n * p.tiles_k;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
@@ -223,6 +223,33 @@ __global__ __launch_bounds__(256) void gemm_tn8_kernel(const Tn8Args p) {
         }
 }
 
+template <int NST>
+__global__ __launch_bounds__(256) void gemm_tn8_kernel(const Tn8Args p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    tn8_body<NST>(p, (int)blockIdx.x, smem);
+}
+
+// Grouped launch: the weight gradients of MANY layers in one persistent grid.  The training step defers its Linear weight
+// gradients (their operands dY and X stay alive: the chip has 288 GB) and flushes them together, so that the launch holds
+// thousands of work items: no launch is short of tiles any more, m splits exist only to bound the item length (fewer
+// atomics), and every CU walks a similar mix of items.  Item i runs on workgroup i % grid, i.e. on XCD i % 8; a problem's
+// items start at a multiple of 8, so the id decode of tn8_body keeps the tiles of one m range on one XCD.
+template <int NST>
+__global__ __launch_bounds__(256) void gemm_tn8_group_kernel(const Tn8Args* __restrict__ probs, int nprob, int total) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    for (int item = blockIdx.x; item < total; item += gridDim.x) {
+        int lo = 0, hi = nprob - 1;
+        while (lo < hi) {                      // last problem whose first item is <= item (workgroup-uniform)
+            const int mid = (lo + hi + 1) >> 1;
+            if (probs[mid].item0 <= item) lo = mid;
+            else hi = mid - 1;
+        }
+        const Tn8Args p = probs[lo];
+        tn8_body<NST>(p, item - p.item0, smem);
+        __syncthreads();                       // the ring is free again (all of this item's stages were waited for)
+    }
+}
+
 int g_tn8_nst = 0;        // ring depth; 0 = heuristic (tools/gemm_tn_bench.py sweeps it through the tuning library)
 int g_tn8_target = 0;     // workgroups to aim at; 0 = heuristic
 int g_tn8_xcd = 1;        // m splits in multiples of 8, one m range per XCD
@@ -302,5 +329,42 @@ extern "C" int emip_gemm_tn8(const void* A, const void* B, float* C, float* db, 
         if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
         hipLaunchKernelGGL(gemm_tn8_kernel<3>, grid, dim3(256), lds, s, a);
     }
+    return emip_launch_status();
+}
+
+// ---- grouped launch ------------------------------------------------------------------------------------------------------
+extern "C" int emip_gemm_tn8_group_recsize(void) { return (int)sizeof(Tn8Args); }
+
+// Fill one record of a grouped launch (HOST memory, emip_gemm_tn8_group_recsize() bytes) for C += A^T B into a PRE-CLEARED C
+// (and db): returns the number of work items of the problem (a multiple of 8), or a negative error code.  item0 = the sum
+// of the items of the records before it.
+extern "C" int emip_gemm_tn8_group_plan(void* rec, const void* A, const void* B, float* C, float* db, long M, int N, int K,
+                                        long lda, long ldb, long ldc, int item0) {
+    if (!(rec && A && B && C && M > 0 && N > 0 && K > 0 && ldc >= K && (item0 & 7) == 0)) return EMIP_E_INVALID;
+    if (!(emip_gemm_tn8_eligible(M, N, K, lda, ldb) && aligned16(A) && aligned16(B))) return EMIP_E_INVALID;
+    Tn8Args a{};
+    a.A = (const bf16_t*)A; a.B = (const bf16_t*)B; a.C = C; a.db = db; a.M = M; a.N = N; a.K = K;
+    a.lda = lda; a.ldb = ldb; a.ldc = ldc;
+    a.a_bytes = (unsigned)(((M - 1) * lda + N) * 2);
+    a.b_bytes = (unsigned)(((M - 1) * ldb + K) * 2);
+    a.tiles_k = (K + 127) / 128;
+    a.tiles = ((N + 127) / 128) * a.tiles_k;
+    const long stages = (M + 63) / 64;
+    long splits = (stages / 60 + 4) / 8 * 8;               // items of ~60 stages, a multiple of 8 m ranges (one per XCD)
+    if (splits < 8) splits = 8;
+    a.m_per_split = ((M + splits - 1) / splits + 63) / 64 * 64;
+    a.splits = (int)splits;
+    a.atomic = 1;
+    a.item0 = item0;
+    *reinterpret_cast<Tn8Args*>(rec) = a;
+    return a.tiles * a.splits;
+}
+
+// probs: DEVICE array of nprob records (as emip_gemm_tn8_group_plan wrote them), total = the sum of their item counts
+extern "C" int emip_gemm_tn8_group(const void* probs, int nprob, int total, void* stream) {
+    EMIP_REQUIRE(probs && nprob > 0 && total > 0 && (reinterpret_cast<uintptr_t>(probs) & 7u) == 0);
+    const int grid = total < 512 ? total : 512;            // 2-deep ring (64 KB): two workgroups per CU
+    hipLaunchKernelGGL(gemm_tn8_group_kernel<2>, dim3(grid), dim3(256), (size_t)2 * 2 * 64 * 256, (hipStream_t)stream,
+                       (const Tn8Args*)probs, nprob, total);
     return emip_launch_status();
 }

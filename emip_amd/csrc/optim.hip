@@ -12,7 +12,7 @@ constexpr int CHUNK = 2048;  // elements per workgroup (256 threads x 2 x float4
 
 struct TensorRec {
     float* p;
-    const float* g;
+    const float* g;     // used when the launch passes no separate gradient-pointer array
     float* m;
     float* v;
     long n;
@@ -21,9 +21,10 @@ struct TensorRec {
 __global__ __launch_bounds__(256) void clamp_adamw_kernel(const TensorRec* __restrict__ recs,
                                                           const int2* __restrict__ blockmap, float lr, float beta1,
                                                           float beta2, float eps, float wd, float clip, float bc1,
-                                                          float bc2_sqrt) {
+                                                          float bc2_sqrt, const float* const* __restrict__ gptrs) {
     const int2 bm = blockmap[blockIdx.x];
-    const TensorRec r = recs[bm.x];
+    TensorRec r = recs[bm.x];
+    if (gptrs) r.g = gptrs[bm.x];
     const long base = (long)bm.y * CHUNK;
     const float step = lr / bc1;
 #pragma unroll
@@ -159,6 +160,13 @@ extern "C" int emip_bn_running_update(const double* sums, float* running_mean, f
 // [nblocks] = (record index, chunk index) with chunks of 2048 elements.  step >= 1 is the AdamW step count.
 extern "C" int emip_clamp_adamw(const void* recs, const void* blockmap, int nblocks, float lr, float beta1,
                                 float beta2, float eps, float weight_decay, float clip, int step, void* stream) {
+    return emip_clamp_adamw_g(recs, blockmap, nullptr, nblocks, lr, beta1, beta2, eps, weight_decay, clip, step, stream);
+}
+
+// The same with the gradient pointers in their own device array (const float* [records]): parameters and moments stay where
+// they are from step to step, gradients are fresh tensors every step, so only this small array changes between launches.
+extern "C" int emip_clamp_adamw_g(const void* recs, const void* blockmap, const void* gptrs, int nblocks, float lr, float beta1,
+                                  float beta2, float eps, float weight_decay, float clip, int step, void* stream) {
     EMIP_REQUIRE(recs && blockmap && nblocks > 0 && step >= 1 && lr >= 0.f && beta1 >= 0.f && beta1 < 1.f &&
                  beta2 >= 0.f && beta2 < 1.f);
     // bias corrections in double on the host, as torch.optim.AdamW evaluates them (float powf is ~6e-5 relative off at small t)
@@ -166,7 +174,7 @@ extern "C" int emip_clamp_adamw(const void* recs, const void* blockmap, int nblo
     const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
     hipLaunchKernelGGL(clamp_adamw_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream,
                        (const TensorRec*)recs, (const int2*)blockmap, lr, beta1, beta2, eps, weight_decay, clip, bc1,
-                       bc2s);
+                       bc2s, (const float* const*)gptrs);
     return emip_launch_status();
 }
 

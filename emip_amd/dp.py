@@ -115,6 +115,9 @@ class GradReducer:
     def _launch(self, bi):
         b = self.buckets[bi]
         ref = b.params[0]
+        if ref.is_cuda:
+            from . import ops
+            ops.flush_wgrads()              # weight gradients the step has deferred must be on the compute stream first
         side = self._stream(ref.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(ref.device))

@@ -341,6 +341,9 @@ class Block(EmipModule):
         return x
 
 
+_KEEP_CACHE = {}
+
+
 def draw_drop_tables(blocks, B, C, device):
     """Stochastic-depth factors of one stage in a handful of launches instead of six per residual branch (612 per
     EMIP-short step): one uniform draw [2 n, B] for the n blocks' attention and Mlp branches, floor(keep + u) / keep per
@@ -352,7 +355,10 @@ def draw_drop_tables(blocks, B, C, device):
         for b in blocks:
             object.__setattr__(b, "_drop_pre", None)
         return
-    k = torch.tensor(keeps, dtype=torch.float32).to(device, non_blocking=True).view(-1, 1)
+    ck = (str(device), tuple(keeps))
+    k = _KEEP_CACHE.get(ck)
+    if k is None:                                   # the keep probabilities of a stage never change: upload them once
+        k = _KEEP_CACHE[ck] = torch.tensor(keeps, dtype=torch.float32).to(device).view(-1, 1)
     s = (torch.floor(k + torch.rand(len(keeps), B, device=device)) / k).view(-1, B, 1).expand(-1, B, C).contiguous()
     sm1 = s - 1.0
     for i, b in enumerate(blocks):

@@ -19,7 +19,9 @@ def dt_code(dtype):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """raw handle of the current HIP stream of the current device (the C accessors: torch.cuda.current_stream() costs 8 us
+    of Python per call, and there is one call per launch)"""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 def _p(t):
@@ -65,6 +67,7 @@ class GradArena:
 
     def end(self):
         self.active = False
+        WGRADS.flush()                       # nothing deferred outlives the step
 
     def zeros(self, shape, device):
         n = 1
@@ -82,6 +85,63 @@ class GradArena:
 
 
 ARENA = GradArena()
+
+
+class WgradQueue:
+    """Deferred Linear weight gradients of a training step.  While the gradient arena is active, gemm_tn does not launch:
+    it takes the (pre-cleared) output slices from the arena, remembers the operands and returns.  flush() hands everything
+    queued to ONE grouped launch (emip_gemm_tn8_group: thousands of work items, no launch short of tiles, m splits only to
+    bound the item length).  The operands (dY, X) stay alive until then -- a few GB at batch 32 on a 288-GB device.
+    Flush points: the end of backward (train_step), before a gradient bucket leaves for its all-reduce (GradReducer), and
+    whenever MAX problems are waiting."""
+
+    MAX = 160
+
+    def __init__(self):
+        self.items, self.enabled = [], __import__('os').environ.get('EMIP_WGRAD_DEFER', '1') != '0'
+        self.stage = None
+
+    def add(self, a, b, c, db, M, N, K, lda, ldb):
+        self.items.append((a, b, c, db, M, N, K, lda, ldb))
+        if len(self.items) >= self.MAX:
+            self.flush()
+
+    def flush(self):
+        if not self.items:
+            return
+        items, self.items = self.items, []
+        lib = _lib.load()
+        rs = lib.emip_gemm_tn8_group_recsize()
+        dev = items[0][0].device
+        # The records go to the device through one of two pinned staging buffers and a non-blocking copy: a pageable .to()
+        # is stream-ordered AND blocking, i.e. it stalls the host until the GPU has caught up (5 ms per flush, measured).
+        if self.stage is None or self.stage[0].numel() < rs * self.MAX:
+            self.stage = [torch.empty(rs * self.MAX, dtype=torch.uint8).pin_memory() for _ in range(2)]
+            self.events, self.turn = [None, None], 0
+        k = self.turn = self.turn ^ 1
+        if self.events[k] is not None:
+            self.events[k].synchronize()           # the copy that read this buffer two flushes ago (long done)
+        host = self.stage[k]
+        total = 0
+        for i, (a, b, c, db, M, N, K, lda, ldb) in enumerate(items):
+            n = lib.emip_gemm_tn8_group_plan(host.data_ptr() + i * rs, _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, total)
+            if n <= 0:
+                raise _lib.EmipLibraryError("emip_gemm_tn8_group_plan failed for %r" % ((M, N, K, lda, ldb),))
+            total += n
+        with torch.cuda.device(dev):
+            table = torch.empty(rs * len(items), dtype=torch.uint8, device=dev)
+            table.copy_(host[:rs * len(items)], non_blocking=True)
+            self.events[k] = torch.cuda.Event()
+            self.events[k].record()
+            _lib.call("emip_gemm_tn8_group", _p(table), len(items), total, _stream())
+
+
+WGRADS = WgradQueue()
+
+
+def flush_wgrads():
+    """launch the weight gradients the training step has deferred so far (no-op when none are waiting)"""
+    WGRADS.flush()
 
 
 def grad_zeros(shape, device):
@@ -566,7 +626,11 @@ def gemm_tn(a, b, with_colsum=False):
     if ARENA.active:                   # training step: accumulate into slices of the step's pre-cleared gradient arena
         c = grad_zeros((N, K), a.device)
         db = grad_zeros((N,), a.device) if with_colsum else None
-        _lib.call("emip_gemm_tn_into", _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, dt_code(a.dtype), _stream())
+        if (WGRADS.enabled and a.dtype == torch.bfloat16 and _lib.load().emip_gemm_tn8_eligible(M, N, K, lda, ldb)
+                and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+            WGRADS.add(a, b, c, db, M, N, K, lda, ldb)         # launched with the other layers' by flush_wgrads()
+        else:
+            _lib.call("emip_gemm_tn_into", _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, dt_code(a.dtype), _stream())
         return (c, db) if with_colsum else c
     if not with_colsum:
         c = torch.empty((N, K), dtype=torch.float32, device=a.device)

@@ -50,6 +50,7 @@ def train_step(model, optimizer, reducer, image1, image2, gts):
             loss_flow = _flow_loss.compute_loss(flow_pair, image_pair)[0]
             loss = loss_pred + loss_flow
             loss.backward()
+            ops.flush_wgrads()                  # the Linear weight gradients backward deferred, as one grouped launch
     finally:
         ops.ARENA.end()
     if reducer is not None:

@@ -323,6 +323,16 @@ int emip_gemm_tn8(const void* A, const void* B, float* C, float* db, long M, int
                   int prezeroed, void* stream);
 int emip_gemm_tn8_eligible(long M, int N, int K, long lda, long ldb);
 
+/* Grouped form: the weight gradients of many layers in ONE persistent launch (the training step defers them and flushes them
+ * together, emip_amd/ops.py WgradQueue).  emip_gemm_tn8_group_plan fills one record (HOST memory,
+ * emip_gemm_tn8_group_recsize() bytes) for C += A^T B (+ db += column sums of A) into PRE-CLEARED outputs and returns the
+ * problem's work-item count (a multiple of 8; negative = error); item0 = the items of the records before it.
+ * emip_gemm_tn8_group takes the records as a DEVICE array. */
+int emip_gemm_tn8_group_recsize(void);
+int emip_gemm_tn8_group_plan(void* rec, const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda,
+                             long ldb, long ldc, int item0);
+int emip_gemm_tn8_group(const void* probs, int nprob, int total, void* stream);
+
 /* LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (f32 atomics).  mean/rstd are recomputed from x.  Workgroup b
  * accumulates into dgamma/dbeta + (b % nparts) * part_stride: nparts > 1 spreads the atomics over partial buffers that
  * the caller sums (nparts = 1: plain accumulation). */
@@ -501,6 +511,10 @@ int emip_scatter_u8(unsigned char* img, const int* offs, const unsigned char* va
 int emip_clamp_adamw(const void* recs, const void* blockmap, int nblocks, float lr, float beta1, float beta2,
                      float eps, float weight_decay, float clip, int step, void* stream);
 int emip_adamw_chunk(void);
+/* the same with the gradient pointers taken from their own device array gptrs (const float* [records]; the g field of the
+ * records is then ignored): the only part of the tables that changes from step to step */
+int emip_clamp_adamw_g(const void* recs, const void* blockmap, const void* gptrs, int nblocks, float lr, float beta1,
+                       float beta2, float eps, float weight_decay, float clip, int step, void* stream);
 
 /* Refresh of every kernel-ready weight copy after an optimizer step (what nn_base.pack_linear / pack_conv / pack_dw and the
  * input-gradient packs of lib/pvt_v2.py build with torch ops on first use) in ONE launch.  recs: device array of 88-byte
