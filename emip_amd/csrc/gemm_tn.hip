@@ -338,6 +338,8 @@ int conv_wgrad(const void* dY, const void* X, float* dW, int B, int H, int Wd, i
     EMIP_REQUIRE(aligned16(dY) && aligned16(X));
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
     EMIP_REQUIRE(Ho > 0 && Wo > 0 && (long)B * Ho * Wo < 2147483647L && (long)KH * KW * Cin < 2147483647L);
+    if (g_tn_ring && dtype == EMIP_BF16 && emip_conv_wgrad8_eligible(B, H, Wd, Cin, ldx, Cout, lddy, KH, KW, stride, pad))
+        return emip_conv_wgrad8(dY, X, dW, B, H, Wd, Cin, ldx, Cout, lddy, KH, KW, stride, pad, prezeroed, stream);
     TnArgs a{};
     a.A = dY; a.B = X; a.C = dW; a.M = (long)B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin;
     a.lda = lddy; a.ldb = ldx; a.ldc = a.K;

@@ -56,13 +56,15 @@ struct Tn8Args {
     unsigned a_bytes, b_bytes;
     int atomic;           // 1: add into C with atomics (several m splits, or a pre-cleared C that others add into as well)
     int item0;            // grouped launch: first work item of this problem
+    // CONV: B[m][k] is the im2col view of an NHWC tensor X (m = output pixel, k = (ky, kx, ci), ci fastest), ldb = pixel stride
+    int H, Wd, Cin, Ho, Wo, KW, stride, pad;
 };
 
 constexpr unsigned TN8_OOB = 0x80000000u;
 __device__ __forceinline__ int tn8_f(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 
 // one work item = one (output tile, m split) of problem p; bid = its index inside the problem
-template <int NST>
+template <int NST, bool CONV = false>
 __device__ __forceinline__ void tn8_body(const Tn8Args& p, const int bid, char* smem) {
     constexpr int RB = 256;                    // bytes per stage row (128 bf16)
     constexpr int TILE = 64 * RB;              // one operand of one stage
@@ -80,9 +82,10 @@ __device__ __forceinline__ void tn8_body(const Tn8Args& p, const int bid, char* 
         const int j = bid >> 3;
         tile = j % p.tiles;
         split = (bid & 7) + 8 * (j / p.tiles);
-    } else {
-        tile = bid % p.tiles;
-        split = bid / p.tiles;
+    } else {                                   // many tiles, few splits: every XCD takes a contiguous run of tiles (they
+        const int rb = xcd_remap(bid, p.tiles * p.splits);      // share their dY panel and walk neighbouring X panels)
+        tile = rb % p.tiles;
+        split = rb / p.tiles;
     }
     const int tile_n = tile / p.tiles_k, tile_k = tile - tile_n * p.tiles_k;
     const int n0 = tile_n * 128, k0 = tile_k * 128;
@@ -106,6 +109,26 @@ __device__ __forceinline__ void tn8_body(const Tn8Args& p, const int bid, char* 
         aoff[j] = n0 + 8 * c < p.N ? (unsigned)((long)r * p.lda * 2) + (unsigned)(n0 + 8 * c) * 2u : TN8_OOB;
         boff[j] = k0 + 8 * c < p.K ? (unsigned)((long)r * p.ldb * 2) + (unsigned)(k0 + 8 * c) * 2u : TN8_OOB;
     }
+    // CONV: this lane's chunk of instruction j is the same (tap, channel) in every stage; the pixel it belongs to moves on
+    // by 64 output pixels per stage and is tracked incrementally (b, oy, ox): no division inside the ring
+    int t_ky[4], t_kx[4], t_ci[4], px_b[4], px_y[4], px_x[4];
+    if (CONV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = (lane & 15) ^ (tn8_f(rloc[j]) << 1);
+            const int k = k0 + 8 * c;
+            const int tap = k / p.Cin;
+            t_ci[j] = k < p.K ? k - tap * p.Cin : -1;
+            t_ky[j] = tap / p.KW;
+            t_kx[j] = tap - t_ky[j] * p.KW;
+            const long m = m_lo + rloc[j];
+            const int hw = p.Ho * p.Wo;
+            px_b[j] = (int)(m / hw);
+            const int rem = (int)(m - (long)px_b[j] * hw);
+            px_y[j] = rem / p.Wo;
+            px_x[j] = rem - px_y[j] * p.Wo;
+        }
+    }
     auto issue = [&](int s, int buf) {
         const long m0 = m_lo + 64L * s;
         const unsigned sa = (unsigned)(m0 * p.lda * 2), sb = (unsigned)(m0 * p.ldb * 2);
@@ -114,7 +137,19 @@ __device__ __forceinline__ void tn8_body(const Tn8Args& p, const int bid, char* 
         for (int j = 0; j < 4; ++j) {
             const bool ok = m0 + rloc[j] < m_hi;
             tn8_dma16(base + j * 4096, ok ? aoff[j] : TN8_OOB, rsA, sa);
-            tn8_dma16(base + TILE + j * 4096, ok ? boff[j] : TN8_OOB, rsB, sb);
+            if (CONV) {
+                const int iy = px_y[j] * p.stride - p.pad + t_ky[j], ix = px_x[j] * p.stride - p.pad + t_kx[j];
+                const bool in = ok && t_ci[j] >= 0 && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                const unsigned off = (unsigned)((((long)px_b[j] * p.H + iy) * p.Wd + ix) * p.ldb + t_ci[j]) * 2u;
+                tn8_dma16(base + TILE + j * 4096, in ? off : TN8_OOB, rsB, 0u);
+                px_x[j] += 64;                                  // stages are issued in order: the next one is 64 pixels on
+                while (px_x[j] >= p.Wo) {
+                    px_x[j] -= p.Wo;
+                    if (++px_y[j] == p.Ho) { px_y[j] = 0; ++px_b[j]; }
+                }
+            } else {
+                tn8_dma16(base + TILE + j * 4096, ok ? boff[j] : TN8_OOB, rsB, sb);
+            }
         }
     };
 
@@ -223,10 +258,10 @@ __device__ __forceinline__ void tn8_body(const Tn8Args& p, const int bid, char* 
         }
 }
 
-template <int NST>
+template <int NST, bool CONV = false>
 __global__ __launch_bounds__(256) void gemm_tn8_kernel(const Tn8Args p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    tn8_body<NST>(p, (int)blockIdx.x, smem);
+    tn8_body<NST, CONV>(p, (int)blockIdx.x, smem);
 }
 
 // Grouped launch: the weight gradients of MANY layers in one persistent grid.  The training step defers its Linear weight
@@ -329,6 +364,50 @@ extern "C" int emip_gemm_tn8(const void* A, const void* B, float* C, float* db, 
         if (!attr3) { (void)hipFuncSetAttribute((const void*)gemm_tn8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr3 = true; }
         hipLaunchKernelGGL(gemm_tn8_kernel<3>, grid, dim3(256), lds, s, a);
     }
+    return emip_launch_status();
+}
+
+// ---- conv weight gradient on the ring: dW[co][ky][kx][ci] (+)= sum_pixels dY[pix][co] X[pix shifted by the tap][ci] ----------------
+extern "C" int emip_conv_wgrad8_eligible(int B, int H, int Wd, int Cin, long ldx, int Cout, long lddy, int KH, int KW, int stride,
+                                         int pad) {
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
+    if (Ho <= 0 || Wo <= 0) return 0;
+    const long M = (long)B * Ho * Wo, K = (long)KH * KW * Cin;
+    return M >= 2048 && (Cin & 7) == 0 && (Cout & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && ldx >= Cin && lddy >= Cout &&
+           K < (1L << 30) && M * lddy * 2 < 0x7FFF0000L && (long)B * H * Wd * ldx * 2 < 0x7FFF0000L;
+}
+
+extern "C" int emip_conv_wgrad8(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout,
+                                long lddy, int KH, int KW, int stride, int pad, int prezeroed, void* stream) {
+    EMIP_REQUIRE(dY && X && dW && emip_conv_wgrad8_eligible(B, H, Wd, Cin, ldx, Cout, lddy, KH, KW, stride, pad));
+    EMIP_REQUIRE(aligned16(dY) && aligned16(X));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
+    Tn8Args a{};
+    a.A = (const bf16_t*)dY; a.B = (const bf16_t*)X; a.C = dW; a.db = nullptr;
+    a.M = (long)B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin; a.lda = lddy; a.ldb = ldx; a.ldc = a.K;
+    a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.a_bytes = (unsigned)(((a.M - 1) * lddy + Cout) * 2);
+    a.b_bytes = (unsigned)((((long)B * H * Wd - 1) * ldx + Cin) * 2);
+    a.tiles_k = (a.K + 127) / 128;
+    a.tiles = ((a.N + 127) / 128) * a.tiles_k;
+    // few tiles: m splits in multiples of 8 (one m range per XCD); many tiles (conv_corr: 1096): two splits keep the last
+    // round of the 512 resident workgroups from running half empty
+    const long max_splits = (a.M + 8 * 64 - 1) / (8 * 64);
+    long splits = (512 + a.tiles - 1) / a.tiles;
+    if (a.tiles >= 512) splits = 2;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    if (splits >= 6 && max_splits >= 8) {
+        splits = (splits + 4) / 8 * 8;
+        if (splits > max_splits) splits = max_splits / 8 * 8;
+    }
+    a.m_per_split = ((a.M + splits - 1) / splits + 63) / 64 * 64;
+    if ((splits & 7) != 0) splits = (a.M + a.m_per_split - 1) / a.m_per_split;
+    a.splits = (int)splits;
+    a.atomic = splits > 1 || prezeroed;
+    if (!prezeroed && splits > 1 && emip_zero_async(dW, sizeof(float) * (size_t)a.N * a.K, s) != EMIP_OK) return EMIP_E_LAUNCH;
+    hipLaunchKernelGGL((gemm_tn8_kernel<2, true>), dim3((unsigned)(a.tiles * splits)), dim3(256), (size_t)2 * 2 * 64 * 256, s, a);
     return emip_launch_status();
 }
 

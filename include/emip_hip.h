@@ -323,6 +323,13 @@ int emip_gemm_tn8(const void* A, const void* B, float* C, float* db, long M, int
                   int prezeroed, void* stream);
 int emip_gemm_tn8_eligible(long M, int N, int K, long lda, long ldb);
 
+/* emip_conv2d_wgrad on the same ring (bf16; the im2col rows of X are gathered by per-lane LDS-DMA offsets, the pixel a lane
+ * fetches tracked incrementally from stage to stage); emip_conv2d_wgrad / _into hand it every eligible launch. */
+int emip_conv_wgrad8(const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx, int Cout, long lddy,
+                     int KH, int KW, int stride, int pad, int prezeroed, void* stream);
+int emip_conv_wgrad8_eligible(int B, int H, int Wd, int Cin, long ldx, int Cout, long lddy, int KH, int KW, int stride,
+                              int pad);
+
 /* Grouped form: the weight gradients of many layers in ONE persistent launch (the training step defers them and flushes them
  * together, emip_amd/ops.py WgradQueue).  emip_gemm_tn8_group_plan fills one record (HOST memory,
  * emip_gemm_tn8_group_recsize() bytes) for C += A^T B (+ db += column sums of A) into PRE-CLEARED outputs and returns the
