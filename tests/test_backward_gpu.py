@@ -108,7 +108,10 @@ def _pack_conv_w(w):  # [Cout,Cin,kh,kw] -> [Cout, kh*kw*Cin]
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s,p", [(2, 44, 44, 64, 96, 3, 1, 1), (2, 30, 26, 96, 128, 3, 2, 1),
                                                   (2, 88, 88, 64, 64, 8, 8, 0), (1, 44, 44, 1936, 72, 3, 1, 1),
-                                                  (2, 64, 48, 8, 64, 7, 4, 3)])
+                                                  (2, 64, 48, 8, 64, 7, 4, 3),
+                                                  # >= 2048 output pixels: the LDS-DMA ring body (gemm_tn8.hip, CONV)
+                                                  (4, 44, 44, 1936, 72, 3, 1, 1), (32, 22, 22, 320, 320, 2, 2, 0),
+                                                  (6, 50, 37, 40, 24, 3, 1, 1), (5, 61, 47, 16, 136, 3, 2, 1)])
 def test_conv_wgrad_and_dgrad(dtype, B, H, W, Cin, Cout, k, s, p):
     from emip_amd import ops
     x, xf = prep(rnd(B, H, W, Cin, seed=1), dtype)
@@ -219,3 +222,32 @@ def test_bilinear_backward(dtype):
     F.interpolate(pc, scale_factor=8, mode="bilinear").backward(g)
     dpc = ops.bilinear_planar_bwd(g.cuda(), 44, 44, False)
     assert rel(dpc.permute(0, 3, 1, 2), pc.grad) < 1e-5
+
+
+def test_deferred_weight_gradients_grouped_launch():
+    """ops.WgradQueue: inside the gradient arena gemm_tn defers; one grouped launch (emip_gemm_tn8_group) then produces every
+    weight gradient and bias gradient -- shapes with tails in all three dimensions, a strided dY, problems of very different
+    length in one group -- exactly what separate launches give"""
+    from emip_amd import ops
+    shapes = [(15488, 320, 1280, True), (7744, 640, 320, False), (5003, 328, 200, True), (123904, 128, 128, True),
+              (2304, 72, 1936, False), (30976, 1280, 320, True)]
+    ops_ = []
+    for i, (M, N, K, bias) in enumerate(shapes):
+        dy, dyf = prep(rnd(M, N + (8 if i == 2 else 0), seed=10 + i), torch.bfloat16)
+        x, xf = prep(rnd(M, K, seed=20 + i), torch.bfloat16)
+        ops_.append((dy[:, :N], dyf[:, :N], x, xf, bias))
+    dev = ops_[0][0].device
+    for rep in range(2):                  # the first pass sizes the arena (everything falls back to torch.zeros)
+        ops.ARENA.begin(dev)
+        outs = []
+        try:
+            for dy, _, x, _, bias in ops_:
+                outs.append(ops.gemm_tn(dy, x, with_colsum=True) if bias else (ops.gemm_tn(dy, x), None))
+            assert len(ops.WGRADS.items) == len(shapes)            # nothing has been launched yet
+            ops.flush_wgrads()
+        finally:
+            ops.ARENA.end()
+        for (dy, dyf, x, xf, bias), (c, db) in zip(ops_, outs):
+            assert rel(c, dyf.t() @ xf) < 2e-3
+            if bias:
+                assert rel(db, dyf.sum(0)) < 2e-3

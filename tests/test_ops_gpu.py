@@ -499,3 +499,33 @@ def test_conv_pair_with_fused_split_k(dt, tol, B, H, C, k, ksplit):
         assert (s_out.float() - s_ref.float()).abs().max().item() < tol * scale
         assert ((st - st_ref).abs() / (st_ref.abs() + 1.0)).max().item() < (2e-2 if dt == torch.bfloat16 else 1e-3)
         assert acc.abs().max().item() == 0 and ticket.abs().max().item() == 0
+
+
+@pytest.mark.parametrize("B,H,W,K,N", [(8, 22, 22, 320, 1280), (3, 22, 22, 320, 1280), (5, 20, 24, 64, 128), (2, 17, 23, 96, 192)])
+def test_mlp_fc1dw_fused_head(B, H, W, K, N):
+    """emip_mlp_fc1dw (lib/pvt_v2.py:45-54 with norm2 folded, 165-169): fc1 + depthwise 3x3 + GELU in one launch == the two
+    launches it replaces (bit for bit where both run the same K order, else to one bf16 step) == torch on the rounded operands.
+    B = 8: the XCD-aware id decode; odd widths and a non-square image: the window logic at the borders."""
+    from emip_amd import ops
+    assert ops.mlp_fc1dw_eligible(B, H, W, K, N)
+    g = torch.Generator().manual_seed(B * 1000 + H)
+    x = (torch.randn(B, H, W, K, generator=g) * 1.3 + 0.2).to(torch.bfloat16).cuda()
+    w1 = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    b1 = (torch.randn(N, generator=g) * 0.1).cuda()
+    wd = (torch.randn(9, N, generator=g) * 0.3).cuda()
+    bd = (torch.randn(N, generator=g) * 0.1).cuda()
+    xf = x.float().view(-1, K)
+    stats = torch.stack((xf.sum(1), (xf * xf).sum(1)), 1).contiguous()
+    cs = w1.float().sum(1).contiguous()
+    fused = ops.mlp_fc1dw(x, w1, b1, cs, stats, 1e-6, wd, bd)
+    two = ops.dwconv3x3(ops.gemm(x, w1, bias=b1, ln_stats=stats, ln_eps=1e-6, colsum=cs), wd, bd, act=ops.ACT_GELU)
+    if B * H * W >= 2048:      # both paths then accumulate over K in the same MFMA order (the 8-wave LDS-DMA loops): no rounding
+        assert torch.equal(fused, two)        # differs.  Fewer rows: the two-launch fc1 runs on the 4-wave 32 x 32 body.
+    assert (fused.float() - two.float()).abs().max().item() <= 2.0 ** -7 * max(1.0, two.float().abs().max().item())
+    mu = xf.mean(1, keepdim=True)
+    xn = (xf - mu) * torch.rsqrt(xf.var(1, unbiased=False, keepdim=True) + 1e-6)
+    h = (xn @ w1.float().t() + b1).to(torch.bfloat16).float().view(B, H, W, N).permute(0, 3, 1, 2)
+    ref = F.gelu(F.conv2d(h, wd.t().reshape(N, 1, 3, 3), bd, padding=1, groups=N)).permute(0, 2, 3, 1)
+    err = (fused.float() - ref).abs().max().item()
+    assert err < 0.03 * max(1.0, ref.abs().max().item()), err
+    assert not ops.mlp_fc1dw_eligible(B, 11, 11, K, N)         # 121 tokens would pad to 512 MFMA rows: two launches stay
