@@ -28,6 +28,13 @@ FUSED_LN = True
 # atomics, the 1.2 MB accumulator to clear and the extra launch cost more than the shorter K walk saves end to end
 # (948 -> 886 pairs/s), so it stays off.
 SPLITK_SR = False
+# ... per stage: split K for the spatial-reduction convs with a reduction ratio >= this (0 = never).  The 8 x 8 conv of stage 1
+# is 31 workgroups walking 64 K tiles (73 us for 2 GFLOP): the one launch of the forward where the shorter walk might pay
+SPLITK_SR_MIN = int(os.environ.get("EMIP_SPLITK_SR_MIN", "0"))
+
+
+def _splitk_sr(sr):
+    return sr > 1 and (SPLITK_SR or (SPLITK_SR_MIN > 0 and sr >= SPLITK_SR_MIN))
 # q projection + spatial-reduction conv of a block hosted by one launch (emip_conv2d_pair)
 PAIR_Q_SR = True
 # ... with the sr conv's long K walk split over workgroups INSIDE that launch: partial tiles meet in an f32 accumulator, the
@@ -229,12 +236,12 @@ class Block(EmipModule):
         """f32 words of statistics scratch one block needs: [sr-conv rows | x1 rows | x2 rows] x 2 (+ split-K accumulator)"""
         M = B * H * W
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
-        return (Ms * C if (sr > 1 and SPLITK_SR) else 0) + 2 * (Ms + 2 * M)
+        return (Ms * C if _splitk_sr(sr) else 0) + 2 * (Ms + 2 * M)
 
     @staticmethod
     def shared_scratch_floats(B, H, W, C, sr):
         """f32 words the blocks of a stage share for the fused split-K of the sr conv: accumulator + one ticket per tile"""
-        if not (sr > 1 and PAIR_Q_SR and PAIR_KSPLIT and not SPLITK_SR):
+        if not (sr > 1 and PAIR_Q_SR and PAIR_KSPLIT and not _splitk_sr(sr)):
             return 0
         Ms = B * (H // sr) * (W // sr)
         return Ms * C + ((Ms + 63) // 64) * ((C + 63) // 64)
@@ -250,11 +257,11 @@ class Block(EmipModule):
         w = self._folded()
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
         # scratch of the block, one allocation: [split-K accumulator of the sr conv | its row stats | stats of x1 | of x2]
-        o = Ms * C if (sr > 1 and SPLITK_SR) else 0
+        o = Ms * C if _splitk_sr(sr) else 0
         acc_sr = buf[:o].view(Ms, C) if o else None
         st_sr, st1, st2 = buf[o:o + 2 * Ms], buf[o + 2 * Ms:o + 2 * Ms + 2 * M], buf[o + 2 * Ms + 2 * M:]
-        use_conv8 = sr > 1 and SR_CONV8 and dt == torch.bfloat16 and LN_EPILOGUE and ops.gemm8_enabled() and not SPLITK_SR
-        use_pair = sr > 1 and PAIR_Q_SR and not SPLITK_SR and not use_conv8
+        use_conv8 = sr > 1 and SR_CONV8 and dt == torch.bfloat16 and LN_EPILOGUE and ops.gemm8_enabled() and not _splitk_sr(sr)
+        use_pair = sr > 1 and PAIR_Q_SR and not _splitk_sr(sr) and not use_conv8
         if use_conv8:
             # both on the 8-wave LDS-DMA body with the LayerNorm on the output side: q over the raw tokens (column sums),
             # the spatial-reduction conv over the raw patches (per-tap sums; the statistics ride the operand ring)
@@ -285,7 +292,7 @@ class Block(EmipModule):
             # 121 output tokens per image against K = sr*sr*C: split K over workgroups (about 256 in total), f32 atomics
             tiles = ((Ms + 63) // 64) * ((C + 63) // 64)
             nk = sr * sr * C // (64 if dt == torch.bfloat16 else 32)
-            ksplit = max(1, min(nk // 2, (256 + tiles - 1) // tiles, 64)) if SPLITK_SR else 1
+            ksplit = max(1, min(nk // 2, (256 + tiles - 1) // tiles, 64)) if _splitk_sr(sr) else 1
             if ksplit > 1:
                 ops.conv2d_splitk(x, w["sr"], sr, sr, sr, 0, w["bsr"], acc_sr, ksplit, ln_stats=stats,
                                   ln_eps=self.norm1.eps)
