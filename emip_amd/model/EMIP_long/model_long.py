@@ -85,7 +85,7 @@ class Model_long(EmipModule):
         st = self.short_term
         S = frames0.shape[0]
         with torch.no_grad():                  # model_long.py:70: the short-term part never carries gradient
-            st.run(frames0, frames1)
+            st.run(frames0, frames1, tail=False)       # its mask is not used from frame 1 on: no short-term decoder
             L = st.last
             fea, cc = L["fea"], L["conv_corr"]
             h, w = fea[0].shape[1:3]

@@ -90,8 +90,11 @@ class CoUpdater(EmipModule):
             object.__setattr__(self, "_side", st)
         return st
 
-    def run(self, image1, image2):
-        """Planar images [B,3,H,W] -> (mask planar f32, flow predictions [2B,2,H,W] list, intermediates)."""
+    def run(self, image1, image2, tail=True):
+        """Planar images [B,3,H,W] -> (mask planar f32, flow predictions [2B,2,H,W] list, intermediates).
+        tail=False: stop behind the motion collector (`conv_corr`) -- EMIP-long reads the backbone features and the
+        correlation features of its short-term part and decodes on its own (model_long.py:68-117), so the short-term
+        prompt injection / reductions / decoder would be computed for nothing; returns (None, flow predictions)."""
         dt = self.cdtype
         B = image1.shape[0]
         imgs = to_cl(torch.cat((image1, image2), 0), dt, 8)            # [2B,H,W,8]
@@ -115,6 +118,9 @@ class CoUpdater(EmipModule):
         else:
             preds, corr = self.GMFlow.run(ab[:B], ab[B:])
         cc = self.run_conv_corr(corr)                                  # motion collector, part 1
+        if not tail:
+            self.last = dict(fea=fea, gm=gm, ab=ab, corr=corr, conv_corr=cc)
+            return None, preds
         fea_new = self.injector1.run(fea[0][:B], cc)
         f1 = self.dr1.run(fea_new)
         f2 = self.dr2.run(fea[1][:B])
