@@ -94,7 +94,7 @@ class CoUpdater(EmipModule):
         """Planar images [B,3,H,W] -> (mask planar f32, flow predictions [2B,2,H,W] list, intermediates).
         tail=False: stop behind the motion collector (`conv_corr`) -- EMIP-long reads the backbone features and the
         correlation features of its short-term part and decodes on its own (model_long.py:68-117), so the short-term
-        prompt injection / reductions / decoder would be computed for nothing; returns (None, flow predictions)."""
+        prompt injection / reductions / decoder and the flow predictions would be computed for nothing; returns (None, [])."""
         dt = self.cdtype
         B = image1.shape[0]
         imgs = to_cl(torch.cat((image1, image2), 0), dt, 8)            # [2B,H,W,8]
@@ -116,7 +116,7 @@ class CoUpdater(EmipModule):
         if torch.is_grad_enabled() and ab.requires_grad:
             preds, corr = self.GMFlow.run_train(ab)
         else:
-            preds, corr = self.GMFlow.run(ab[:B], ab[B:])
+            preds, corr = self.GMFlow.run(ab[:B], ab[B:], flows=tail)
         cc = self.run_conv_corr(corr)                                  # motion collector, part 1
         if not tail:
             self.last = dict(fea=fea, gm=gm, ab=ab, corr=corr, conv_corr=cc)

@@ -72,9 +72,11 @@ class GMFlow(EmipModule):
         self.last = dict(tokens=c0, flow_prop=flow)
         return preds, corr
 
-    def run(self, a, b):
+    def run(self, a, b, flows=True):
         """a, b: channels-last prompted features [B,h,w,C] of frame 1 / frame 2.
-        Returns (flow predictions: list of planar f32 [2B,2,8h,8w], corr [B, h*w(src), h*w(tgt)])."""
+        Returns (flow predictions: list of planar f32 [2B,2,8h,8w], corr [B, h*w(src), h*w(tgt)]).
+        flows=False (EMIP-long's short-term part: only the correlation volume is read): no backward-direction matching, no
+        flow propagation, no upsampling; returns ([], corr)."""
         dt = self.cdtype
         B, h, w, C = a.shape
         n = h * w
@@ -92,6 +94,9 @@ class GMFlow(EmipModule):
         common = dict(batch=B, heads=1, nwin=1, Lq=n, Lk=n, D=C, DV=32, q_bs=n * C, k_bs=n * C, v_bs=0, o_bs=n * 32,
                       ldq=C, ldk=C, ldv=32, ldo=32, scale=C ** -0.5)
         ops.attention(c0[:B], c0[B:], grid, o[:B], scores=corr, s_bs=n * n, lds=n, **common)
+        if not flows:
+            self.last = dict(tokens=c0)
+            return [], corr
         ops.attention(c0[B:], c0[:B], grid, o[B:], **common)
         flow = ops.corresp_to_flow(o, 2 * B, h, w, True)      # f32 [2B,h,w,2]
         preds = []
