@@ -70,7 +70,7 @@ struct G8Args {
     unsigned a_bytes, a2_bytes, w_bytes;            // descriptor extents (< 2^31)
     int tiles_m, tiles_n;
 #ifdef EMIP_TUNING
-    int dbg;      // ablations (tuning library only): 1 = no epilogue stores, 2 = no MFMA, 4 = no operand loads
+    int dbg;      // ablations (tuning library only): 1 = no epilogue stores, 2 = no MFMA, 4 = no operand loads, 8 = return at entry
 #endif
 };
 
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     static_assert(NST * STAGE <= 160 * 1024 && NST >= 2 && NST <= 5 && 3 * LPT < 64, "LDS / ring depth");
     static_assert(!LNT || (CONV && BM <= 256), "per-tap LayerNorm is a conv mode");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
+    if (G8_DBG(p, 8)) return;                          // tuning build: the bare launch (dispatch + kernel boundary)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
