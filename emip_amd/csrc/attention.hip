@@ -20,6 +20,9 @@
 // ds_read_b128; the bf16 V tile is swizzled for conflict-free transposed reads.
 #include "common.h"
 
+extern "C" int emip_attention_rot(const void*, const void*, const void*, void*, void*, int, int, int, int, int, int, int, long,
+                                  long, long, long, long, long, long, long, long, long, long, long, long, long, const int*,
+                                  const int*, const int*, const int*, float, int, int, float*, int, int, void*);
 extern "C" int emip_attention_splitkv(const void*, const void*, const void*, void*, void*, int, int, int, int, int, int, int, long,
                                       long, long, long, long, long, long, long, long, long, long, long, long, long, const int*,
                                       const int*, const int*, const int*, float, int, int, float*, int, void*);
@@ -47,6 +50,9 @@ struct AttnArgs {
     // combines the splits and writes O
     int ksplit;
     float* ws;
+    // keys / values of batch element b are read from element (b + kv_rot) mod nbatch (cross attention between the two
+    // halves of a batch without a copy: kv_rot = nbatch / 2)
+    int kv_rot, nbatch;
 };
 
 template <int RB>
@@ -92,8 +98,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void a
     const int split = p.ksplit > 1 ? (int)blockIdx.y - head * p.ksplit : 0;
 
     const T* __restrict__ Qp = reinterpret_cast<const T*>(p.Q) + batch * p.q_bs + head * p.q_hs;
-    const T* __restrict__ Kp = reinterpret_cast<const T*>(p.K) + batch * p.k_bs + head * p.k_hs;
-    const T* __restrict__ Vp = reinterpret_cast<const T*>(p.V) + batch * p.v_bs + head * p.v_hs;
+    long kvb = batch + p.kv_rot;
+    if (kvb >= p.nbatch) kvb -= p.nbatch;
+    const T* __restrict__ Kp = reinterpret_cast<const T*>(p.K) + kvb * p.k_bs + head * p.k_hs;
+    const T* __restrict__ Vp = reinterpret_cast<const T*>(p.V) + kvb * p.v_bs + head * p.v_hs;
     const int* qrows = p.q_rows ? p.q_rows + (long)win * p.Lq : nullptr;
     const int* krows = p.k_rows ? p.k_rows + (long)win * p.Lk : nullptr;
     const int* kgid = p.k_gid ? p.k_gid + (long)win * p.Lk : nullptr;
@@ -456,6 +464,21 @@ extern "C" int emip_attention_splitkv(const void* Q, const void* K, const void* 
                                       long v_hs, long o_hs, const int* q_rows, const int* k_rows, const int* q_gid,
                                       const int* k_gid, float scale, int o_f32, int ksplit, float* ws, int dtype,
                                       void* stream) {
+    return emip_attention_rot(Q, K, V, O, S, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_bs, o_bs, s_bs, ldq, ldk, ldv,
+                              ldo, lds, q_hs, k_hs, v_hs, o_hs, q_rows, k_rows, q_gid, k_gid, scale, o_f32, ksplit, ws, 0,
+                              dtype, stream);
+}
+
+// ... with the keys / values of batch element b taken from element (b + kv_batch_rot) mod batch: GMFlow's cross attention
+// between the two frames of a pair (transformer.py:281-301: source = the OTHER frame's tokens) reads the other half of the
+// batch in place, so the k / v projections of both frames stay ONE GEMM over the whole batch.
+extern "C" int emip_attention_rot(const void* Q, const void* K, const void* V, void* O, void* S, int batch, int heads,
+                                  int nwin, int Lq, int Lk, int D, int DV, long q_bs, long k_bs, long v_bs, long o_bs,
+                                  long s_bs, long ldq, long ldk, long ldv, long ldo, long lds, long q_hs, long k_hs,
+                                  long v_hs, long o_hs, const int* q_rows, const int* k_rows, const int* q_gid,
+                                  const int* k_gid, float scale, int o_f32, int ksplit, float* ws, int kv_batch_rot,
+                                  int dtype, void* stream) {
+    EMIP_REQUIRE(kv_batch_rot >= 0 && kv_batch_rot < batch);
     EMIP_REQUIRE(ksplit >= 1 && ksplit <= 32 && (ksplit == 1 || (ws && (reinterpret_cast<uintptr_t>(ws) & 15) == 0)));
     EMIP_REQUIRE((long)heads * ksplit < 65536);
     EMIP_REQUIRE(Q && K && V && O && batch > 0 && heads > 0 && nwin > 0 && Lq > 0 && Lk > 0);
@@ -478,6 +501,7 @@ extern "C" int emip_attention_splitkv(const void* Q, const void* K, const void* 
     a.q_rows = q_rows; a.k_rows = k_rows; a.q_gid = q_gid; a.k_gid = k_gid;
     a.scale = scale; a.o_f32 = o_f32;
     a.ksplit = ksplit; a.ws = ws;
+    a.kv_rot = kv_batch_rot; a.nbatch = batch;
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
 #define ATTN_CASE(d, dv)                                                                     \
     if (D == d && DV == dv)                                                                  \

@@ -67,8 +67,21 @@ class TransformerLayer(EmipModule):
         return LinearFn.apply(x, mod.weight, mod.bias, res, wp, wpt)
 
 
+# inference: the five input projections of a block as one GEMM, the cross attention reading the other half of the batch in place
+FUSED_IN = __import__("os").environ.get("EMIP_GMF_FUSED_IN", "1") != "0"
+
+
 class TransformerBlock(EmipModule):
     """self attention, then cross attention + FFN (transformer.py:348-401)."""
+
+    def fused_in(self):
+        """[q | k | v of the self attention | k | v of the cross attention] as ONE [5C, C] weight: all five projections read
+        the block's input tokens (the cross attention's source is the other frame AS IT IS AT BLOCK START), so they are one
+        GEMM over the whole batch instead of three launches"""
+        dt = self.cdtype
+        sa, ca = self.self_attn, self.cross_attn_ffn
+        return self.packed("in5", (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight, ca.k_proj.weight, ca.v_proj.weight),
+                           lambda *ws_: torch.cat([t.detach() for t in ws_], 0).to(dt).contiguous())
 
     def __init__(self, d_model=256, nhead=1, attention_type='swin', ffn_dim_expansion=4, with_shift=False, **kw):
         super().__init__()
@@ -78,15 +91,16 @@ class TransformerBlock(EmipModule):
                                                with_shift=with_shift)
 
 
-def _window_attention(q, k, v, B2, h, w, C, ldq, ldk, ldv, shift, splits):
-    """q/k/v: views with row strides ld*; returns message [B2, h*w, C]"""
+def _window_attention(q, k, v, B2, h, w, C, ldq, ldk, ldv, shift, splits, kv_rot=0):
+    """q/k/v: views with row strides ld*; returns message [B2, h*w, C].  kv_rot: keys / values of batch element b come from
+    element (b + kv_rot) mod B2 (cross attention: the other frame of the pair)"""
     rows, gid = window_tables(h, w, splits, shift, q.device)
     L = (h // splits) * (w // splits)
     out = torch.empty((B2, h * w, C), dtype=q.dtype, device=q.device)
     n = h * w
     ops.attention(q, k, v, out, batch=B2, heads=1, nwin=splits * splits, Lq=L, Lk=L, D=C, DV=C, q_bs=n * ldq,
                   k_bs=n * ldk, v_bs=n * ldv, o_bs=n * C, ldq=ldq, ldk=ldk, ldv=ldv, ldo=C, q_rows=rows, k_rows=rows,
-                  q_gid=gid if shift else None, k_gid=gid if shift else None, scale=C ** -0.5)
+                  q_gid=gid if shift else None, k_gid=gid if shift else None, scale=C ** -0.5, kv_rot=kv_rot)
     return out
 
 
@@ -136,19 +150,26 @@ class FeatureTransformer(EmipModule):
         for blk in self.layers:
             ws, wc = blk.self_attn.weights(), blk.cross_attn_ffn.weights()
             shift = blk.self_attn.with_shift
-            # k/v of the cross attention come from the OTHER frame as it is at block start
-            kvx = torch.empty((B2, n, 2 * C), dtype=dt, device=c0.device)
-            ops.gemm(c0[:B], wc["kv"], out=kvx[B:])
-            ops.gemm(c0[B:], wc["kv"], out=kvx[:B])
+            # one GEMM: q | k | v of the self attention and k | v of the cross attention, whose source is the OTHER frame as it
+            # is at block start -- read in place from the other half of the batch (kv_rot = B)
+            if FUSED_IN:
+                big = ops.gemm(c0, blk.fused_in())                               # [2B, n, 5C]
+                ck, cv, ldc5, rot = big[..., 3 * C:], big[..., 4 * C:], 5 * C, B
+            else:                       # three launches: the swapped halves projected separately, then q | k | v
+                kvx = torch.empty((B2, n, 2 * C), dtype=dt, device=c0.device)
+                ops.gemm(c0[:B], wc["kv"], out=kvx[B:])
+                ops.gemm(c0[B:], wc["kv"], out=kvx[:B])
+                big = ops.gemm(c0, ws["qkv"])
+                ck, cv, ldc5, rot = kvx, kvx[..., C:], 2 * C, 0
+            ldb = big.shape[-1]
             # ---- self attention (no FFN): c0 += LN(merge(attn))
-            qkv = ops.gemm(c0, ws["qkv"])
-            msg = _window_attention(qkv, qkv[..., C:], qkv[..., 2 * C:], B2, h, w, C, 3 * C, 3 * C, 3 * C, shift,
+            msg = _window_attention(big, big[..., C:], big[..., 2 * C:], B2, h, w, C, ldb, ldb, ldb, shift,
                                     attn_num_splits)
             msg = ops.gemm(msg, ws["merge"])
             ops.layernorm(msg, ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, out=c0, res=c0)    # c0 += LN(msg)
             # ---- cross attention + FFN
             q = ops.gemm(c0, wc["q"])
-            msg = _window_attention(q, kvx, kvx[..., C:], B2, h, w, C, C, 2 * C, 2 * C, shift, attn_num_splits)
+            msg = _window_attention(q, ck, cv, B2, h, w, C, C, ldc5, ldc5, shift, attn_num_splits, kv_rot=rot)
             msg = ops.gemm(msg, wc["merge"])
             msg = ops.layernorm(msg, wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps, out=msg)
             hid = ops.gemm(c0, wc["m0"], a2=msg, act=ops.ACT_GELU)

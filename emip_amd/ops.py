@@ -370,7 +370,8 @@ KV_SPLIT_TARGET = int(__import__('os').environ.get('EMIP_KV_TARGET', '512'))    
 
 def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo,
               q_hs=0, k_hs=0, v_hs=0, o_hs=0, q_rows=None, k_rows=None, q_gid=None, k_gid=None, scale=1.0,
-              scores=None, s_bs=0, lds=0, ksplit=None):
+              scores=None, s_bs=0, lds=0, ksplit=None, kv_rot=0):
+    """... kv_rot: keys / values of batch element b are read from element (b + kv_rot) mod batch"""
     _dev(q)
     o_f32 = 1 if (out.dtype == torch.float32 and q.dtype != torch.float32) else 0
     # long key sets on small grids: split the keys over workgroups (>= 4 key tiles each).  The kernel runs one wave per SIMD
@@ -385,11 +386,12 @@ def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_
         ksplit = 1
     else:
         ksplit = max(1, min(ntile // 4, (KV_SPLIT_TARGET + wgs - 1) // wgs, 32))
-    if ksplit > 1:
-        ws = torch.empty(batch * nwin * heads * ksplit * Lq * (DV + 2), dtype=torch.float32, device=q.device)
-        _lib.call("emip_attention_splitkv", _p(q), _p(k), _p(v), _p(out), _p(scores), batch, heads, nwin, Lq, Lk, D, DV,
+    if ksplit > 1 or kv_rot:
+        ws = (torch.empty(batch * nwin * heads * ksplit * Lq * (DV + 2), dtype=torch.float32, device=q.device)
+              if ksplit > 1 else None)
+        _lib.call("emip_attention_rot", _p(q), _p(k), _p(v), _p(out), _p(scores), batch, heads, nwin, Lq, Lk, D, DV,
                   q_bs, k_bs, v_bs, o_bs, s_bs, ldq, ldk, ldv, ldo, lds, q_hs, k_hs, v_hs, o_hs, _p(q_rows), _p(k_rows),
-                  _p(q_gid), _p(k_gid), float(scale), o_f32, ksplit, _p(ws), dt_code(q.dtype), _stream())
+                  _p(q_gid), _p(k_gid), float(scale), o_f32, ksplit, _p(ws), int(kv_rot), dt_code(q.dtype), _stream())
         return out
     _lib.call("emip_attention", _p(q), _p(k), _p(v), _p(out), _p(scores), batch, heads, nwin, Lq, Lk, D, DV, q_bs,
               k_bs, v_bs, o_bs, s_bs, ldq, ldk, ldv, ldo, lds, q_hs, k_hs, v_hs, o_hs, _p(q_rows), _p(k_rows),

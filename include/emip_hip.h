@@ -183,6 +183,15 @@ int emip_attention_splitkv(const void* Q, const void* K, const void* V, void* O,
                            const int* q_rows, const int* k_rows, const int* q_gid, const int* k_gid, float scale,
                            int o_f32, int ksplit, float* ws, int dtype, void* stream);
 
+/* emip_attention_splitkv with the keys / values of batch element b read from element (b + kv_batch_rot) mod batch: the cross
+ * attention of gmflow/transformer.py:281-301 (source = the other frame of the pair) on a batch that holds both frames, without
+ * copying or re-projecting the swapped halves. */
+int emip_attention_rot(const void* Q, const void* K, const void* V, void* O, void* S, int batch, int heads, int nwin, int Lq,
+                       int Lk, int D, int DV, long q_bs, long k_bs, long v_bs, long o_bs, long s_bs, long ldq, long ldk,
+                       long ldv, long ldo, long lds, long q_hs, long k_hs, long v_hs, long o_hs, const int* q_rows,
+                       const int* k_rows, const int* q_gid, const int* k_gid, float scale, int o_f32, int ksplit, float* ws,
+                       int kv_batch_rot, int dtype, void* stream);
+
 /* MDTA channel attention matrix: L2-normalise q,k over pixels, 64x64 Gram per head, * temperature, softmax.
  * PromptInteract.py:423-428.  ws: f32 [B*heads*(4096+128)] scratch; attn out: T [B][heads][64][64]. */
 int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K, long ldk, long k_bs, const float* temperature,
