@@ -56,11 +56,11 @@ def _launch_info(lib, name, a):
         # fc1 as a GEMM + 9 taps per hidden element; tokens in, weights once, activated hidden tensor out (the fc1 output
         # itself never leaves the CU, so it is not algorithmic traffic of this kernel)
         return 2.0 * M * N * K + 18.0 * M * N, "mlp_fc1dw_kernel", 2.0 * (M * K + N * K + M * N) + 8.0 * M + 44.0 * N
-    if name in ("emip_attention", "emip_attention_splitkv"):      # splitkv: the same arguments + (ksplit, workspace)
+    if name in ("emip_attention", "emip_attention_splitkv", "emip_attention_rot"):      # splitkv: + (ksplit, workspace); rot: + kv_rot
         batch, heads, nwin, Lq, Lk, D, DV = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
         dv = 2 if DV == 32 else DV                          # DV=32 carries a 2-channel value (flow / pixel grid)
         z = batch * heads * nwin
-        o_f32 = a[-3] if name == "emip_attention" else a[-5]
+        o_f32 = a[{"emip_attention": -3, "emip_attention_splitkv": -5, "emip_attention_rot": -6}[name]]
         byt = 2.0 * z * (Lq * D + Lk * D + Lk * dv) + (4.0 if o_f32 else 2.0) * z * Lq * dv
         if a[4]:                                            # raw scores (the correlation volume) written out
             byt += 2.0 * z * Lq * Lk
