@@ -207,52 +207,75 @@ class DwConvFn(Function):
 
 class SraAttentionFn(Function):
     """softmax(q k^T scale) v with head_dim 64 and <= 128 keys (PVT spatial-reduction attention).
-    q [B,N,C], kv [B,Lk,2C] (k | v, head h at columns 64h).  Backward recomputes P per head."""
+    q [B,N,C], kv [B,Lk,2C] (k | v, head h at columns 64h).  bf16: one launch forward (emip_sra_attention_lse, which also
+    leaves the log-sum-exp of every query) and ONE launch backward (emip_sra_attention_bwd: P recomputed from L, dQ / dK / dV
+    in a single pass over the queries).  f32 parity mode: the generic attention kernel forward, the unfused chain backward."""
 
     @staticmethod
     def forward(ctx, q, kv, heads, scale):
         B, N, C = q.shape
         Lk = kv.shape[1]
         out = torch.empty_like(q)
-        ops.attention(q, kv, kv[..., C:], out, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
-                      k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
-                      k_hs=64, v_hs=64, o_hs=64, scale=scale)
-        ctx.save_for_backward(q, kv)
-        ctx.cfg = (heads, scale)
+        fused = SRA_FUSED_BWD and q.dtype == torch.bfloat16 and Lk <= 128 and q.is_contiguous() and kv.is_contiguous()
+        if fused:
+            L = ops.sra_attention_lse(q, kv, out, B, heads, N, Lk, scale)
+            ctx.save_for_backward(q, kv, out, L)
+        else:
+            ops.attention(q, kv, kv[..., C:], out, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
+                          k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
+                          k_hs=64, v_hs=64, o_hs=64, scale=scale)
+            ctx.save_for_backward(q, kv)
+        ctx.cfg = (heads, scale, fused)
         return out
 
     @staticmethod
     def backward(ctx, do):
-        """all heads in one launch per step (two-level batch: image, head); dK / dV are accumulated straight into the f32
-        gradient of the kv projection output"""
-        q, kv = ctx.saved_tensors
-        heads, scale = ctx.cfg
-        do = do.contiguous()
-        B, N, C = q.shape
-        Lk = kv.shape[1]
-        Lp = 128
-        assert Lk <= Lp
-        dt, dev = q.dtype, q.device
-        Z = B * heads
-        k_, v_ = kv, kv[..., C:]                                  # head h: columns 64 h .. of k, C + 64 h .. of v
-        S = torch.empty((B, heads, N, Lp), dtype=dt, device=dev)
-        ops.gemm_heads(q, k_, S, Z, heads, N, Lk, 64, C, 2 * C, Lp, N * C, 64, Lk * 2 * C, 64, heads * N * Lp, N * Lp)
-        P = ops.softmax_rows(S.view(Z * N, Lp), Lk, scale, out=S.view(Z * N, Lp))
-        dkv32 = torch.zeros((B, Lp, 2 * C), dtype=torch.float32, device=dev)
-        ops.gemm_tn_heads(P, do, dkv32[..., C:], Z, heads, N, Lp, 64, Lp, C, 2 * C, heads * N * Lp, N * Lp, N * C, 64,
-                          Lp * 2 * C, 64)                                                         # dV
-        dP = torch.empty((B, heads, N, Lp), dtype=dt, device=dev)
-        ops.gemm_heads(do, v_, dP, Z, heads, N, Lk, 64, C, 2 * C, Lp, N * C, 64, Lk * 2 * C, 64, heads * N * Lp, N * Lp)
-        dS = ops.softmax_bwd_rows(P, dP.view(Z * N, Lp), Lk, scale, out=dP.view(Z * N, Lp))
-        kT = ops.transpose_pad_heads(kv, Z, heads, Lk, 64, Lp, 2 * C, Lk * 2 * C, 64)               # [Z,64,Lp]
-        dq = torch.empty_like(q)
-        ops.gemm_heads(dS, kT, dq, Z, heads, N, 64, Lp, Lp, Lp, C, heads * N * Lp, N * Lp, heads * 64 * Lp, 64 * Lp,
-                       N * C, 64)
-        ops.gemm_tn_heads(dS, q, dkv32, Z, heads, N, Lp, 64, Lp, C, 2 * C, heads * N * Lp, N * Lp, N * C, 64, Lp * 2 * C,
-                          64)                                                                      # dK
-        dkv = torch.empty((B, Lp, 2 * C), dtype=dt, device=dev)
-        ops.copy_cols(dkv32.view(B * Lp, 2 * C), 0, 2 * C, dkv.view(B * Lp, 2 * C), 0)
-        return dq, dkv[:, :Lk].contiguous(), None, None
+        heads, scale, fused = ctx.cfg
+        if fused:
+            q, kv, out, L = ctx.saved_tensors
+            B, N, C = q.shape
+            Lk = kv.shape[1]
+            dq, dkv32 = ops.sra_attention_bwd(q, kv, out, do.contiguous(), L, B, heads, N, Lk, scale)
+            dkv = torch.empty((B, 128, 2 * C), dtype=q.dtype, device=q.device)
+            ops.copy_cols(dkv32.view(B * 128, 2 * C), 0, 2 * C, dkv.view(B * 128, 2 * C), 0)
+            return dq, dkv[:, :Lk].contiguous(), None, None
+        return _sra_backward_unfused(ctx, do)
+
+
+SRA_FUSED_BWD = __import__("os").environ.get("EMIP_SRA_FUSED_BWD", "1") != "0"
+
+
+def _sra_backward_unfused(ctx, do):
+    """all heads in one launch per step (two-level batch: image, head); dK / dV are accumulated straight into the f32
+    gradient of the kv projection output"""
+    q, kv = ctx.saved_tensors
+    heads, scale, _ = ctx.cfg
+    do = do.contiguous()
+    B, N, C = q.shape
+    Lk = kv.shape[1]
+    Lp = 128
+    assert Lk <= Lp
+    dt, dev = q.dtype, q.device
+    Z = B * heads
+    k_, v_ = kv, kv[..., C:]                                  # head h: columns 64 h .. of k, C + 64 h .. of v
+    S = torch.empty((B, heads, N, Lp), dtype=dt, device=dev)
+    ops.gemm_heads(q, k_, S, Z, heads, N, Lk, 64, C, 2 * C, Lp, N * C, 64, Lk * 2 * C, 64, heads * N * Lp, N * Lp)
+    P = ops.softmax_rows(S.view(Z * N, Lp), Lk, scale, out=S.view(Z * N, Lp))
+    dkv32 = torch.zeros((B, Lp, 2 * C), dtype=torch.float32, device=dev)
+    ops.gemm_tn_heads(P, do, dkv32[..., C:], Z, heads, N, Lp, 64, Lp, C, 2 * C, heads * N * Lp, N * Lp, N * C, 64,
+                      Lp * 2 * C, 64)                                                         # dV
+    dP = torch.empty((B, heads, N, Lp), dtype=dt, device=dev)
+    ops.gemm_heads(do, v_, dP, Z, heads, N, Lk, 64, C, 2 * C, Lp, N * C, 64, Lk * 2 * C, 64, heads * N * Lp, N * Lp)
+    dS = ops.softmax_bwd_rows(P, dP.view(Z * N, Lp), Lk, scale, out=dP.view(Z * N, Lp))
+    kT = ops.transpose_pad_heads(kv, Z, heads, Lk, 64, Lp, 2 * C, Lk * 2 * C, 64)               # [Z,64,Lp]
+    dq = torch.empty_like(q)
+    ops.gemm_heads(dS, kT, dq, Z, heads, N, 64, Lp, Lp, Lp, C, heads * N * Lp, N * Lp, heads * 64 * Lp, 64 * Lp,
+                   N * C, 64)
+    ops.gemm_tn_heads(dS, q, dkv32, Z, heads, N, Lp, 64, Lp, C, 2 * C, heads * N * Lp, N * Lp, N * C, 64, Lp * 2 * C,
+                      64)                                                                      # dK
+    dkv = torch.empty((B, Lp, 2 * C), dtype=dt, device=dev)
+    ops.copy_cols(dkv32.view(B * Lp, 2 * C), 0, 2 * C, dkv.view(B * Lp, 2 * C), 0)
+    return dq, dkv[:, :Lk].contiguous(), None, None
 
 
 class BNReluFn(Function):

@@ -24,6 +24,8 @@ struct SraArgs {
     bf16_t* O;           // [B, Lq, C]
     int Lq, Lk, C, splits;
     float scale;
+    float* L;            // optional [B, heads, Lq]: log2-sum-exp of the scaled scores of every query (for the backward kernel)
+    int heads;
 };
 
 // byte offset of 16-B chunk c of row `row` in the V tile (128-B rows), conflict-free for the transposed reads
@@ -122,6 +124,8 @@ __global__ __launch_bounds__(256) void sra_kernel(const SraArgs p) {
                 psum += e;
             }
         psum += __shfl_xor(psum, 32);
+        if (p.L && h == 0 && blk * 32 + lq < p.Lq)
+            p.L[(batch * p.heads + head) * p.Lq + blk * 32 + lq] = mx + __log2f(psum);
         // ---- O^T = V^T P
         f32x16 oacc[2];
 #pragma unroll
@@ -178,11 +182,17 @@ __global__ __launch_bounds__(256) void sra_kernel(const SraArgs p) {
 
 extern "C" int emip_sra_attention(const void* Q, const void* KV, void* O, int batch, int heads, int Lq, int Lk, int C,
                                   float scale, void* stream) {
+    return emip_sra_attention_lse(Q, KV, O, nullptr, batch, heads, Lq, Lk, C, scale, stream);
+}
+
+// ... that also leaves L[b][head][q] = log2 sum_k exp2(scale log2(e) q.k) (f32), which emip_sra_attention_bwd needs
+extern "C" int emip_sra_attention_lse(const void* Q, const void* KV, void* O, float* L, int batch, int heads, int Lq, int Lk,
+                                      int C, float scale, void* stream) {
     EMIP_REQUIRE(Q && KV && O && batch > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lk <= 128 && C == heads * 64);
     EMIP_REQUIRE(batch < 65536 && heads < 65536 && aligned16(Q) && aligned16(KV) && aligned16(O));
     SraArgs a{};
     a.Q = (const bf16_t*)Q; a.KV = (const bf16_t*)KV; a.O = (bf16_t*)O;
-    a.Lq = Lq; a.Lk = Lk; a.C = C; a.scale = scale;
+    a.Lq = Lq; a.Lk = Lk; a.C = C; a.scale = scale; a.L = L; a.heads = heads;
     // about one workgroup per CU, and at least 4 query blocks (one per wave) in each
     const int nblk = (Lq + 31) / 32, pairs = batch * heads;
     int splits = (256 + pairs - 1) / pairs;

@@ -409,6 +409,27 @@ def sra_attention(q, kv, out, batch, heads, Lq, Lk, scale):
     return out
 
 
+def sra_attention_lse(q, kv, out, batch, heads, Lq, Lk, scale):
+    """sra_attention that also returns L f32 [batch, heads, Lq] (log2-sum-exp of the scaled scores) for sra_attention_bwd"""
+    _dev(q)
+    C = heads * 64
+    assert q.dtype == kv.dtype == out.dtype == torch.bfloat16 and q.is_contiguous() and kv.is_contiguous() and out.is_contiguous()
+    L = torch.empty((batch, heads, Lq), dtype=torch.float32, device=q.device)
+    _lib.call("emip_sra_attention_lse", _p(q), _p(kv), _p(out), _p(L), batch, heads, Lq, Lk, C, float(scale), _stream())
+    return L
+
+
+def sra_attention_bwd(q, kv, out, dout, L, batch, heads, Lq, Lk, scale):
+    """-> (dq bf16 [B,Lq,C], dkv f32 [B,128,2C]: dK at columns 64 h, dV at C + 64 h, rows >= Lk zero)"""
+    C = heads * 64
+    assert q.is_contiguous() and kv.is_contiguous() and out.is_contiguous() and dout.is_contiguous()
+    dq = torch.empty_like(q)
+    dkv = torch.zeros((batch, 128, 2 * C), dtype=torch.float32, device=q.device)
+    _lib.call("emip_sra_attention_bwd", _p(q), _p(kv), _p(out), _p(dout), _p(L), _p(dq), _p(dkv), batch, heads, Lq, Lk, C,
+              float(scale), _stream())
+    return dq, dkv
+
+
 def mdta_attn(q, kv_k, temperature, B, heads, P):
     """q [B,P,ldq] view, kv_k [B,P,ldk] view (the k half) -> attn [B,heads,64,64]."""
     _dev(q)

@@ -108,6 +108,18 @@ int emip_gemm8_cfg_stages(int cfg, int lnt);
  * pair stay in registers and the values in LDS while a wave streams 32-query blocks (sra.hip). */
 int emip_sra_attention(const void* Q, const void* KV, void* O, int batch, int heads, int Lq, int Lk, int C, float scale,
                        void* stream);
+/* ... that also leaves L[b][head][q] = log2-sum-exp of the scaled scores (f32 [batch][heads][Lq]) for emip_sra_attention_bwd */
+int emip_sra_attention_lse(const void* Q, const void* KV, void* O, float* L, int batch, int heads, int Lq, int Lk, int C,
+                           float scale, void* stream);
+
+/* Backward of the spatial-reduction attention (lib/pvt_v2.py:113-125 under loss.backward(), train.py:52-58), bf16, head_dim 64,
+ * Lk <= 128, in ONE launch: recomputes P from Q, K and the saved L, and produces dQ [B, Lq, C] (bf16) and dKV f32
+ * [B, 128, 2C] (dK at columns 64 h, dV at C + 64 h; rows >= Lk untouched), ADDED into a buffer the caller has cleared
+ * (the query range of an (image, head) pair may be split over workgroups).  O = the forward output, dO its gradient.
+ * Replaces the unfused chain of the first rounds (three batched GEMMs, two softmax passes, two transposed GEMMs, two copies
+ * per block), which materialised the [B, heads, Lq, 128] score matrices four times. */
+int emip_sra_attention_bwd(const void* Q, const void* KV, const void* O, const void* dO, const float* L, void* dQ, float* dKV,
+                           int batch, int heads, int Lq, int Lk, int C, float scale, void* stream);
 
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
 int emip_gemm_tile(long M, long N, long batch, long K);

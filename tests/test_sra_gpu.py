@@ -49,3 +49,35 @@ def test_sra_writes_nothing_beyond_its_rows():
     buf = torch.full((B * N * C + 4096,), 9.0, device=dev, dtype=torch.bfloat16)
     ops.sra_attention(q, kv, buf[:B * N * C].view(B, N, C), B, heads, N, Lk, 0.125)
     assert (buf[B * N * C:] == 9.0).all()
+
+
+@pytest.mark.parametrize("B,heads,Lq,Lk", [(3, 5, 484, 121), (2, 1, 7744, 121), (4, 2, 1936, 121), (2, 8, 121, 121), (2, 2, 300, 77)])
+def test_sra_attention_backward_fused(B, heads, Lq, Lk):
+    """emip_sra_attention_lse + emip_sra_attention_bwd (one launch each) against torch autograd on the rounded operands:
+    the forward's output and log-sum-exp, dQ, dK, dV.  Shapes: the four PVT stages (stage 1 splits its 242 query blocks over
+    workgroups: dK / dV meet by atomics), and one with a ragged query count and fewer keys."""
+    from emip_amd import ops
+    C = heads * 64
+    g = torch.Generator().manual_seed(B * 100 + heads)
+    q = torch.randn(B, Lq, C, generator=g).to(torch.bfloat16).cuda()
+    kv = torch.randn(B, Lk, 2 * C, generator=g).to(torch.bfloat16).cuda()
+    do = torch.randn(B, Lq, C, generator=g).to(torch.bfloat16).cuda()
+    scale = 0.125
+    out = torch.empty_like(q)
+    L = ops.sra_attention_lse(q, kv, out, B, heads, Lq, Lk, scale)
+    dq, dkv = ops.sra_attention_bwd(q, kv, out, do, L, B, heads, Lq, Lk, scale)
+    qf = q.float().view(B, Lq, heads, 64).permute(0, 2, 1, 3).requires_grad_(True)
+    kf = kv.float()[..., :C].reshape(B, Lk, heads, 64).permute(0, 2, 1, 3).requires_grad_(True)
+    vf = kv.float()[..., C:].reshape(B, Lk, heads, 64).permute(0, 2, 1, 3).requires_grad_(True)
+    s = (qf @ kf.transpose(-1, -2)) * scale
+    ref = torch.softmax(s, -1) @ vf
+    ref.backward(do.float().view(B, Lq, heads, 64).permute(0, 2, 1, 3))
+    rel = lambda a, b: ((a.float() - b).abs().max() / (b.abs().max() + 1e-9)).item()
+    assert rel(out.view(B, Lq, heads, 64).permute(0, 2, 1, 3), ref.detach()) < 1e-2
+    lref = torch.logsumexp(s.detach(), -1) * 1.4426950408889634
+    assert (L - lref).abs().max().item() < 2e-2
+    assert rel(dq.view(B, Lq, heads, 64).permute(0, 2, 1, 3), qf.grad) < 2e-2
+    dk = dkv[:, :Lk, :C].reshape(B, Lk, heads, 64).permute(0, 2, 1, 3)
+    dv = dkv[:, :Lk, C:].reshape(B, Lk, heads, 64).permute(0, 2, 1, 3)
+    assert rel(dk, kf.grad) < 2e-2 and rel(dv, vf.grad) < 2e-2
+    assert not dkv[:, Lk:].any()
