@@ -236,9 +236,9 @@ class SraAttentionFn(Function):
             B, N, C = q.shape
             Lk = kv.shape[1]
             dq, dkv32 = ops.sra_attention_bwd(q, kv, out, do.contiguous(), L, B, heads, N, Lk, scale)
-            dkv = torch.empty((B, 128, 2 * C), dtype=q.dtype, device=q.device)
-            ops.copy_cols(dkv32.view(B * 128, 2 * C), 0, 2 * C, dkv.view(B * 128, 2 * C), 0)
-            return dq, dkv[:, :Lk].contiguous(), None, None
+            dkv = torch.empty((B, Lk, 2 * C), dtype=q.dtype, device=q.device)
+            ops.copy_cols(dkv32.view(B * Lk, 2 * C), 0, 2 * C, dkv.view(B * Lk, 2 * C), 0)
+            return dq, dkv, None, None
         return _sra_backward_unfused(ctx, do)
 
 

@@ -12,7 +12,7 @@
 //   * S^T, dP^T come out with the query on the lane, so P and dS are the B operand of dQ^T += K_w^T dS^T as they stand;
 //     for dV += P^T dO and dK += dS^T Q they take A-operand shape through a wave-private 32 x 32 LDS tile;
 //   * the four waves' dQ partials (one per key block) meet in LDS and leave as whole 128-byte rows;
-//   * dK / dV are ADDED (f32 atomics, 128-byte row segments) into a pre-cleared [B, 128, 2C] buffer: the query range of an
+//   * dK / dV are ADDED (f32 atomics, 128-byte row segments) into a pre-cleared [B, Lk, 2C] buffer: the query range of an
 //     (image, head) pair may be split over workgroups.
 #include "common.h"
 
@@ -25,7 +25,7 @@ struct SraBwdArgs {
     const bf16_t* dO;    // [B, Lq, C]
     const float* L;      // [B, heads, Lq]  log2-sum-exp of the scaled scores
     bf16_t* dQ;          // [B, Lq, C]
-    float* dKV;          // [B, 128, 2C]  accumulated into
+    float* dKV;          // [B, Lk, 2C]  accumulated into
     int Lq, Lk, C, heads, splits;
     float scale;
 };
@@ -259,7 +259,7 @@ __global__ __launch_bounds__(256) void sra_bwd_kernel(const SraBwdArgs p) {
     }
 
     // ---- dK_w, dV_w: lane = head channel 32 dt + lq, register = key 32 w + 8 (r >> 2) + 4 h + (r & 3) ----------------------
-    float* __restrict__ dkp = p.dKV + batch * 128 * 2 * p.C + head * 64;
+    float* __restrict__ dkp = p.dKV + batch * p.Lk * 2 * p.C + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll

@@ -420,11 +420,11 @@ def sra_attention_lse(q, kv, out, batch, heads, Lq, Lk, scale):
 
 
 def sra_attention_bwd(q, kv, out, dout, L, batch, heads, Lq, Lk, scale):
-    """-> (dq bf16 [B,Lq,C], dkv f32 [B,128,2C]: dK at columns 64 h, dV at C + 64 h, rows >= Lk zero)"""
+    """-> (dq bf16 [B,Lq,C], dkv f32 [B,Lk,2C]: dK at columns 64 h, dV at C + 64 h)"""
     C = heads * 64
     assert q.is_contiguous() and kv.is_contiguous() and out.is_contiguous() and dout.is_contiguous()
     dq = torch.empty_like(q)
-    dkv = torch.zeros((batch, 128, 2 * C), dtype=torch.float32, device=q.device)
+    dkv = torch.zeros((batch, Lk, 2 * C), dtype=torch.float32, device=q.device)
     _lib.call("emip_sra_attention_bwd", _p(q), _p(kv), _p(out), _p(dout), _p(L), _p(dq), _p(dkv), batch, heads, Lq, Lk, C,
               float(scale), _stream())
     return dq, dkv

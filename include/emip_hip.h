@@ -114,7 +114,7 @@ int emip_sra_attention_lse(const void* Q, const void* KV, void* O, float* L, int
 
 /* Backward of the spatial-reduction attention (lib/pvt_v2.py:113-125 under loss.backward(), train.py:52-58), bf16, head_dim 64,
  * Lk <= 128, in ONE launch: recomputes P from Q, K and the saved L, and produces dQ [B, Lq, C] (bf16) and dKV f32
- * [B, 128, 2C] (dK at columns 64 h, dV at C + 64 h; rows >= Lk untouched), ADDED into a buffer the caller has cleared
+ * [B, Lk, 2C] (dK at columns 64 h, dV at C + 64 h), ADDED into a buffer the caller has cleared
  * (the query range of an (image, head) pair may be split over workgroups).  O = the forward output, dO its gradient.
  * Replaces the unfused chain of the first rounds (three batched GEMMs, two softmax passes, two transposed GEMMs, two copies
  * per block), which materialised the [B, heads, Lq, 128] score matrices four times. */
