@@ -33,10 +33,22 @@ class LinearFn(Function):
     """y = x W^T + b (+ res).  wp: W packed [N,K] in the activation dtype, wpt: W^T packed [K,N]."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, wp, wpt, bpack=None):
+    def forward(ctx, x, weight, bias, res, wp, wpt, bpack=None, drop=None):
         # wp may carry zero-padded output rows (N padded to a multiple of 8: the 1-channel mask head); bpack is the
-        # matching padded bias
-        y = ops.gemm(x, wp, bias=bias if bpack is None else bpack, res=res)
+        # matching padded bias.  drop = (scale f32 [B], scale [B, C], scale - 1 [B, C], rows per sample): stochastic depth,
+        # y = res + scale[sample] * (x W^T + b), applied in the GEMM's epilogue where the 8-wave body takes the launch
+        b = bias if bpack is None else bpack
+        ctx.drop = None
+        if drop is not None:
+            sb, s_bc, sm1, rps = drop
+            ctx.drop = (sm1, rps)
+            y = ops.gemm_rowscale(x, wp, b, res, sb, rps)
+            if y is None:
+                br = ops.gemm(x, wp, bias=b)
+                y = torch.empty_like(res)
+                ops.colscale_add(res, br, s_bc, s_bc.shape[1], rps, y)
+        else:
+            y = ops.gemm(x, wp, bias=b, res=res)
         ctx.save_for_backward(x, weight)
         ctx.wpt, ctx.has_bias, ctx.has_res = wpt, bias is not None, res is not None
         return y
@@ -45,6 +57,12 @@ class LinearFn(Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
+        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
+        if ctx.drop is not None:                  # the branch sees scale * dy; the skip path the plain dy
+            sm1, rps = ctx.drop
+            dyb = torch.empty_like(dy)
+            ops.colscale_add(dy, dy, sm1, sm1.shape[1], rps, dyb)        # dy + (s - 1) dy = s dy
+            dy = dyb
         dx = ops.gemm(dy, ctx.wpt) if ctx.needs_input_grad[0] else None
         dw = db = None
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
@@ -59,8 +77,7 @@ class LinearFn(Function):
             dw = dwf[:n, :kw].contiguous().view_as(weight)
         elif want_db:
             db = colsum_f32(dy)[:weight.shape[0]].contiguous()
-        dres = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
-        return dx, dw, db, dres, None, None, None
+        return dx, dw, db, dres, None, None, None, None
 
 
 class ConvFn(Function):

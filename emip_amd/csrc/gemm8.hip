@@ -57,6 +57,8 @@ struct G8Args {
     const float* lne_colsum;   // [N] column sums of W
     float lne_eps;
     float* out_stats;          // [M, 2]: accumulates (sum, sum of squares) of the stored rows
+    const float* rowscale;     // [M / rs_rows] or null: act(...) of row m is multiplied by rowscale[m / rs_rows] BEFORE the
+    int rs_rows;               // residual is added (stochastic depth: residual + scale[sample] * branch)
     unsigned* zero_ptr;
     long zero_words;
     int H, Wd, Cin, KH, KW, stride, pad, Ho, Wo;   // conv geometry (CONV instances)
@@ -360,11 +362,12 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
         const bool gelu = p.act == EMIP_ACT_GELU, relu = p.act == EMIP_ACT_RELU;
         const float invK = 1.f / (float)p.K;
         const bool vec_ok = ((p.ldc & 7) == 0) && (!p.R || (p.ldr & 7) == 0);
-        float rsv[TM], mrsv[TM], st1[TM], st2[TM];
+        float rsv[TM], mrsv[TM], st1[TM], st2[TM], rsc[TM];
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             rsv[a] = 1.f;
             mrsv[a] = st1[a] = st2[a] = 0.f;
+            rsc[a] = p.rowscale ? p.rowscale[min(m0 + wm * WTM + 16 * a + fr, p.M - 1) / p.rs_rows] : 1.f;
             if (p.lne_stats) {
                 const int m = min(m0 + wm * WTM + 16 * a + fr, p.M - 1);
                 const float2 s2 = *reinterpret_cast<const float2*>(p.lne_stats + 2 * (long)m);
@@ -398,6 +401,10 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                     if (gelu) x = gelu_t<bf16_t>(x);
                     else if (relu) x = fmaxf(x, 0.f);
                     v[j] = x;
+                }
+                if (p.rowscale) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= rsc[a];
                 }
                 if (m < p.M && n < p.N) {
                     bf16_t* cp = p.C + (long)m * p.ldc + n;
@@ -447,6 +454,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                                                                             p.bias ? p.bias[n + j] : 0.f));
                             if (gelu) x = gelu_t<bf16_t>(x);
                             else if (relu) x = fmaxf(x, 0.f);
+                            x *= rsc[a];
                             if (p.R) x += (float)p.R[(long)m * p.ldr + n + j];
                             const bf16_t o = (bf16_t)x;
                             p.C[(long)m * p.ldc + n + j] = o;
@@ -616,6 +624,33 @@ extern "C" int emip_gemm8(const void* A, const void* A2, const void* W, void* C,
     a.ldc = ldc; a.ldr = ldr; a.act = act; a.lne_stats = lne_stats; a.lne_colsum = lne_colsum; a.lne_eps = lne_eps;
     a.out_stats = out_stats; a.zero_ptr = (unsigned*)zero_ptr; a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
     a.a_bytes = (unsigned)ab; a.a2_bytes = (unsigned)a2b; a.w_bytes = (unsigned)wb;
+    return launch(a, cfg, false, (hipStream_t)stream);
+}
+
+// emip_gemm8 with a per-sample scale on the branch: C = R + rowscale[m / rs_rows] * act(A W^T + bias) -- stochastic depth
+// (timm DropPath as used by lib/pvt_v2.py:167-169) applied in the epilogue of the proj / fc2 GEMM of a training forward
+extern "C" int emip_gemm8_rs(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M,
+                          int N, int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act,
+                          const float* lne_stats, const float* lne_colsum, float lne_eps, float* out_stats, void* zero_ptr,
+                          long zero_bytes, const float* rowscale, int rs_rows, int cfg, void* stream) {
+    EMIP_REQUIRE(!rowscale || rs_rows > 0);
+    EMIP_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && (K % 64) == 0);
+    EMIP_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C) && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= (A2 ? K1 : K) &&
+                 ldw >= K && ldc >= N);
+    EMIP_REQUIRE(!R || (aligned16(R) && ldr >= N));
+    EMIP_REQUIRE(!A2 || (aligned16(A2) && K1 > 0 && K1 < K && (K1 % 64) == 0 && (lda2 % 8) == 0 && lda2 >= K - K1));
+    EMIP_REQUIRE(!lne_stats || lne_colsum);
+    EMIP_REQUIRE((zero_bytes % 4) == 0 && (!zero_ptr || (reinterpret_cast<uintptr_t>(zero_ptr) & 3u) == 0));
+    const long ab = ((long)(M - 1) * lda + (A2 ? K1 : K)) * 2, wb = ((long)(N - 1) * ldw + K) * 2;
+    const long a2b = A2 ? ((long)(M - 1) * lda2 + (K - K1)) * 2 : 0;
+    EMIP_REQUIRE(ab < (1L << 31) && wb < (1L << 31) && a2b < (1L << 31));
+    G8Args a = {};
+    a.A = (const bf16_t*)A; a.A2 = (const bf16_t*)A2; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias;
+    a.R = (const bf16_t*)R; a.M = M; a.N = N; a.K = K; a.K1 = A2 ? K1 : K; a.lda = lda; a.lda2 = A2 ? lda2 : 0; a.ldw = ldw;
+    a.ldc = ldc; a.ldr = ldr; a.act = act; a.lne_stats = lne_stats; a.lne_colsum = lne_colsum; a.lne_eps = lne_eps;
+    a.out_stats = out_stats; a.zero_ptr = (unsigned*)zero_ptr; a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
+    a.a_bytes = (unsigned)ab; a.a2_bytes = (unsigned)a2b; a.w_bytes = (unsigned)wb;
+    a.rowscale = rowscale; a.rs_rows = rs_rows;
     return launch(a, cfg, false, (hipStream_t)stream);
 }
 

@@ -80,7 +80,7 @@ class Mlp(EmipModule):
         self.dwconv = DWConv(hidden_features)
         self.fc2 = nn.Linear(hidden_features, out_features)
 
-    def run_train(self, h, residual):
+    def run_train(self, h, residual, drop=None):
         dt = self.cdtype
         dw = self.dwconv.dwconv
         (w1, w1t), (w2, w2t), wd, wdf = self.packed(
@@ -88,11 +88,11 @@ class Mlp(EmipModule):
             lambda a, b, c: (_lin_packs(a, dt), _lin_packs(b, dt), pack_dw(c), pack_dw(c, flip=True)))
         t = LinearFn.apply(h, self.fc1.weight, self.fc1.bias, None, w1, w1t)
         t = DwConvFn.apply(t, dw.weight, dw.bias, wd, wdf, True)
-        return LinearFn.apply(t, self.fc2.weight, self.fc2.bias, residual, w2, w2t)
+        return LinearFn.apply(t, self.fc2.weight, self.fc2.bias, residual, w2, w2t, None, drop)
 
-    def run(self, h, residual):
+    def run(self, h, residual, drop=None):
         if torch.is_grad_enabled():
-            return self.run_train(h, residual)
+            return self.run_train(h, residual, drop)
         dt = self.cdtype
         w1, b1, wd, bd, w2, b2 = self.packed(
             "mlp", (self.fc1.weight, self.fc1.bias, self.dwconv.dwconv.weight, self.dwconv.dwconv.bias,
@@ -118,7 +118,7 @@ class Attention(EmipModule):
             self.sr = nn.Conv2d(dim, dim, kernel_size=sr_ratio, stride=sr_ratio)
             self.norm = nn.LayerNorm(dim)
 
-    def run_train(self, h, residual):
+    def run_train(self, h, residual, drop=None):
         dt, C, heads, sr = self.cdtype, self.dim, self.num_heads, self.sr_ratio
         B, H, W, _ = h.shape
         (wq, wqt), (wkv, wkvt), (wp, wpt) = self.packed(
@@ -135,12 +135,12 @@ class Attention(EmipModule):
         Lk = s_.shape[1] * s_.shape[2]
         kv = LinearFn.apply(s_, self.kv.weight, self.kv.bias, None, wkv, wkvt)
         a = SraAttentionFn.apply(q.view(B, H * W, C), kv.view(B, Lk, 2 * C), heads, self.scale).view(B, H, W, C)
-        return LinearFn.apply(a, self.proj.weight, self.proj.bias, residual, wp, wpt)
+        return LinearFn.apply(a, self.proj.weight, self.proj.bias, residual, wp, wpt, None, drop)
 
-    def run(self, h, residual):
+    def run(self, h, residual, drop=None):
         """h: normed tokens [B,H,W,C]; returns residual + proj(attn) written in place."""
         if torch.is_grad_enabled():
-            return self.run_train(h, residual)
+            return self.run_train(h, residual, drop)
         dt, C, heads, sr = self.cdtype, self.dim, self.num_heads, self.sr_ratio
         B, H, W, _ = h.shape
         assert C // heads == 64, "the fused attention kernel is built for head_dim 64"
@@ -182,21 +182,22 @@ class Block(EmipModule):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio))
 
     def _drop_scale(self, x, tag):
-        """per-sample DropPath factor Bernoulli(keep) / keep as f32 [B, C], and the same minus one (the backward's
-        coefficient).  `forced_drop` (dict tag -> [B] factors) overrides the draw (parity tests force the same factors on
-        both sides); otherwise the stage drew the factors of all its blocks in one go (`_drop_pre`, see draw_drop_tables)."""
+        """per-sample DropPath factor Bernoulli(keep) / keep as (f32 [B], the same repeated over channels [B, C], that minus
+        one -- the backward's coefficient).  `forced_drop` (dict tag -> [B] factors) overrides the draw (parity tests force
+        the same factors on both sides); otherwise the stage drew the factors of all its blocks in one go (`_drop_pre`, see
+        draw_drop_tables)."""
         B, C = x.shape[0], x.shape[-1]
         forced = getattr(self, "forced_drop", None)
         pre = getattr(self, "_drop_pre", None)
-        if forced is None and pre is not None and pre[tag][0].shape == (B, C) and pre[tag][0].device == x.device:
+        if forced is None and pre is not None and pre[tag][1].shape == (B, C) and pre[tag][1].device == x.device:
             return pre[tag]
         if forced is not None:
-            s = forced[tag].to(device=x.device, dtype=torch.float32)
+            sb = forced[tag].to(device=x.device, dtype=torch.float32).contiguous()
         else:
             keep = 1.0 - self.drop_path_rate
-            s = torch.floor(keep + torch.rand(B, device=x.device)) / keep
-        s = s.view(B, 1).expand(B, C).contiguous()
-        return s, s - 1.0
+            sb = torch.floor(keep + torch.rand(B, device=x.device)) / keep
+        s = sb.view(B, 1).expand(B, C).contiguous()
+        return sb, s, s - 1.0
 
     def _folded(self):
         """packed weights with the block's LayerNorm affines folded in: y = LN(x) W^T + b = xhat (W*gamma)^T + (b + W beta)"""
@@ -332,10 +333,11 @@ class Block(EmipModule):
                 with torch.enable_grad():
                     return self.run(x)
             rps = x.shape[1] * x.shape[2]
+            # the per-sample factor is applied in the epilogue of the branch's last GEMM (proj / fc2), which also adds the skip
             h, xs = LayerNormSkipFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-            x = DropPathAddFn.apply(xs, self.attn.run(h, None), *self._drop_scale(x, "attn"), rps)
+            x = self.attn.run(h, xs, drop=self._drop_scale(x, "attn") + (rps,))
             h, xs = LayerNormSkipFn.apply(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-            return DropPathAddFn.apply(xs, self.mlp.run(h, None), *self._drop_scale(x, "mlp"), rps)
+            return self.mlp.run(h, xs, drop=self._drop_scale(x, "mlp") + (rps,))
         if torch.is_grad_enabled():
             h, xs = LayerNormSkipFn.apply(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
             x = self.attn.run(h, xs)
@@ -366,10 +368,12 @@ def draw_drop_tables(blocks, B, C, device):
     k = _KEEP_CACHE.get(ck)
     if k is None:                                   # the keep probabilities of a stage never change: upload them once
         k = _KEEP_CACHE[ck] = torch.tensor(keeps, dtype=torch.float32).to(device).view(-1, 1)
-    s = (torch.floor(k + torch.rand(len(keeps), B, device=device)) / k).view(-1, B, 1).expand(-1, B, C).contiguous()
+    sb = (torch.floor(k + torch.rand(len(keeps), B, device=device)) / k).contiguous()        # [2 n, B]
+    s = sb.view(-1, B, 1).expand(-1, B, C).contiguous()
     sm1 = s - 1.0
     for i, b in enumerate(blocks):
-        object.__setattr__(b, "_drop_pre", {"attn": (s[2 * i], sm1[2 * i]), "mlp": (s[2 * i + 1], sm1[2 * i + 1])})
+        object.__setattr__(b, "_drop_pre", {"attn": (sb[2 * i], s[2 * i], sm1[2 * i]),
+                                            "mlp": (sb[2 * i + 1], s[2 * i + 1], sm1[2 * i + 1])})
 
 
 class OverlapPatchEmbed(EmipModule):

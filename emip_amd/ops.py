@@ -194,6 +194,25 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=No
     return out
 
 
+DROP_EPILOGUE = __import__('os').environ.get('EMIP_DROP_EPILOGUE', '1') != '0'
+
+
+def gemm_rowscale(a, w, bias, res, rowscale, rs_rows):
+    """res + rowscale[m // rs_rows] * (a w^T + bias): the branch of a residual block scaled per sample in the GEMM's epilogue
+    (stochastic depth).  Returns None when the launch is not one the 8-wave body takes (the caller then scales separately)."""
+    M, K, lda = rows(a)
+    N = w.shape[0]
+    if not (DROP_EPILOGUE and a.dtype == torch.bfloat16 and gemm8_enabled()
+            and _lib.load().emip_gemm8_dispatch(M, N, K, lda, K, K, 0, 0)):
+        return None
+    out = torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
+    _, _, ldr = rows(res)
+    assert rowscale.dtype == torch.float32 and rowscale.is_contiguous() and rowscale.numel() * rs_rows >= M
+    _lib.call("emip_gemm8_rs", _p(a), None, _p(w), _p(out), _p(bias), _p(res), M, N, K, K, lda, 0, K, N, ldr, ACT_NONE, None,
+              None, 0.0, None, None, 0, _p(rowscale), int(rs_rows), 0, _stream())
+    return out
+
+
 def gemm8_enabled():
     """False when EMIP_GEMM8=0 keeps every launch on the 4-wave bodies (A/B calibration)"""
     import os

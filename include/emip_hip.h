@@ -85,6 +85,12 @@ int emip_gemm8(const void* A, const void* A2, const void* W, void* C, const floa
                int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, const float* ln_stats,
                const float* colsum, float ln_eps, float* out_stats, void* zero_ptr, long zero_bytes, int cfg,
                void* stream);
+/* emip_gemm8 with a per-sample scale on the branch: C = R + rowscale[m / rs_rows] * act(A W^T + bias) -- stochastic depth
+ * (lib/pvt_v2.py:167-169 DropPath in the training forward) in the epilogue of the proj / fc2 GEMM; rowscale f32 [ceil(M / rs_rows)] */
+int emip_gemm8_rs(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M, int N,
+               int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, const float* ln_stats,
+               const float* colsum, float ln_eps, float* out_stats, void* zero_ptr, long zero_bytes, const float* rowscale,
+                  int rs_rows, int cfg, void* stream);
 /* emip_conv8 with ln_stats != NULL: a pad-0 patch conv behind a folded LayerNorm (the spatial-reduction conv of
  * lib/pvt_v2.py:106-108 reading norm1(x)) with the LayerNorm on the OUTPUT side, tap by tap:
  *   y = sum_tap rstd_tap (W_tap . x_tap - mean_tap tapsum_tap) + bias,

@@ -128,3 +128,26 @@ def test_dispatch_routes_large_bf16_launches_to_the_same_arithmetic():
     assert (ops.gemm(a2, w2).float() - ref).abs().max().item() < 3e-2
     a3, w3 = _rand(4096, 320, seed=23), _rand(64, 320, scale=320 ** -0.5, seed=24)
     assert (ops.gemm(a3, w3) - a3 @ w3.t()).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("B,rps,K,N", [(8, 484, 320, 320), (5, 1936, 512, 128), (64, 121, 2048, 512)])
+def test_gemm8_rowscale_epilogue(B, rps, K, N):
+    """emip_gemm8_rs: res + scale[sample] * (a w^T + bias) -- stochastic depth (lib/pvt_v2.py:167-169) in the epilogue of
+    the branch's last GEMM -- against torch on the rounded operands, with dropped samples (scale 0) in the batch"""
+    from emip_amd import ops
+    M = B * rps
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    res = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    sc = torch.floor(0.7 + torch.rand(B, generator=g)) / 0.7
+    sc[1], sc[2] = 0.0, 1.0 / 0.7                              # at least one dropped and one kept sample
+    sc = sc.cuda()
+    out = ops.gemm_rowscale(a, w, bias, res, sc, rps)
+    assert out is not None
+    ref = res.float() + sc.repeat_interleave(rps).view(M, 1) * (a.float() @ w.float().t() + bias)
+    err = (out.float() - ref).abs().max().item()
+    assert err < 0.02 * ref.abs().max().item(), err
+    drop = (sc.repeat_interleave(rps) == 0).nonzero()[:4, 0]
+    assert torch.equal(out[drop], res[drop])                  # a dropped sample keeps its skip path bit for bit
