@@ -100,7 +100,9 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int WGM, int WGN, int NST, bool CONV, bool LNT = false>
+// RS: the per-sample scale of the epilogue (emip_gemm8_rs) is its own instance -- compiled into every instance it cost the
+// inference step 1.2 % (1133 -> 1120 pairs/s in-call: one more live register per accumulator row in every epilogue)
+template <int BM, int BN, int WGM, int WGN, int NST, bool CONV, bool LNT = false, bool RS = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;      // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16;        // 16x16 accumulators per wave
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
         for (int a = 0; a < TM; ++a) {
             rsv[a] = 1.f;
             mrsv[a] = st1[a] = st2[a] = 0.f;
-            rsc[a] = p.rowscale ? p.rowscale[min(m0 + wm * WTM + 16 * a + fr, p.M - 1) / p.rs_rows] : 1.f;
+            rsc[a] = RS ? p.rowscale[min(m0 + wm * WTM + 16 * a + fr, p.M - 1) / p.rs_rows] : 1.f;
             if (p.lne_stats) {
                 const int m = min(m0 + wm * WTM + 16 * a + fr, p.M - 1);
                 const float2 s2 = *reinterpret_cast<const float2*>(p.lne_stats + 2 * (long)m);
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                     else if (relu) x = fmaxf(x, 0.f);
                     v[j] = x;
                 }
-                if (p.rowscale) {
+                if (RS) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] *= rsc[a];
                 }
@@ -454,7 +456,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                                                                             p.bias ? p.bias[n + j] : 0.f));
                             if (gelu) x = gelu_t<bf16_t>(x);
                             else if (relu) x = fmaxf(x, 0.f);
-                            x *= rsc[a];
+                            if (RS) x *= rsc[a];
                             if (p.R) x += (float)p.R[(long)m * p.ldr + n + j];
                             const bf16_t o = (bf16_t)x;
                             p.C[(long)m * p.ldc + n + j] = o;
@@ -492,15 +494,17 @@ struct Cfg {
     void (*dense)(const G8Args);
     void (*conv)(const G8Args);
     void (*lnt)(const G8Args);      // conv with the per-tap LayerNorm (small tiles only)
+    void (*rs)(const G8Args);       // dense with the per-sample epilogue scale (emip_gemm8_rs)
 };
 
-#define G8_CFG(BM, BN, WGM, WGN, NST) \
-    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr}
+#define G8_CFG(BM, BN, WGM, WGN, NST)                                                                            \
+    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr, \
+     gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>}
 // the per-tap LayerNorm instances serve 31..183 workgroups walking 20..64 K tiles each: a 5-deep ring (4 tiles in flight)
 constexpr int NST_LNT = 5;
 #define G8_CFG_LNT(BM, BN, WGM, WGN, NST)                                                             \
     {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, \
-     gemm8_kernel<BM, BN, WGM, WGN, NST_LNT, true, true>}
+     gemm8_kernel<BM, BN, WGM, WGN, NST_LNT, true, true>, gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>}
 
 const Cfg g_cfg[] = {
     G8_CFG(256, 128, 4, 2, 3),       // 1: wave 64 x 64, 144 KB
@@ -541,9 +545,11 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     size_t lds = (size_t)g.nst * (g.bm + g.bn) * 128;
     if (lnt) lds = (size_t)NST_LNT * ((g.bm + g.bn) * 128 + 2048) + (size_t)a.KH * a.KW * g.bn * 4;
     if (lds > 160 * 1024) return EMIP_E_INVALID;
-    auto fn = lnt ? g.lnt : (conv ? g.conv : g.dense);
-    const int which = lnt ? 2 : (conv ? 1 : 0);
-    static size_t attr_done[NCFG][3];
+    const bool rs = a.rowscale != nullptr;
+    if (rs && (lnt || conv)) return EMIP_E_INVALID;
+    auto fn = rs ? g.rs : (lnt ? g.lnt : (conv ? g.conv : g.dense));
+    const int which = rs ? 3 : (lnt ? 2 : (conv ? 1 : 0));
+    static size_t attr_done[NCFG][4];
     if (attr_done[cfg - 1][which] < lds) {
         if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return EMIP_E_LAUNCH;
