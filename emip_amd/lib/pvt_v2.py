@@ -59,6 +59,8 @@ SRA_KERNEL = os.environ.get("EMIP_SRA_KERNEL", "1") != "0"
 _lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
 # fc1 + depthwise + GELU as one kernel where an image fits one workgroup (stages 3 and 4); EMIP_MLP_FC1DW=0: two launches
 MLP_FC1DW = os.environ.get("EMIP_MLP_FC1DW", "1") != "0"
+# q projection + spatial-reduction attention + proj + residual of the inference block in one launch (emip_sra_block)
+SRA_BLOCK = os.environ.get("EMIP_SRA_BLOCK", "1") != "0"
 
 
 class DWConv(EmipModule):
@@ -222,6 +224,12 @@ class Block(EmipModule):
             # column sums of the packed (rounded) weights: the output-side form of the folded LayerNorm (emip_gemm_lne)
             for k in ("q", "kv", "w1"):
                 out["s" + k] = out[k].float().sum(1).contiguous()
+            if sr > 1 and SRA_BLOCK and dt == torch.bfloat16 and ops.sra_block_eligible(a.dim, 121):
+                # emip_sra_block reads the q / proj weights in the order its MFMA accumulators have (bits 2, 3 of the row
+                # index swapped inside every 16; for proj also of the column index); the vectors stay in channel order
+                sw = ops.swap23(a.dim, wq.device)
+                out["qf"] = out["q"][sw].contiguous()
+                out["pf"] = f(wp).to(dt)[sw][:, sw].contiguous()
             if sr > 1:      # ... and per tap for the spatial-reduction conv (emip_conv8 with ln_stats): [sr*sr, C]
                 out["tsr"] = out["sr"].float().view(out["sr"].shape[0], sr * sr, -1).sum(2).t().contiguous()
             return out
@@ -263,7 +271,15 @@ class Block(EmipModule):
         st_sr, st1, st2 = buf[o:o + 2 * Ms], buf[o + 2 * Ms:o + 2 * Ms + 2 * M], buf[o + 2 * Ms + 2 * M:]
         use_conv8 = sr > 1 and SR_CONV8 and dt == torch.bfloat16 and LN_EPILOGUE and ops.gemm8_enabled() and not _splitk_sr(sr)
         use_pair = sr > 1 and PAIR_Q_SR and not _splitk_sr(sr) and not use_conv8
-        if use_conv8:
+        use_block = SRA_BLOCK and use_conv8 and "qf" in w and ops.sra_block_eligible(C, (H // sr) * (W // sr))
+        if use_block:
+            # spatial-reduction conv -> kv, then q projection + attention + proj + residual in ONE launch (emip_sra_block)
+            s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
+                          out_stats=st_sr)
+            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"])
+            ops.sra_block(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), w["pf"], w["bp"], heads,
+                          a.scale, out_stats=st1)
+        elif use_conv8:
             # both on the 8-wave LDS-DMA body with the LayerNorm on the output side: q over the raw tokens (column sums),
             # the spatial-reduction conv over the raw patches (per-tap sums; the statistics ride the operand ring)
             q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["sq"])
@@ -306,14 +322,17 @@ class Block(EmipModule):
             s = x
             kv = ops.gemm(x, w["kv"], bias=w["bkv"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["skv"] if LN_EPILOGUE else None)
         Lk = s.shape[1] * s.shape[2]
-        att = torch.empty((B, H, W, C), dtype=dt, device=x.device)
-        if dt == torch.bfloat16 and Lk <= 128 and SRA_KERNEL:
+        att = None if use_block else torch.empty((B, H, W, C), dtype=dt, device=x.device)
+        if use_block:
+            pass
+        elif dt == torch.bfloat16 and Lk <= 128 and SRA_KERNEL:
             ops.sra_attention(q, kv, att, B, heads, N, Lk, a.scale)      # keys resident in registers, queries streamed
         else:
             ops.attention(q, kv, kv[..., C:], att, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
                           k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
                           k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
-        ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)                          # x += proj(attn)
+        if not use_block:
+            ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)                      # x += proj(attn)
         hid = w["w1"].shape[0]
         if MLP_FC1DW and dt == torch.bfloat16 and LN_EPILOGUE and ops.mlp_fc1dw_eligible(B, H, W, C, hid):
             # fc1 + depthwise 3x3 + GELU in one launch, one whole image per workgroup: the fc1 output never leaves the CU

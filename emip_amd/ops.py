@@ -449,6 +449,31 @@ def sra_attention_bwd(q, kv, out, dout, L, batch, heads, Lq, Lk, scale):
     return dq, dkv
 
 
+def sra_block_eligible(C, Lk):
+    return bool(_lib.load().emip_sra_block_eligible(C, Lk))
+
+
+def swap23(n, device=None):
+    """index permutation of the emip_sra_block weight packs: bits 2 and 3 swapped inside every 16 (an involution)"""
+    i = torch.arange(n, device=device)
+    return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1)
+
+
+def sra_block(x, stats, eps, wq, bq, colsum_q, kv, wp, bp, heads, scale, out_stats=None):
+    """x <- x + proj(softmax((LN(x) wq^T) k^T scale) v), in place, one launch (bf16).  x [B,H,W,C] raw tokens with their row
+    statistics stats [B*H*W, 2]; wq = (W_q gamma)[swap23] with bq / colsum_q in channel order, kv [B,Lk,2C], wp =
+    W_proj[swap23][:, swap23]; out_stats [B*H*W, 2] receives the statistics of the new rows"""
+    B, H, W, C = x.shape
+    M, _, ldx = rows(x)
+    Lk = kv.shape[1]
+    assert x.dtype == wq.dtype == wp.dtype == kv.dtype == torch.bfloat16 and C == heads * 64
+    assert wq.is_contiguous() and wp.is_contiguous() and kv.is_contiguous() and kv.shape == (B, Lk, 2 * C)
+    assert wq.shape == wp.shape == (C, C)
+    _lib.call("emip_sra_block", _p(x), ldx, _p(stats), float(eps), _p(wq), _p(bq), _p(colsum_q), _p(kv), _p(wp), _p(bp),
+              _p(x), ldx, _p(out_stats), B, H * W, Lk, C, float(scale), _stream())
+    return x
+
+
 def mdta_attn(q, kv_k, temperature, B, heads, P):
     """q [B,P,ldq] view, kv_k [B,P,ldk] view (the k half) -> attn [B,heads,64,64]."""
     _dev(q)

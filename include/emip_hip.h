@@ -127,6 +127,19 @@ int emip_sra_attention_lse(const void* Q, const void* KV, void* O, float* L, int
 int emip_sra_attention_bwd(const void* Q, const void* KV, const void* O, const void* dO, const float* L, void* dQ, float* dKV,
                            int batch, int heads, int Lq, int Lk, int C, float scale, void* stream);
 
+/* The attention half of a PVTv2 block in one launch (bf16 inference; lib/pvt_v2.py:95-127 Attention.forward with sr_ratio > 1
+ * and the residual add of Block.forward, :165-168):  Out = X + proj(softmax((LN(X) Wq^T) k^T scale) v).
+ * X / Out [B*N, ld] tokens (Out may alias X), stats [B*N, 2] = (sum, sum of squares) of the rows of X (norm1 is applied on
+ * the output side of the q projection: Wq carries gamma, bq = bias + Wq beta, colsum_q = row sums of the packed Wq), KV
+ * [B, Lk, 2C] as the kv Linear leaves it, Lk <= 128, C = 64 heads in {64, 128, 320}.  Wq has bits 2 and 3 of its ROW index
+ * swapped inside every 16 rows, Wp of its row AND column index (emip_amd/lib/pvt_v2.py Block._folded builds both); the
+ * vectors stay in channel order.  out_stats (may be null) receives the row sums / sums of squares of Out (stored).
+ * Replaces three launches (q GEMM, emip_sra_attention, proj GEMM): Q, the scores and the attention output stay on the CU. */
+int emip_sra_block_eligible(int C, int Lk);
+int emip_sra_block(const void* X, long ldx, const float* stats, float eps, const void* Wq, const float* bq,
+                   const float* colsum_q, const void* KV, const void* Wp, const float* bp, void* Out, long ldo,
+                   float* out_stats, int B, int N, int Lk, int C, float scale, void* stream);
+
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
 int emip_gemm_tile(long M, long N, long batch, long K);
 
