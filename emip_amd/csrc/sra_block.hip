@@ -420,6 +420,224 @@ __global__ __launch_bounds__(256) void sra_block_kernel(const SbArgs p) {
     }
 }
 
+// ---- q projection + attention of ONE head per workgroup (the 22 x 22 stage) ------------------------------------------------
+// With C = 320 the kernel above leaves three quarters of the SIMDs idle (16 images x 484 tokens are 242 blocks of 32 queries)
+// and every wave walks 20 weight tiles and 5 heads on its own: 42 us against 31 for the three launches.  Here the grid is
+// (image, 128 queries, HEAD): a wave computes the 64 channels of its head's Q (two weight tiles, both resident: no ring) and
+// runs the head -- the work of emip_sra_attention plus 40 MFMAs per wave, without Q ever reaching memory.  The attention
+// output goes out as bf16 rows; the proj GEMM (residual, statistics) stays the launch it was.
+template <int C>
+__global__ __launch_bounds__(256) void sra_q_kernel(const SbArgs p) {
+    typedef SbCfg<C> G;
+    constexpr int KS = G::KS, HEADS = G::HEADS, CH = G::CH, SB = G::SB, PPW = G::PPW, SLOT = G::SLOT;
+    constexpr int OFF_K = 2 * SLOT, OFF_V = OFF_K + 16384;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lq = lane & 31, h = lane >> 5, srow = lane >> 3, sch = lane & 7;
+    const int per = p.tpi * HEADS;
+    int img, r;
+    if (p.xcd_map) {
+        const int j = blockIdx.x >> 3;
+        r = j % per;
+        img = (blockIdx.x & 7) + 8 * (j / per);
+    } else {
+        r = blockIdx.x % per;
+        img = blockIdx.x / per;
+    }
+    const int hd = r % HEADS, qt = r / HEADS;
+    const long rowbase = (long)img * p.N;
+    const int q0 = qt * 128 + wave * 32;
+
+    const i32x4 rsQ = sb_rsrc(p.Wq, (unsigned)(C * C * 2));
+    const i32x4 rsKV = sb_rsrc(p.KV + (long)img * p.Lk * 2 * C, (unsigned)(p.Lk * 4 * C));
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
+
+    float rs, mrs;
+    {
+        const float2 s2 = *reinterpret_cast<const float2*>(p.stats + 2 * (rowbase + min(q0 + lq, p.N - 1)));
+        const float mu = s2.x * (1.f / (float)C);
+        rs = rsqrtf(fmaxf(s2.y * (1.f / (float)C) - mu * mu, 0.f) + p.eps);
+        mrs = mu * rs;
+    }
+    // register 4 g + j of tile tt = head channel 32 tt + 16 (g >> 1) + 8 h + 4 (g & 1) + j
+    float4 bqv[2][4], csv[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 64 * hd + 32 * tt + 16 * (g >> 1) + 8 * h + 4 * (g & 1);
+            bqv[tt][g] = *reinterpret_cast<const float4*>(p.bq + d0);
+            csv[tt][g] = *reinterpret_cast<const float4*>(p.csq + d0);
+        }
+    u32x4 xs[CH][4];
+#pragma unroll
+    for (int cc = 0; cc < CH; ++cc)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const long rr = rowbase + min(q0 + srow + 8 * j, p.N - 1);
+            xs[cc][j] = *reinterpret_cast<const u32x4*>(p.X + rr * p.ldx + 64 * cc + 8 * sch);
+        }
+    // K tile and the head's two weight tiles by LDS-DMA (V follows once the staging windows, which lie in its place, are done)
+    const unsigned kvso = (unsigned)(hd * 128);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = 8 * (wave + 4 * k) + srow;
+        sb_dma16(lds0 + OFF_K + (wave + 4 * k) * 1024, row < p.Lk ? (unsigned)(row * 4 * C + 16 * (sch ^ (row & 7))) : SB_OOB, rsKV,
+                 kvso);
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int k = 0; k < PPW; ++k) {
+            const int P = 1024 * (wave + 4 * k) + 16 * lane;
+            const int row = P / SB, within = P - row * SB;
+            sb_dma16(lds0 + tt * SLOT + (wave + 4 * k) * 1024,
+                     (row < 32 && within < 2 * C) ? (unsigned)(row * 2 * C + within) : SB_OOB, rsQ,
+                     (unsigned)((2 * hd + tt) * 32 * 2 * C));
+        }
+    u32x4 xf[KS];
+    {
+        char* win = smem + OFF_V + wave * 4096;
+#pragma unroll
+        for (int cc = 0; cc < CH; ++cc) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(win + sb_r128(srow + 8 * j, sch)) = xs[cc][j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) xf[4 * cc + i] = *reinterpret_cast<const u32x4*>(win + sb_r128(lq, 2 * i + h));
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // every wave has its token fragments: the V tile may land
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = 8 * (wave + 4 * k) + srow;
+        sb_dma16(lds0 + OFF_V + (wave + 4 * k) * 1024,
+                 row < p.Lk ? (unsigned)(row * 4 * C + 2 * C + 16 * (sch ^ (((row >> 1) & 1) << 2))) : SB_OOB, rsKV, kvso);
+    }
+    sb_wait<4>();                                         // all but the V pieces
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- Q^T of the head: two tiles ---------------------------------------------------------------------------------------
+    bf16x8 qf[4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const char* sa = smem + tt * SLOT + lq * SB + 16 * h;
+        f32x16 a0, a1;
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) a0[r16] = a1[r16] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KS; i += 2) {
+            a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + 32 * i)),
+                                                         __builtin_bit_cast(bf16x8, xf[i]), a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(sa + 32 * i + 32)),
+                                                         __builtin_bit_cast(bf16x8, xf[i + 1]), a1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float bb[4] = {bqv[tt][g].x, bqv[tt][g].y, bqv[tt][g].z, bqv[tt][g].w};
+            const float cs[4] = {csv[tt][g].x, csv[tt][g].y, csv[tt][g].z, csv[tt][g].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                qf[2 * tt + (g >> 1)][4 * (g & 1) + j] = (bf16_t)fmaf(a0[4 * g + j] + a1[4 * g + j], rs, fmaf(-mrs, cs[j], bb[j]));
+        }
+    }
+
+    // ---- the head: S^T = K Q^T, one-pass softmax, O^T = V^T P ---------------------------------------------------------------
+    const float sc2 = p.scale * 1.4426950408889634f;
+    const int i16 = lane & 15, g16 = (lane >> 4) & 1;
+    const char* kt_ = smem + OFF_K;
+    const char* vt_ = smem + OFF_V;
+    f32x16 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) s[kt][r16] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(kt_ + sb_r128(32 * kt + lq, 2 * i + h))), qf[i], s[kt], 0, 0, 0);
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+        const bool edge = 32 * kt + 31 >= p.Lk;
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) {
+            float v = s[kt][r16] * sc2;
+            if (edge && 32 * kt + 8 * (r16 >> 2) + 4 * h + (r16 & 3) >= p.Lk) v = -INFINITY;
+            s[kt][r16] = v;
+            mx = fmaxf(mx, v);
+        }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float psum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) {
+            const float e = __builtin_amdgcn_exp2f(s[kt][r16] - mx);
+            s[kt][r16] = e;
+            psum += e;
+        }
+    psum += __shfl_xor(psum, 32);
+    sb_wait<0>();                                         // the V tile
+    __builtin_amdgcn_s_barrier();                          // ... of every wave; and every wave has left the weight tiles
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 oacc[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int r16 = 0; r16 < 16; ++r16) oacc[d][r16] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+        for (int sp = 0; sp < 2; ++sp) {
+            bf16x8 pf;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)s[kt][8 * sp + j];
+            const int base0 = 32 * kt + 16 * sp + 4 * h + (i16 >> 2);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const int col = 32 * d + 16 * g16 + 4 * (i16 & 3);
+                const int c = col >> 3, half = (col >> 2) & 1;
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt_ + sb_v128(base0, c) + 8 * half));
+                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vt_ + sb_v128(base0 + 8, c) + 8 * half));
+                bf16x8 vf;
+                const bf16x4 b0 = __builtin_bit_cast(bf16x4, v0), b1 = __builtin_bit_cast(bf16x4, v1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    vf[j] = b0[j];
+                    vf[4 + j] = b1[j];
+                }
+                oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[d], 0, 0, 0);
+            }
+        }
+    }
+    // ---- normalise, pack, through the wave's staging image (in the first weight tile's place), whole 128-byte rows out ------
+    char* st_ = smem + wave * 4096;
+    const float inv = 1.0f / psum;
+#pragma unroll
+    for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {     // registers 4 g .. 4 g + 3 = channels 32 d + 8 g + 4 h + (0..3) of query lq
+            bf16x4 t;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = (bf16_t)(oacc[d][4 * g + j] * inv);
+            *reinterpret_cast<uint2*>(st_ + sb_r128(lq, 4 * d + g) + 8 * h) = __builtin_bit_cast(uint2, t);
+        }
+    bf16_t* Op = p.Out + rowbase * p.ldo + hd * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = q0 + srow + 8 * j;
+        const uint4 v = *reinterpret_cast<const uint4*>(st_ + sb_r128(srow + 8 * j, sch));
+        if (q < p.N) *reinterpret_cast<uint4*>(Op + (long)q * p.ldo + sch * 8) = v;
+    }
+}
+
 template <int C>
 int sb_launch(const SbArgs& a, hipStream_t stream) {
     static bool attr = false;
@@ -434,6 +652,30 @@ int sb_launch(const SbArgs& a, hipStream_t stream) {
 }
 
 }  // namespace
+
+// O = softmax((LN(X) Wq^T) k^T scale) v, the q projection computed on the fly (one head per workgroup); Wq is the row-swapped
+// pack of emip_sra_block.  O [B*N, ldo] must not alias X.
+extern "C" int emip_sra_qattn(const void* X, long ldx, const float* stats, float eps, const void* Wq, const float* bq,
+                              const float* colsum_q, const void* KV, void* O, long ldo, int B, int N, int Lk, int C, float scale,
+                              void* stream) {
+    EMIP_REQUIRE(X && stats && Wq && bq && colsum_q && KV && O && O != X && B > 0 && N > 0);
+    EMIP_REQUIRE(C == 320 && Lk > 0 && Lk <= 128 && ldx >= C && (ldx & 7) == 0 && ldo >= C && (ldo & 7) == 0);
+    EMIP_REQUIRE(aligned16(X) && aligned16(Wq) && aligned16(KV) && aligned16(O) && aligned16(bq) && aligned16(colsum_q) &&
+                 (reinterpret_cast<uintptr_t>(stats) & 7u) == 0);
+    SbArgs a{};
+    a.X = (const bf16_t*)X; a.Out = (bf16_t*)O; a.stats = stats; a.Wq = (const bf16_t*)Wq; a.bq = bq; a.csq = colsum_q;
+    a.KV = (const bf16_t*)KV; a.ldx = ldx; a.ldo = ldo; a.B = B; a.N = N; a.Lk = Lk; a.tpi = (N + 127) / 128;
+    a.xcd_map = (B % 8) == 0; a.eps = eps; a.scale = scale;
+    constexpr int LDS = 2 * SbCfg<320>::SLOT + 32768;
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
+        if (hipFuncSetAttribute((const void*)sra_q_kernel<320>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess)
+            return EMIP_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(sra_q_kernel<320>, dim3((unsigned)(B * a.tpi * 5)), dim3(256), LDS, (hipStream_t)stream, a);
+    return emip_launch_status();
+}
 
 extern "C" int emip_sra_block_eligible(int C, int Lk) { return (C == 64 || C == 128 || C == 320) && Lk > 0 && Lk <= 128; }
 

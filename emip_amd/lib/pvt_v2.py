@@ -61,6 +61,7 @@ _lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
 MLP_FC1DW = os.environ.get("EMIP_MLP_FC1DW", "1") != "0"
 # q projection + spatial-reduction attention + proj + residual of the inference block in one launch (emip_sra_block)
 SRA_BLOCK = os.environ.get("EMIP_SRA_BLOCK", "1") != "0"
+SRA_BLOCK_MAXC = int(os.environ.get("EMIP_SRA_BLOCK_MAXC", "128"))      # wider stages: emip_sra_qattn + the proj GEMM
 
 
 class DWConv(EmipModule):
@@ -277,8 +278,12 @@ class Block(EmipModule):
             s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
                           out_stats=st_sr)
             kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"])
-            ops.sra_block(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), w["pf"], w["bp"], heads,
-                          a.scale, out_stats=st1)
+            if C <= SRA_BLOCK_MAXC:
+                ops.sra_block(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), w["pf"], w["bp"], heads,
+                              a.scale, out_stats=st1)
+            else:       # too few 128-query workgroups at C = 320: q + attention per (image, queries, head), proj as it was
+                att = ops.sra_qattn(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), heads, a.scale)
+                ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)
         elif use_conv8:
             # both on the 8-wave LDS-DMA body with the LayerNorm on the output side: q over the raw tokens (column sums),
             # the spatial-reduction conv over the raw patches (per-tap sums; the statistics ride the operand ring)

@@ -474,6 +474,20 @@ def sra_block(x, stats, eps, wq, bq, colsum_q, kv, wp, bp, heads, scale, out_sta
     return x
 
 
+def sra_qattn(x, stats, eps, wq, bq, colsum_q, kv, heads, scale):
+    """softmax((LN(x) wq^T) k^T scale) v -> [B,H,W,C] bf16 with the q projection computed inside the attention launch (one head
+    per workgroup; C = 320).  wq = (W_q gamma)[swap23]"""
+    B, H, W, C = x.shape
+    M, _, ldx = rows(x)
+    Lk = kv.shape[1]
+    assert x.dtype == wq.dtype == kv.dtype == torch.bfloat16 and C == heads * 64 and wq.shape == (C, C)
+    assert wq.is_contiguous() and kv.is_contiguous() and kv.shape == (B, Lk, 2 * C)
+    out = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    _lib.call("emip_sra_qattn", _p(x), ldx, _p(stats), float(eps), _p(wq), _p(bq), _p(colsum_q), _p(kv), _p(out), C, B, H * W, Lk,
+              C, float(scale), _stream())
+    return out
+
+
 def mdta_attn(q, kv_k, temperature, B, heads, P):
     """q [B,P,ldq] view, kv_k [B,P,ldk] view (the k half) -> attn [B,heads,64,64]."""
     _dev(q)

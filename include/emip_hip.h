@@ -140,6 +140,13 @@ int emip_sra_block(const void* X, long ldx, const float* stats, float eps, const
                    const float* colsum_q, const void* KV, const void* Wp, const float* bp, void* Out, long ldo,
                    float* out_stats, int B, int N, int Lk, int C, float scale, void* stream);
 
+/* The q projection and the attention of emip_sra_block without the proj half, one HEAD per workgroup (C = 320, the 22 x 22
+ * stage, where emip_sra_block has too few workgroups): O = softmax((LN(X) Wq^T) k^T scale) v, bf16 [B*N, ldo]; Q never reaches
+ * memory.  Arguments as emip_sra_block; O must not alias X. */
+int emip_sra_qattn(const void* X, long ldx, const float* stats, float eps, const void* Wq, const float* bq,
+                   const float* colsum_q, const void* KV, void* O, long ldo, int B, int N, int Lk, int C, float scale,
+                   void* stream);
+
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
 int emip_gemm_tile(long M, long N, long batch, long K);
 

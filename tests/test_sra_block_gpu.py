@@ -77,6 +77,32 @@ def test_sra_block_matches_reference_and_the_three_launches(B, H, W, C, Lk):
     assert torch.allclose(st_new, want, rtol=2e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,W,Lk", [(4, 22, 22, 121), (16, 22, 22, 121), (3, 10, 10, 25), (1, 1, 1, 128), (2, 13, 11, 77)])
+def test_sra_qattn_matches_reference_and_the_two_launches(B, H, W, Lk):
+    """emip_sra_qattn (q projection inside the attention launch, one head per workgroup, C = 320) against the f32 restatement
+    and against emip_gemm8 (output-side LayerNorm) + emip_sra_attention"""
+    from emip_amd import ops
+    C, heads, scale = 320, 5, 0.125
+    x, kv, wq, wp, bq, bp, stats = _make(B, H, W, C, Lk, H + Lk)
+    csq = wq.float().sum(1).contiguous()
+    q = ops.gemm(x, wq, bias=bq, ln_stats=stats, ln_eps=EPS, colsum=csq)
+    old = torch.empty_like(x)
+    ops.sra_attention(q.view(B, H * W, C), kv, old.view(B, H * W, C), B, heads, H * W, Lk, scale)
+    got = ops.sra_qattn(x, stats, EPS, wq[ops.swap23(C, x.device)].contiguous(), bq, csq, kv, heads, scale)
+    torch.cuda.synchronize()
+    xf = x.float().view(B, H * W, C)
+    mu = xf.mean(-1, keepdim=True)
+    xh = (xf - mu) * torch.rsqrt(((xf * xf).mean(-1, keepdim=True) - mu * mu).clamp_min(0) + EPS)
+    qr = (xh @ wq.float().t() + bq).to(torch.bfloat16).float().view(B, H * W, heads, 64).permute(0, 2, 1, 3)
+    k = kv.float()[..., :C].reshape(B, Lk, heads, 64).permute(0, 2, 1, 3)
+    v = kv.float()[..., C:].reshape(B, Lk, heads, 64).permute(0, 2, 1, 3)
+    ref = (torch.softmax(qr @ k.transpose(-1, -2) * scale, -1) @ v).permute(0, 2, 1, 3).reshape(B, H, W, C)
+    top = max(1.0, ref.abs().max().item())
+    e_new, e_old = (got.float() - ref).abs(), (old.float() - ref).abs()
+    assert e_new.max().item() < 3e-2 * top
+    assert e_new.mean().item() <= 1.1 * e_old.mean().item() + 1e-4 * top
+
+
 def test_sra_block_writes_nothing_beyond_its_rows_and_strided_rows():
     """rows of a wider buffer (ldx > C): the columns beside them and the rows behind them stay untouched"""
     from emip_amd import ops
@@ -119,7 +145,7 @@ def test_pvt_block_fused_path_uses_it_and_matches_the_unfused_launches():
             _lib.profile(None)
             torch.cuda.synchronize()
             names = [r[0] for r in rec]
-            assert ("emip_sra_block" in names) == flag, names
+            assert ("emip_sra_qattn" in names) == flag and ("emip_sra_attention" in names) != flag, names
             outs.append((y.float().clone(), st.clone()))
         finally:
             pvt_v2.SRA_BLOCK = True
