@@ -39,8 +39,8 @@ def _g8_key(lib, cfg, conv, lnt):
     t = lib.emip_gemm8_cfg_tile(cfg)
     bm, bn = t // 1000, t % 1000
     wm, wn = WAVES[(bm, bn)]
-    return "gemm8_kernel<%d, %d, %d, %d, %d, %s, %s>" % (bm, bn, wm, wn, lib.emip_gemm8_cfg_stages(cfg, 1 if lnt else 0),
-                                                          "true" if conv else "false", "true" if lnt else "false")
+    return "gemm8_kernel<%d, %d, %d, %d, %d, %s, %s, false>" % (bm, bn, wm, wn, lib.emip_gemm8_cfg_stages(cfg, 1 if lnt else 0),
+                                                                 "true" if conv else "false", "true" if lnt else "false")
 
 
 def _launch_info(lib, name, a):
@@ -50,6 +50,16 @@ def _launch_info(lib, name, a):
         batch, heads, Lq, Lk = a[3], a[4], a[5], a[6]
         z = batch * heads
         return 4.0 * z * Lq * Lk * 64, "sra_kernel", 2.0 * z * (2 * Lq * 64 + 2 * Lk * 64)
+    if name == "emip_sra_qattn":          # (X, ldx, stats, eps, Wq, bq, csq, KV, O, ldo, B, N, Lk, C, scale, stream)
+        Bm, N, Lk, C = a[10], a[11], a[12], a[13]
+        M = Bm * N
+        # q projection + attention of all heads; tokens in, Wq and the k / v rows once, attention output out (Q stays on the CU)
+        return 2.0 * M * C * C + 4.0 * M * Lk * C, "sra_q_kernel", 2.0 * (2 * M * C + C * C + Bm * Lk * 2 * C) + 8.0 * M
+    if name == "emip_sra_block":          # (X, ldx, stats, eps, Wq, bq, csq, KV, Wp, bp, Out, ldo, out_stats, B, N, Lk, C, scale, stream)
+        Bm, N, Lk, C = a[13], a[14], a[15], a[16]
+        M = Bm * N
+        # q projection + attention + proj + residual: tokens in and out, both weight matrices and the k / v rows once
+        return 4.0 * M * C * C + 4.0 * M * Lk * C, "sra_block_kernel", 2.0 * (2 * M * C + 2 * C * C + Bm * Lk * 2 * C) + 16.0 * M
     if name == "emip_mlp_fc1dw":          # (X, ldx, W1, b1, colsum, ln_stats, eps, Wdw, bd, G, ldg, B, H, W, K, N, stream)
         Bm, H, W, K, N = a[11], a[12], a[13], a[14], a[15]
         M = Bm * H * W
@@ -136,7 +146,7 @@ def kernel_breakdown(net, im1, im2, splits=1):
     return agg
 
 
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r02b_bench_kernel_stats.csv")
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r02c_bench_kernel_stats.csv")
 
 
 def rocprof_avg(key):
@@ -596,8 +606,14 @@ def main():
                          "same_kernel_unsplit_batch_TFLOPs": (round(whole[1] / (whole[0] * 1e-3) / 1e12, 2)
                                                               if whole else None)})
         out["roofline_named"] = {
-            "sra": named_roofline(agg, "sra_kernel",
-                                  "PVTv2 spatial-reduction attention softmax(q k^T / 8) v, lib/pvt_v2.py:113-125"),
+            "sra": named_roofline(agg, "sra_q_kernel",
+                                  "PVTv2 spatial-reduction attention of the 22x22 stage with its q projection, "
+                                  "softmax((LN(x) Wq^T) k^T / 8) v, lib/pvt_v2.py:95-125 (emip_sra_qattn)"),
+            "sra_block": named_roofline(agg, "sra_block_kernel",
+                                        "the same with proj and the residual add in the launch (88x88 and 44x44 stages), "
+                                        "lib/pvt_v2.py:95-127,165-168 (emip_sra_block)"),
+            "sra_attention_only": named_roofline(agg, "sra_kernel",
+                                                 "softmax(q k^T / 8) v alone (the 11x11 stage, sr_ratio 1), lib/pvt_v2.py:113-125"),
             "correlation": named_roofline(agg, "attn_kernel<bf16,128,32,64>+scores",
                                           "GMFlow all-pairs correlation + softmax expectation, raw correlation "
                                           "written once as [src][tgt], gmflow/matching.py:13-41")}

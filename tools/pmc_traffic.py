@@ -18,8 +18,9 @@ def bench_key(name):
     m = re.search(r"(gemm8_kernel<[^>]*>)", name)          # demangled template instance: exactly bench.py's key
     if m:
         return m.group(1)
-    if "sra_kernel" in name:
-        return "sra_kernel"
+    for k in ("sra_q_kernel", "sra_block_kernel", "sra_kernel"):
+        if k in name:
+            return k
     m = re.search(r"gemm_kernelI(DF16b|f)Li(\d+)ELi(\d+)ELb([01])ELi(\d+)ELb([01])EE", name)
     if m:
         return "gemm_kernel<%s,%s,%s,%s>" % ("bf16" if m.group(1) == "DF16b" else "f32", m.group(2), m.group(3),
