@@ -672,6 +672,69 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ X
     }
 }
 
+// The same for bf16 rows read 16 bytes per lane with four rows in flight per thread: the form above (8-byte loads, one
+// dependent row after the other) streamed the GMFlow encoder's 63-MB feature maps at 1.2-1.5 TB/s.
+__global__ __launch_bounds__(256) void chan_stats_wide_kernel(const bf16_t* __restrict__ X, long ldx, double* __restrict__ sums,
+                                                              long rows, int C, int rows_per_block) {
+    __shared__ float red[256 * 16];
+    const int nv = C >> 3;
+    const int plan = 256 / nv;  // row lanes
+    const int vi = threadIdx.x % nv, rl = threadIdx.x / nv;
+    const long g = blockIdx.y;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    float s[8], q[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+    if (rl < plan) {
+        const bf16_t* base = X + g * rows * ldx + vi * 8;
+        long r = r0 + rl;
+        for (; r + 3L * plan < r1; r += 4L * plan) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const uint4*>(base + (r + (long)u * plan) * ldx);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float a = __uint_as_float(w[k] << 16), b = __uint_as_float(w[k] & 0xFFFF0000u);
+                    s[2 * k] += a;
+                    q[2 * k] = fmaf(a, a, q[2 * k]);
+                    s[2 * k + 1] += b;
+                    q[2 * k + 1] = fmaf(b, b, q[2 * k + 1]);
+                }
+            }
+        }
+        for (; r < r1; r += plan) {
+            const uint4 v = *reinterpret_cast<const uint4*>(base + r * ldx);
+            const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float a = __uint_as_float(w[k] << 16), b = __uint_as_float(w[k] & 0xFFFF0000u);
+                s[2 * k] += a;
+                q[2 * k] = fmaf(a, a, q[2 * k]);
+                s[2 * k + 1] += b;
+                q[2 * k + 1] = fmaf(b, b, q[2 * k + 1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[threadIdx.x * 16 + j] = s[j];
+        red[threadIdx.x * 16 + 8 + j] = q[j];
+    }
+    __syncthreads();
+    // one (channel, statistic) pair per thread: 2 C <= 256 sums over the row lanes, then one f64 atomic each
+    if ((int)threadIdx.x < 2 * C) {
+        const int c = threadIdx.x >> 1, which = threadIdx.x & 1;
+        const int slot = (c >> 3) * 16 + which * 8 + (c & 7);
+        float t = 0.f;
+        for (int l = 0; l < plan; ++l) t += red[l * nv * 16 + slot];
+        atomicAdd(sums + (g * C + c) * 2 + which, (double)t);
+    }
+}
+
 // y = [relu]( R + [relu]( (x - mean) * rstd * gamma + beta ) ), statistics from chan_stats_kernel.
 template <typename T>
 __global__ __launch_bounds__(256) void chan_norm_apply_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y,
@@ -1155,6 +1218,10 @@ extern "C" int emip_chan_stats(const void* X, long ldx, double* sums, long group
     if (!prezeroed && emip_zero_async(sums, sizeof(double) * 2 * groups * C, s) != EMIP_OK) return EMIP_E_LAUNCH;
     const int rpb = 512;
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)groups);
+    if (dtype == EMIP_BF16 && (C & 7) == 0 && C <= 128 && (ldx & 7) == 0 && aligned16(X)) {
+        hipLaunchKernelGGL(chan_stats_wide_kernel, grid, dim3(256), 0, s, (const bf16_t*)X, ldx, sums, rows, C, rpb);
+        return emip_launch_status();
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(chan_stats_kernel<T>, grid, dim3(256), 0, s, (const T*)X, ldx, sums, rows, C,
                                          rpb));
     return emip_launch_status();
