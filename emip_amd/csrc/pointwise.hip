@@ -958,6 +958,19 @@ __global__ __launch_bounds__(256) void planar_to_cl_kernel(const float* __restri
     }
 }
 
+// ... for images (C <= 8 planes -> 8 bf16 channels): one pixel per thread, plane reads and 16-byte row writes both coalesced
+// (the 32 x 32 transpose above uses 3 of its 32 tile rows on an RGB frame and writes 2 bytes per lane)
+__global__ __launch_bounds__(256) void planar_to_cl8_kernel(const float* __restrict__ X, bf16_t* __restrict__ Y, int B, int C, long P) {
+    const long total = (long)B * P;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / P, p = i - b * P;
+        bf16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o[c] = (bf16_t)(c < C ? X[(b * C + c) * P + p] : 0.f);
+        *reinterpret_cast<bf16x8*>(Y + i * 8) = o;
+    }
+}
+
 // channels-last T [B][P][ldx] (channels xc..xc+C-1)  ->  planar f32 [B][C][P]
 template <typename T>
 __global__ __launch_bounds__(256) void cl_to_planar_kernel(const T* __restrict__ X, long ldx, int xc,
@@ -1298,6 +1311,11 @@ extern "C" int emip_planar_to_cl(const float* X, void* Y, long ldy, int B, int C
     EMIP_REQUIRE(X && Y && B > 0 && B < 65536 && C > 0 && P > 0 && Cpad >= C && ldy >= Cpad);
     dim3 grid((unsigned)((P + 31) / 32), (unsigned)((Cpad + 31) / 32), (unsigned)B);
     EMIP_REQUIRE(grid.y < 65536);
+    if (dtype == EMIP_BF16 && C <= 8 && Cpad == 8 && ldy == 8 && aligned16(Y)) {
+        hipLaunchKernelGGL(planar_to_cl8_kernel, dim3(grid_for((long)B * P, 256)), dim3(256), 0, (hipStream_t)stream, X,
+                           (bf16_t*)Y, B, C, P);
+        return emip_launch_status();
+    }
     DISPATCH_T(dtype, hipLaunchKernelGGL(planar_to_cl_kernel<T>, grid, dim3(256), 0, (hipStream_t)stream, X, (T*)Y,
                                          ldy, B, C, P, Cpad));
     return emip_launch_status();
