@@ -1232,7 +1232,11 @@ extern "C" int emip_chan_stats(const void* X, long ldx, double* sums, long group
     const int rpb = 512;
     dim3 grid((unsigned)((rows + rpb - 1) / rpb), (unsigned)groups);
     if (dtype == EMIP_BF16 && (C & 7) == 0 && C <= 128 && (ldx & 7) == 0 && aligned16(X)) {
-        hipLaunchKernelGGL(chan_stats_wide_kernel, grid, dim3(256), 0, s, (const bf16_t*)X, ldx, sums, rows, C, rpb);
+        // at least ~512 workgroups: the 44 x 44 maps (1936 rows x 16 images) had 64 of them with 512 rows each
+        int wrpb = 512;
+        while (wrpb > 64 && ((rows + wrpb - 1) / wrpb) * groups < 512) wrpb >>= 1;
+        hipLaunchKernelGGL(chan_stats_wide_kernel, dim3((unsigned)((rows + wrpb - 1) / wrpb), (unsigned)groups), dim3(256), 0, s,
+                           (const bf16_t*)X, ldx, sums, rows, C, wrpb);
         return emip_launch_status();
     }
     DISPATCH_T(dtype, hipLaunchKernelGGL(chan_stats_kernel<T>, grid, dim3(256), 0, s, (const T*)X, ldx, sums, rows, C,
