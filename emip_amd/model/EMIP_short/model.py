@@ -97,7 +97,12 @@ class CoUpdater(EmipModule):
         prompt injection / reductions / decoder and the flow predictions would be computed for nothing; returns (None, [])."""
         dt = self.cdtype
         B = image1.shape[0]
-        imgs = to_cl(torch.cat((image1, image2), 0), dt, 8)            # [2B,H,W,8]
+        if torch.is_grad_enabled() or image1.shape != image2.shape or image1.dtype != torch.float32:
+            imgs = to_cl(torch.cat((image1, image2), 0), dt, 8)        # [2B,H,W,8]
+        else:       # both frames straight into their halves of the channels-last batch (no concatenated f32 copy)
+            imgs = torch.empty((2 * B,) + tuple(image1.shape[2:]) + (8,), dtype=dt, device=image1.device)
+            ops.planar_to_cl(image1.contiguous(), dt, 8, out=imgs[:B])
+            ops.planar_to_cl(image2.contiguous(), dt, 8, out=imgs[B:])
         if FORK_CNN and not torch.is_grad_enabled() and imgs.is_cuda:
             # The GMFlow CNN encoder does not depend on the PVT backbone: run it on a side stream next to it (ONE fork / join
             # per forward -- also inside a captured hipGraph), so that the phases of one chain fill the idle ones of the other

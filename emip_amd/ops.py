@@ -601,13 +601,15 @@ def eltwise(a, b, mode, c3=None, period=0, out=None):
     return out
 
 
-def planar_to_cl(x, dtype, cpad=None):
-    """planar f32 [B,C,H,W] -> channels-last [B,H,W,cpad]"""
+def planar_to_cl(x, dtype, cpad=None, out=None):
+    """planar f32 [B,C,H,W] -> channels-last [B,H,W,cpad] (out: a contiguous [B,H,W,cpad] view to fill, e.g. half of a batch)"""
     _dev(x)
     B, C, H, W = x.shape
     assert x.dtype == torch.float32 and x.is_contiguous()
     cpad = cpad or C
-    out = torch.empty((B, H, W, cpad), dtype=dtype, device=x.device)
+    if out is None:
+        out = torch.empty((B, H, W, cpad), dtype=dtype, device=x.device)
+    assert out.shape == (B, H, W, cpad) and out.dtype == dtype and out.is_contiguous()
     _lib.call("emip_planar_to_cl", _p(x), _p(out), cpad, B, C, H * W, cpad, dt_code(dtype), _stream())
     return out
 
