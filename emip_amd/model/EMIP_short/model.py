@@ -27,6 +27,11 @@ import os as _os
 # 1007 -> 1029 pairs/s, two sub-batch graphs 1073 -> 1056: the two-graph replay already fills the idle phases, so it is off
 # by default (EMIP_FORK_CNN=1 turns it on)
 FORK_CNN = _os.environ.get("EMIP_FORK_CNN", "0") != "0"
+# Order of the two independent encoders at the head of the forward.  emip_amd.graph captures every second sub-batch graph
+# with the GMFlow CNN first (EMIP_STAGGER=0 turns that off): the concurrent streams then do not walk the same phases in
+# lockstep -- one is in the bandwidth-bound CNN while the other is in the PVT stages.
+CNN_FIRST = False
+STAGGER = _os.environ.get("EMIP_STAGGER", "1") != "0"
 
 class CoUpdater(EmipModule):
     def __init__(self, args=None):
@@ -114,6 +119,9 @@ class CoUpdater(EmipModule):
             fea = self.backbone.feat_net.run(imgs)                     # stages 2..4 of both frames
             cur.wait_stream(side)
             gm.record_stream(cur)
+        elif CNN_FIRST:
+            gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
+            fea = self.backbone.feat_net.run(imgs)
         else:
             fea = self.backbone.feat_net.run(imgs)                     # stages 2..4 of both frames
             gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
