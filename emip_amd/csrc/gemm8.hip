@@ -588,7 +588,7 @@ static int g8_enabled() {
 }
 namespace emip_internal {
 int gemm8_choice(int M, int N, long K, long lda, long ldw, int K1, bool has_a2, long lda2) {
-    if (!g8_enabled() || M < 2048 || N < 64 || (K % 64) != 0 || (lda % 8) != 0 || (ldw % 8) != 0) return 0;
+    if (!g8_enabled() || M < 1024 || N < 64 || (K % 64) != 0 || (lda % 8) != 0 || (ldw % 8) != 0) return 0;
     if (has_a2 && ((K1 % 64) != 0 || (lda2 % 8) != 0)) return 0;
     if (((long)(M - 1) * lda + K) * 2 >= (1L << 31) || ((long)(N - 1) * ldw + K) * 2 >= (1L << 31)) return 0;
     return pick_cfg(M, N, K);
