@@ -59,6 +59,9 @@ struct G8Args {
     float* out_stats;          // [M, 2]: accumulates (sum, sum of squares) of the stored rows
     const float* rowscale;     // [M / rs_rows] or null: act(...) of row m is multiplied by rowscale[m / rs_rows] BEFORE the
     int rs_rows;               // residual is added (stochastic depth: residual + scale[sample] * branch)
+    const float* lno_gamma;    // LNO instances: C = R + LayerNorm_over_N(A W^T + bias) * gamma + beta, one output tile per row
+    const float* lno_beta;     // block (N <= BN): post-norm Linear layers (GMFlow transformer.py:87-113: merge -> norm1, mlp -> norm2)
+    float lno_eps;
     unsigned* zero_ptr;
     long zero_words;
     int H, Wd, Cin, KH, KW, stride, pad, Ho, Wo;   // conv geometry (CONV instances)
@@ -102,7 +105,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // RS: the per-sample scale of the epilogue (emip_gemm8_rs) is its own instance -- compiled into every instance it cost the
 // inference step 1.2 % (1133 -> 1120 pairs/s in-call: one more live register per accumulator row in every epilogue)
-template <int BM, int BN, int WGM, int WGN, int NST, bool CONV, bool LNT = false, bool RS = false>
+// LNO: LayerNorm over the N columns of the output row in the epilogue (its own instances too): the waves of a tile row meet
+// through 2 KB of LDS behind the ring
+template <int BM, int BN, int WGM, int WGN, int NST, bool CONV, bool LNT = false, bool RS = false, bool LNO = false>
 __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;      // wave tile
     constexpr int TM = WTM / 16, TN = WTN / 16;        // 16x16 accumulators per wave
@@ -378,6 +383,54 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                 mrsv[a] = mu * rsv[a];
             }
         }
+        float lmean[TM], lrstd[TM];
+        if (LNO) {
+            // pass 1: sums of (acc + bias) and of its square over this wave's columns, the 4 lanes of a row, the WGN waves
+            static_assert(!LNO || (TN % 2 == 0), "LNO: paired column blocks only");
+            float* red = reinterpret_cast<float*>(smem + NST * STAGE);      // [BM][WGN][2]
+            float q1[TM], q2[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) q1[a] = q2[a] = 0.f;
+#pragma unroll
+            for (int pb = 0; pb < NPAIR; ++pb) {
+                const int n = nb + 32 * pb + 8 * fq;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const bool in = n + j < p.N;
+                    const float b = (p.bias && in) ? p.bias[n + j] : 0.f;
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const float x = in ? acc[a][2 * pb + (j >> 2)][j & 3] + b : 0.f;
+                        q1[a] += x;
+                        q2[a] = fmaf(x, x, q2[a]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                q1[a] += __shfl_xor(q1[a], 16);
+                q2[a] += __shfl_xor(q2[a], 16);
+                q1[a] += __shfl_xor(q1[a], 32);
+                q2[a] += __shfl_xor(q2[a], 32);
+                if (fq == 0) *reinterpret_cast<float2*>(red + ((wm * WTM + 16 * a + fr) * WGN + wn) * 2) = make_float2(q1[a], q2[a]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            const float invN = 1.f / (float)p.N;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WGN; ++w) {
+                    const float2 t = *reinterpret_cast<const float2*>(red + ((wm * WTM + 16 * a + fr) * WGN + w) * 2);
+                    t1 += t.x;
+                    t2 += t.y;
+                }
+                lmean[a] = t1 * invN;
+                lrstd[a] = rsqrtf(fmaxf(t2 * invN - lmean[a] * lmean[a], 0.f) + p.lno_eps);
+            }
+        }
 #pragma unroll
         for (int pb = 0; pb < NPAIR; ++pb) {
             const int n = nb + 32 * pb + 8 * fq;
@@ -403,6 +456,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                     if (gelu) x = gelu_t<bf16_t>(x);
                     else if (relu) x = fmaxf(x, 0.f);
                     v[j] = x;
+                }
+                if (LNO) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int nc = min(n + j, p.N - 1);
+                        v[j] = (v[j] - lmean[a]) * lrstd[a] * p.lno_gamma[nc] + p.lno_beta[nc];
+                    }
                 }
                 if (RS) {
 #pragma unroll
@@ -495,21 +555,26 @@ struct Cfg {
     void (*conv)(const G8Args);
     void (*lnt)(const G8Args);      // conv with the per-tap LayerNorm (small tiles only)
     void (*rs)(const G8Args);       // dense with the per-sample epilogue scale (emip_gemm8_rs)
+    void (*lno)(const G8Args);      // dense with the LayerNorm over the output row (emip_gemm8_lno; BN = 128 tiles only)
 };
 
 #define G8_CFG(BM, BN, WGM, WGN, NST)                                                                            \
     {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr, \
-     gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>}
+     gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>, nullptr}
+#define G8_CFG_LNO(BM, BN, WGM, WGN, NST)                                                                        \
+    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr, \
+     gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>, gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, false, true>}
 // the per-tap LayerNorm instances serve 31..183 workgroups walking 20..64 K tiles each: a 5-deep ring (4 tiles in flight)
 constexpr int NST_LNT = 5;
 #define G8_CFG_LNT(BM, BN, WGM, WGN, NST)                                                             \
     {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, \
-     gemm8_kernel<BM, BN, WGM, WGN, NST_LNT, true, true>, gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>}
+     gemm8_kernel<BM, BN, WGM, WGN, NST_LNT, true, true>, gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>, \
+     gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, false, true>}
 
 const Cfg g_cfg[] = {
     G8_CFG(256, 128, 4, 2, 3),       // 1: wave 64 x 64, 144 KB
     G8_CFG(128, 256, 2, 4, 3),       // 2: wave 64 x 64, 144 KB
-    G8_CFG(128, 128, 2, 4, 2),       // 3: wave 64 x 32, 64 KB (2 workgroups per CU)
+    G8_CFG_LNO(128, 128, 2, 4, 2),   // 3: wave 64 x 32, 64 KB (2 workgroups per CU)
     G8_CFG(128, 320, 2, 4, 2),       // 4: wave 64 x 80 (N = 320 in one tile), 112 KB
     G8_CFG(64, 320, 2, 4, 3),        // 5: wave 32 x 80, 144 KB
     G8_CFG(256, 64, 4, 2, 2),        // 6: wave 64 x 32, 80 KB (2 per CU)
@@ -547,9 +612,12 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     if (lds > 160 * 1024) return EMIP_E_INVALID;
     const bool rs = a.rowscale != nullptr;
     if (rs && (lnt || conv)) return EMIP_E_INVALID;
-    auto fn = rs ? g.rs : (lnt ? g.lnt : (conv ? g.conv : g.dense));
-    const int which = rs ? 3 : (lnt ? 2 : (conv ? 1 : 0));
-    static size_t attr_done[NCFG][4];
+    const bool lno = a.lno_gamma != nullptr;
+    if (lno && (rs || lnt || conv || !g.lno || a.tiles_n != 1 || a.act != EMIP_ACT_NONE)) return EMIP_E_INVALID;
+    if (lno) lds += (size_t)g.bm * 8 * 4;                      // [BM][WGN <= 4][2] f32 behind the ring
+    auto fn = lno ? g.lno : (rs ? g.rs : (lnt ? g.lnt : (conv ? g.conv : g.dense)));
+    const int which = lno ? 4 : (rs ? 3 : (lnt ? 2 : (conv ? 1 : 0)));
+    static size_t attr_done[NCFG][5];
     if (attr_done[cfg - 1][which] < lds) {
         if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return EMIP_E_LAUNCH;
@@ -631,6 +699,26 @@ extern "C" int emip_gemm8(const void* A, const void* A2, const void* W, void* C,
     a.out_stats = out_stats; a.zero_ptr = (unsigned*)zero_ptr; a.zero_words = zero_ptr ? zero_bytes / 4 : 0;
     a.a_bytes = (unsigned)ab; a.a2_bytes = (unsigned)a2b; a.w_bytes = (unsigned)wb;
     return launch(a, cfg, false, (hipStream_t)stream);
+}
+
+// C = R + LayerNorm(A W^T + bias) * gamma + beta, the normalisation over the N <= 128 output columns of a row in the epilogue
+// (post-norm Linear layers: GMFlow transformer.py:87-113 merge -> norm1 and mlp -> norm2, the residual of :113 as R)
+extern "C" int emip_gemm8_lno(const void* A, const void* W, void* C, const float* bias, const void* R, const float* gamma,
+                              const float* beta, float eps, int M, int N, int K, long lda, long ldw, long ldc, long ldr,
+                              void* stream) {
+    EMIP_REQUIRE(A && W && C && gamma && beta && M > 0 && N > 0 && N <= 128 && (N % 8) == 0 && K > 0 && (K % 64) == 0);
+    EMIP_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C) && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K &&
+                 ldc >= N && (ldc % 8) == 0);
+    EMIP_REQUIRE(!R || (aligned16(R) && ldr >= N && (ldr % 8) == 0));
+    const long ab = ((long)(M - 1) * lda + K) * 2, wb = ((long)(N - 1) * ldw + K) * 2;
+    EMIP_REQUIRE(ab < (1L << 31) && wb < (1L << 31));
+    G8Args a = {};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias; a.R = (const bf16_t*)R;
+    a.M = M; a.N = N; a.K = K; a.K1 = K; a.lda = lda; a.ldw = ldw; a.ldc = ldc; a.ldr = ldr; a.act = EMIP_ACT_NONE;
+    a.lno_gamma = gamma; a.lno_beta = beta; a.lno_eps = eps;
+    a.a_bytes = (unsigned)ab; a.w_bytes = (unsigned)wb;
+    // 64 x 128 tiles unless there are more than two 128-row tiles per CU
+    return launch(a, (long)((M + 127) / 128) >= 512 ? 3 : 9, false, (hipStream_t)stream);
 }
 
 // emip_gemm8 with a per-sample scale on the branch: C = R + rowscale[m / rs_rows] * act(A W^T + bias) -- stochastic depth

@@ -165,16 +165,13 @@ class FeatureTransformer(EmipModule):
             # ---- self attention (no FFN): c0 += LN(merge(attn))
             msg = _window_attention(big, big[..., C:], big[..., 2 * C:], B2, h, w, C, ldb, ldb, ldb, shift,
                                     attn_num_splits)
-            msg = ops.gemm(msg, ws["merge"])
-            ops.layernorm(msg, ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, out=c0, res=c0)    # c0 += LN(msg)
+            ops.gemm_ln_out(msg, ws["merge"], ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, res=c0, out=c0)  # c0 += LN(merge)
             # ---- cross attention + FFN
             q = ops.gemm(c0, wc["q"])
             msg = _window_attention(q, ck, cv, B2, h, w, C, C, ldc5, ldc5, shift, attn_num_splits, kv_rot=rot)
-            msg = ops.gemm(msg, wc["merge"])
-            msg = ops.layernorm(msg, wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps, out=msg)
+            msg = ops.gemm_ln_out(msg, wc["merge"], wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps)
             hid = ops.gemm(c0, wc["m0"], a2=msg, act=ops.ACT_GELU)
-            msg = ops.gemm(hid, wc["m2"])
-            ops.layernorm(msg, wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps, out=c0, res=c0)     # c0 += LN(msg)
+            ops.gemm_ln_out(hid, wc["m2"], wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps, res=c0, out=c0)  # c0 += LN(mlp)
         return c0
 
 

@@ -382,6 +382,28 @@ def layernorm(x, gamma, beta, eps, out=None, res=None, out_stats=None):
     return out
 
 
+GEMM_LN_OUT = __import__('os').environ.get('EMIP_GEMM_LN_OUT', '1') != '0'
+
+
+def gemm_ln_out(a, w, gamma, beta, eps, bias=None, res=None, out=None):
+    """res + LayerNorm(a w^T + bias) * gamma + beta over the N <= 128 output columns -- a post-norm Linear: the norm runs in
+    the GEMM epilogue (emip_gemm8_lno) where the shape allows, else GEMM + emip_layernorm.  out may alias res."""
+    M, K, lda = rows(a)
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
+    if (GEMM_LN_OUT and a.dtype == torch.bfloat16 and gemm8_enabled() and N <= 128 and N % 8 == 0 and K % 64 == 0 and M >= 1024
+            and w.is_contiguous() and lda % 8 == 0):
+        _, _, ldc = rows(out)
+        ldr = rows(res)[2] if res is not None else 0
+        if ldc % 8 == 0 and ldr % 8 == 0:
+            _lib.call("emip_gemm8_lno", _p(a), _p(w), _p(out), _p(bias), _p(res), _p(gamma), _p(beta), float(eps), M, N, K, lda,
+                      w.stride(0), ldc, ldr, _stream())
+            return out
+    msg = gemm(a, w, bias=bias)
+    return layernorm(msg, gamma, beta, eps, out=out, res=res)
+
+
 KV_SPLIT = True      # emip_attention_splitkv for >= KV_SPLIT_MIN_KEYS keys on grids of < KV_SPLIT_TARGET workgroups
 KV_SPLIT_MIN_KEYS = int(__import__('os').environ.get('EMIP_KV_MIN', '1024'))
 KV_SPLIT_TARGET = int(__import__('os').environ.get('EMIP_KV_TARGET', '512'))      # workgroups to aim at (two per CU)

@@ -147,6 +147,12 @@ int emip_sra_qattn(const void* X, long ldx, const float* stats, float eps, const
                    const float* colsum_q, const void* KV, void* O, long ldo, int B, int N, int Lk, int C, float scale,
                    void* stream);
 
+/* Post-norm Linear in one launch (bf16): C = R + LayerNorm(A W^T + bias) * gamma + beta with the LayerNorm over the N <= 128
+ * output columns evaluated in the GEMM epilogue (GMFlow transformer.py:87-113: message = norm1(merge(message)), message =
+ * norm2(mlp(...)), return source + message: R = source, may alias C; R may be null).  K % 64 == 0. */
+int emip_gemm8_lno(const void* A, const void* W, void* C, const float* bias, const void* R, const float* gamma,
+                   const float* beta, float eps, int M, int N, int K, long lda, long ldw, long ldc, long ldr, void* stream);
+
 /* Introspection: block tile (BM*1000+BN) emip_gemm / emip_conv2d dispatch for an (M, N, batch, K) problem. */
 int emip_gemm_tile(long M, long N, long batch, long K);
 

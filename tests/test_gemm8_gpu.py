@@ -151,3 +151,34 @@ def test_gemm8_rowscale_epilogue(B, rps, K, N):
     assert err < 0.02 * ref.abs().max().item(), err
     drop = (sc.repeat_interleave(rps) == 0).nonzero()[:4, 0]
     assert torch.equal(out[drop], res[drop])                  # a dropped sample keeps its skip path bit for bit
+
+
+@pytest.mark.parametrize("M,N,K,res,bias", [(30976, 128, 128, True, False), (30976, 128, 1024, True, False), (3000, 128, 256, False, True),
+                                            (1100, 96, 64, True, True), (70000, 128, 128, True, False)])
+def test_gemm8_layernorm_on_output(M, N, K, res, bias):
+    """emip_gemm8_lno: R + LayerNorm(A W^T + b) * gamma + beta with the norm in the GEMM epilogue (GMFlow transformer.py:87-113)
+    against an f32 restatement and against the two launches it replaces (GEMM, emip_layernorm with residual)"""
+    from emip_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = (torch.randn(M, K, device=dev, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5 * 2).to(torch.bfloat16)
+    b = torch.randn(N, device=dev, generator=g) * 0.5 if bias else None
+    r = torch.randn(M, N, device=dev, generator=g).to(torch.bfloat16) if res else None
+    gamma = 1 + 0.2 * torch.randn(N, device=dev, generator=g)
+    beta = 0.1 * torch.randn(N, device=dev, generator=g)
+    y = a.float() @ w.float().t() + (b if bias else 0)
+    ref = torch.nn.functional.layer_norm(y, (N,), gamma, beta, 1e-5) + (r.float() if res else 0)
+    got = ops.gemm_ln_out(a, w, gamma, beta, 1e-5, bias=b, res=r)
+    old = ops.layernorm(ops.gemm(a, w, bias=b), gamma, beta, 1e-5, res=r)
+    torch.cuda.synchronize()
+    top = max(1.0, ref.abs().max().item())
+    e_new, e_old = (got.float() - ref).abs(), (old.float() - ref).abs()
+    assert e_new.max().item() < 2e-2 * top, e_new.max().item()
+    # one rounding (f32 accumulators normalised directly) instead of two: never worse than the two launches
+    assert e_new.mean().item() <= 1.05 * e_old.mean().item() + 1e-5 * top
+    # in place over the residual, as the transformer uses it
+    if res:
+        r2 = r.clone()
+        ops.gemm_ln_out(a, w, gamma, beta, 1e-5, bias=b, res=r2, out=r2)
+        assert torch.equal(r2, got)
