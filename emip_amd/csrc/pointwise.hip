@@ -1198,10 +1198,11 @@ extern "C" int emip_rows_finalize(const float* A, long lda, void* Y, long ldy, f
     return emip_launch_status();
 }
 
-static int g_lnb_wide = 1;
+static int g_lnb_wide = 1, g_lnb_rows = 1;
 #ifdef EMIP_TUNING
-extern "C" int emip_debug_set_lnb(int wide) {
-    g_lnb_wide = wide;
+extern "C" int emip_debug_set_lnb(int wide) {          // 0: the 4-channel form, 1: two 8-channel vectors per lane, 2 (default): + rows
+    g_lnb_wide = wide != 0;
+    g_lnb_rows = wide >= 2 || wide < 0;
     return EMIP_OK;
 }
 #endif
@@ -1212,6 +1213,121 @@ extern "C" int emip_layernorm_bwd(const void* X, long ldx, const void* DY, long 
                                   int C, float eps, int dtype, void* stream) {
     return emip_layernorm_bwd_res(X, ldx, DY, lddy, DX, lddx, nullptr, 0, gamma, dgamma, dbeta, nparts, part_stride, M, C,
                                   eps, dtype, stream);
+}
+
+// bf16 rows of C = 8 * 8 * VPL / ... channels with EIGHT lanes per row and VPL 16-byte vectors per lane (vector v of the row
+// sits in lane v % 8): every lane works (the two-vectors-per-lane form above keeps 40 of 64 vector slots busy at C = 320 and
+// reduces over 32 lanes: it ran the 15 488 x 320 launches of the training step at 1 TB/s), a row statistic is three shuffle
+// levels, a wave instruction reads whole 128-byte segments of 8 rows.
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_rows_kernel(const bf16_t* __restrict__ X, long ldx,
+                                                                 const bf16_t* __restrict__ DY, long lddy,
+                                                                 bf16_t* __restrict__ DX, long lddx,
+                                                                 const float* __restrict__ gamma, float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, long M, int C, float eps, int nparts,
+                                                                 long part_stride, const bf16_t* __restrict__ DR, long lddr) {
+    extern __shared__ float red[];   // [2][C]
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 7, rsub = lane >> 3;
+    const int nv8 = C >> 3;
+    const int nwave = blockDim.x >> 6;
+    const long wave_global = (long)blockIdx.x * nwave + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * nwave * 8;
+    for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) red[i] = 0.f;
+    __syncthreads();
+    float gam[VPL][8], ag[VPL][8], ab[VPL][8];
+    bool act[VPL];
+    int vcl[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int vi = sub + 8 * i;
+        act[i] = vi < nv8;
+        vcl[i] = min(vi, nv8 - 1) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gam[i][j] = act[i] ? gamma[vcl[i] + j] : 0.f;
+            ag[i][j] = ab[i][j] = 0.f;
+        }
+    }
+    const float invC = 1.f / (float)C;
+    for (long row0 = wave_global * 8; row0 < M; row0 += stride) {
+        const long row = row0 + rsub;
+        const long rowc = row < M ? row : M - 1;
+        Raw8<bf16_t> rx[VPL], rdy[VPL], rdr[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            rx[i].load(X + rowc * ldx + vcl[i]);
+            rdy[i].load(DY + rowc * lddy + vcl[i]);
+            if (DR) rdr[i].load(DR + rowc * lddr + vcl[i]);
+        }
+        float x[VPL][8], dy[VPL][8];
+        float s = 0.f, s2 = 0.f, sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            const float keep = (row < M && act[i]) ? 1.f : 0.f;
+            rx[i].unpack(x[i], keep);
+            rdy[i].unpack(dy[i], keep);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xv = x[i][j], g = dy[i][j] * gam[i][j];
+                s += xv;
+                s2 += xv * xv;
+                sg += g;
+                sgx += g * xv;
+            }
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) {
+            s += __shfl_xor(s, o);
+            s2 += __shfl_xor(s2, o);
+            sg += __shfl_xor(sg, o);
+            sgx += __shfl_xor(sgx, o);
+        }
+        const float mean = s * invC;
+        const float rstd = rsqrtf(fmaxf(s2 * invC - mean * mean, 0.f) + eps);
+        const float mg = sg * invC, mgx = rstd * (sgx - mean * sg) * invC;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float o8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xh = (x[i][j] - mean) * rstd;           // padded lanes / rows: dy = 0, nothing is accumulated
+                ag[i][j] += dy[i][j] * xh;
+                ab[i][j] += dy[i][j];
+                o8[j] = rstd * (dy[i][j] * gam[i][j] - mg - xh * mgx);
+            }
+            if (DR) {
+                float r8[8];
+                rdr[i].unpack(r8, 1.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] += r8[j];
+            }
+            if (row < M && act[i]) store8<bf16_t>(DX + row * lddx + vcl[i], o8);
+        }
+    }
+    // the 8 row groups of a wave hold partial dgamma / dbeta of the same channels: shuffles, one LDS atomic per channel and
+    // wave, one global atomic per channel and workgroup
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float a = ag[i][j], b = ab[i][j];
+#pragma unroll
+            for (int o = 32; o >= 8; o >>= 1) {
+                a += __shfl_xor(a, o);
+                b += __shfl_xor(b, o);
+            }
+            if (rsub == 0 && act[i]) {
+                atomicAdd(&red[vcl[i] + j], a);
+                atomicAdd(&red[C + vcl[i] + j], b);
+            }
+        }
+    __syncthreads();
+    const long po = (long)(blockIdx.x % nparts) * part_stride;
+    for (int i = threadIdx.x; i < C; i += blockDim.x) {
+        atomicAdd(dgamma + po + i, red[i]);
+        atomicAdd(dbeta + po + i, red[C + i]);
+    }
 }
 
 // The same with DX = LayerNorm backward + DR: in a pre-norm residual block x feeds the LayerNorm AND the skip connection, so
@@ -1226,8 +1342,31 @@ extern "C" int emip_layernorm_bwd_res(const void* X, long ldx, const void* DY, l
     if (DR) EMIP_REQUIRE((lddr & 3) == 0 && lddr >= C);
     if (g_lnb_wide && (C & 7) == 0 && (ldx & 7) == 0 && (lddy & 7) == 0 && (lddx & 7) == 0 && aligned16(X) && aligned16(DY) &&
         aligned16(DX) && (!DR || ((lddr & 7) == 0 && aligned16(DR)))) {
-        const int U = 1;
         const int nv8 = C >> 3;
+        if (dtype == EMIP_BF16 && g_lnb_rows && nv8 <= 64) {
+            // eight lanes per row: 256-thread workgroups of 32 rows per sweep, about 8 sweeps per workgroup
+            const int vpl = (nv8 + 7) / 8;
+            long blocks = (M + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            if (blocks < 1) blocks = 1;
+#define EMIP_LNB_ROWS(V)                                                                                                       \
+    hipLaunchKernelGGL((layernorm_bwd_rows_kernel<V>), dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float),               \
+                       (hipStream_t)stream, (const bf16_t*)X, ldx, (const bf16_t*)DY, lddy, (bf16_t*)DX, lddx, gamma, dgamma,  \
+                       dbeta, M, C, eps, nparts, part_stride, (const bf16_t*)DR, lddr)
+            switch (vpl) {
+                case 1: EMIP_LNB_ROWS(1); break;
+                case 2: EMIP_LNB_ROWS(2); break;
+                case 3: EMIP_LNB_ROWS(3); break;
+                case 4: EMIP_LNB_ROWS(4); break;
+                case 5: EMIP_LNB_ROWS(5); break;
+                case 6: EMIP_LNB_ROWS(6); break;
+                case 7: EMIP_LNB_ROWS(7); break;
+                default: EMIP_LNB_ROWS(8); break;
+            }
+#undef EMIP_LNB_ROWS
+            return emip_launch_status();
+        }
+        const int U = 1;
         int lg = 0;
         while ((2 << lg) < nv8 && lg < 6) ++lg;
         const long rows_per_wave = (64 >> lg) * U;
