@@ -331,6 +331,99 @@ struct Raw8<bf16_t> {
     }
 };
 
+// Forward LayerNorm for bf16 rows, eight lanes per row and VPL 16-byte vectors per lane (vector v of a row in lane v % 8):
+// every lane works at C = 64 / 128 / 320 / 512, a row statistic is three shuffle levels, a wave instruction reads whole
+// 128-byte segments of 8 rows.  Same arithmetic as layernorm_kernel (mean, then the sum of squared deviations).
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ X, long ldx, bf16_t* __restrict__ Y, long ldy,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const bf16_t* R, long ldr, float* __restrict__ out_stats, long M,
+                                                             int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & 7, rsub = lane >> 3;
+    const int nv8 = C >> 3;
+    const long wave_global = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long stride = (long)gridDim.x * 32;
+    bool act[VPL];
+    int vcl[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        act[i] = sub + 8 * i < nv8;
+        vcl[i] = min(sub + 8 * i, nv8 - 1) * 8;
+    }
+    const float invC = 1.f / (float)C;
+    for (long row0 = wave_global * 8; row0 < M; row0 += stride) {
+        const long row = row0 + rsub;
+        const bool ok = row < M;
+        const long rowc = ok ? row : M - 1;
+        Raw8<bf16_t> rx[VPL], rr[VPL];
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            rx[i].load(X + rowc * ldx + vcl[i]);
+            if (R) rr[i].load(R + rowc * ldr + vcl[i]);
+        }
+        float x[VPL][8];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            rx[i].unpack(x[i], (ok && act[i]) ? 1.f : 0.f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += x[i][j];
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s * invC;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i)
+            if (act[i]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = x[i][j] - mean;
+                    q += d * d;
+                }
+            }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = rsqrtf(q * invC + eps);
+        float os1 = 0.f, os2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < VPL; ++i) {
+            float o8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o8[j] = (x[i][j] - mean) * rstd * gamma[vcl[i] + j] + beta[vcl[i] + j];
+            if (R) {
+                float r8[8];
+                rr[i].unpack(r8, 1.f);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o8[j] += r8[j];
+            }
+            if (ok && act[i]) {
+                store8<bf16_t>(Y + row * ldy + vcl[i], o8);
+                if (out_stats) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = (float)(bf16_t)o8[j];
+                        os1 += v;
+                        os2 += v * v;
+                    }
+                }
+            }
+        }
+        if (out_stats) {
+#pragma unroll
+            for (int o = 4; o > 0; o >>= 1) {
+                os1 += __shfl_xor(os1, o);
+                os2 += __shfl_xor(os2, o);
+            }
+            if (ok && sub == 0) {
+                out_stats[2 * row] = os1;
+                out_stats[2 * row + 1] = os2;
+            }
+        }
+    }
+}
+
 template <typename T, int U>
 __global__ __launch_bounds__(1024) void layernorm_bwd_wide_kernel(const T* __restrict__ X, long ldx,
                                                                   const T* __restrict__ DY, long lddy,
@@ -1170,6 +1263,26 @@ extern "C" int emip_layernorm(const void* X, long ldx, void* Y, long ldy, const 
     EMIP_REQUIRE(X && Y && gamma && beta && M > 0 && C >= 4 && C <= 1024 && (C & 3) == 0);
     EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
     if (R) EMIP_REQUIRE((ldr & 3) == 0 && ldr >= C);
+    if (dtype == EMIP_BF16 && (C & 7) == 0 && C <= 512 && (ldx & 7) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y) &&
+        (!R || ((ldr & 7) == 0 && aligned16(R)))) {
+        const int vpl = ((C >> 3) + 7) / 8;
+        const int grid = grid_for((M + 7) / 8, 4);
+#define EMIP_LN_ROWS(V)                                                                                                   \
+    hipLaunchKernelGGL((layernorm_rows_kernel<V>), dim3(grid), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx,    \
+                       (bf16_t*)Y, ldy, gamma, beta, (const bf16_t*)R, ldr, out_stats, M, C, eps)
+        switch (vpl) {
+            case 1: EMIP_LN_ROWS(1); break;
+            case 2: EMIP_LN_ROWS(2); break;
+            case 3: EMIP_LN_ROWS(3); break;
+            case 4: EMIP_LN_ROWS(4); break;
+            case 5: EMIP_LN_ROWS(5); break;
+            case 6: EMIP_LN_ROWS(6); break;
+            case 7: EMIP_LN_ROWS(7); break;
+            default: EMIP_LN_ROWS(8); break;
+        }
+#undef EMIP_LN_ROWS
+        return emip_launch_status();
+    }
     const int nv = C >> 2;
     int lg = 0;
     while ((1 << lg) < nv && lg < 6) ++lg;
