@@ -586,12 +586,12 @@ constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
 
 // Tile choice, from the per-shape sweep of tools/gemm8_bench.py on MI355X (profiles/r02_gemm8_sweep.txt):
 //   * long K x wide N (conv_corr, big GEMMs): 256 x 256, the only tile whose L2 -> LDS bytes per MAC keep the MFMA fed;
-//   * fewer than ~1.5 tiles of 128 x 128 per CU: 64 x 128 / 128 x 64 (two workgroups per CU overlap their fill / drain);
+//   * fewer than ~0.75 tiles of 128 x 128 per CU (round 2c; first ~1.5): 64 x 128 / 128 x 64 (two workgroups per CU overlap their fill / drain);
 //   * N = 64 (mod 128): 256 x 64; else 128 x 128 with two workgroups per CU.
 int pick_cfg(int M, int N, long K) {
     if ((double)K * N >= 4.0e6 && M >= 8192) return 7;
     const long tiles3 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    if (tiles3 < 384) return N <= 64 ? 8 : 9;
+    if (tiles3 < 192) return N <= 64 ? 8 : 9;   // round 2c: was 384 (8-pair sub-batches: the 242-tile GEMMs prefer 128 x 128)
     if (N % 128 == 64 || N <= 64) return 6;
     return 3;
 }
