@@ -34,13 +34,14 @@ WAVES = {(256, 128): (4, 2), (128, 256): (2, 4), (128, 128): (2, 4), (128, 320):
          (256, 256): (2, 4), (128, 64): (4, 2), (64, 128): (2, 4)}
 
 
-def _g8_key(lib, cfg, conv, lnt):
+def _g8_key(lib, cfg, conv, lnt, lno=False):
     """kernel symbol of a gemm8 configuration, as rocprofv3 prints it"""
     t = lib.emip_gemm8_cfg_tile(cfg)
     bm, bn = t // 1000, t % 1000
     wm, wn = WAVES[(bm, bn)]
-    return "gemm8_kernel<%d, %d, %d, %d, %d, %s, %s, false>" % (bm, bn, wm, wn, lib.emip_gemm8_cfg_stages(cfg, 1 if lnt else 0),
-                                                                 "true" if conv else "false", "true" if lnt else "false")
+    return "gemm8_kernel<%d, %d, %d, %d, %d, %s, %s, false, %s>" % (bm, bn, wm, wn, lib.emip_gemm8_cfg_stages(cfg, 1 if lnt else 0),
+                                                                     "true" if conv else "false", "true" if lnt else "false",
+                                                                     "true" if lno else "false")
 
 
 def _launch_info(lib, name, a):
@@ -50,6 +51,10 @@ def _launch_info(lib, name, a):
         batch, heads, Lq, Lk = a[3], a[4], a[5], a[6]
         z = batch * heads
         return 4.0 * z * Lq * Lk * 64, "sra_kernel", 2.0 * z * (2 * Lq * 64 + 2 * Lk * 64)
+    if name == "emip_gemm8_lno":          # (A, W, C, bias, R, gamma, beta, eps, M, N, K, lda, ldw, ldc, ldr, stream)
+        M, N, K = a[8], a[9], a[10]
+        return (2.0 * M * N * K, _g8_key(lib, 3 if (M + 127) // 128 >= 512 else 9, False, False, True),
+                2.0 * (M * K + N * K + M * N * (2 if a[4] else 1)))
     if name == "emip_sra_qattn":          # (X, ldx, stats, eps, Wq, bq, csq, KV, O, ldo, B, N, Lk, C, scale, stream)
         Bm, N, Lk, C = a[10], a[11], a[12], a[13]
         M = Bm * N
