@@ -159,6 +159,35 @@ def test_softmax_rows_fwd_bwd(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,L,ld,masked", [(1452, 484, 488, True), (700, 1936, 1936, False), (300, 484, 512, False), (64, 130, 136, True)])
+def test_softmax_rows_wide_rows(dtype, M, L, ld, masked):
+    """the 484-key window and 1936-key matching softmaxes of the GMFlow training path (transformer.py:33-70: scores / 128**0.5,
+    -100 on the pairs a shifted window separates): the bf16 form reads 16 bytes per lane"""
+    from emip_amd import ops
+    x, xf = prep(rnd(M, ld, seed=1) * 3, dtype)
+    dp, dpf = prep(rnd(M, ld, seed=2), dtype)
+    gq = gk = None
+    sc = xf[:, :L] * 0.25
+    if masked:                       # 3 windows of `period` rows each, groups of 2 ids
+        period, nwin = M // 3 if M % 3 == 0 else M, 3 if M % 3 == 0 else 1
+        gq = torch.randint(0, 2, (nwin, period), dtype=torch.int32)
+        gk = torch.randint(0, 2, (nwin, L), dtype=torch.int32)
+        win = (torch.arange(M) // period) % nwin
+        sc = sc + torch.where(gq[win, torch.arange(M) % period][:, None] != gk[win], -100.0, 0.0)
+        p = ops.softmax_rows(x, L, scale=0.25, gid_q=gq.cuda(), gid_k=gk.cuda(), period=period, nwin=nwin)
+    else:
+        p = ops.softmax_rows(x, L, scale=0.25)
+    ref = sc.softmax(-1)
+    assert rel(p[:, :L], ref) < (1e-5 if dtype == torch.float32 else 1e-2)
+    assert L == ld or p[:, L:].abs().max().item() == 0
+    pf = p.float().cpu()[:, :L]
+    ds = ops.softmax_bwd_rows(p, dp, L, scale=0.25)
+    refds = pf * (dpf[:, :L] - (pf * dpf[:, :L]).sum(-1, keepdim=True)) * 0.25
+    assert rel(ds[:, :L], refds) < (1e-5 if dtype == torch.float32 else 2e-2)
+    assert L == ld or ds[:, L:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_gelu_dwconv_wgrad(dtype):
     from emip_amd import ops
     k, kf = prep(rnd(6, 121, 64, seed=1), dtype)
