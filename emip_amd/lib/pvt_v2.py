@@ -60,6 +60,7 @@ _lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
 # fc1 + depthwise + GELU as one kernel where an image fits one workgroup (stages 3 and 4); EMIP_MLP_FC1DW=0: two launches
 MLP_FC1DW = os.environ.get("EMIP_MLP_FC1DW", "1") != "0"
 # q projection + spatial-reduction attention + proj + residual of the inference block in one launch (emip_sra_block)
+SR_CFG = int(os.environ.get("EMIP_SR_CFG", "0"))       # gemm8 configuration of the spatial-reduction conv (0 = the library's choice)
 SRA_BLOCK = os.environ.get("EMIP_SRA_BLOCK", "1") != "0"
 SRA_BLOCK_MAXC = int(os.environ.get("EMIP_SRA_BLOCK_MAXC", "128"))      # wider stages: emip_sra_qattn + the proj GEMM
 
@@ -276,7 +277,7 @@ class Block(EmipModule):
         if use_block:
             # spatial-reduction conv -> kv, then q projection + attention + proj + residual in ONE launch (emip_sra_block)
             s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
-                          out_stats=st_sr)
+                          out_stats=st_sr, cfg=SR_CFG if C > 64 else 0)
             kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"])
             if C <= SRA_BLOCK_MAXC:
                 ops.sra_block(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), w["pf"], w["bp"], heads,
@@ -289,7 +290,7 @@ class Block(EmipModule):
             # the spatial-reduction conv over the raw patches (per-tap sums; the statistics ride the operand ring)
             q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["sq"])
             s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
-                          out_stats=st_sr)
+                          out_stats=st_sr, cfg=SR_CFG if C > 64 else 0)
             kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"])
         elif use_pair:
             # q projection (as a 1x1 conv over the tokens) and the spatial-reduction conv in ONE launch
