@@ -88,7 +88,15 @@ class GraphedShort:
 
 
 class _LongPart:
-    def __init__(self, net, streams, size, device, warmup):
+    def __init__(self, net, streams, size, device, warmup, cnn_first=False):
+        from .model.EMIP_short import model as _m
+        prev, _m.CNN_FIRST = _m.CNN_FIRST, bool(cnn_first and _m.STAGGER)
+        try:
+            self._build(net, streams, size, device, warmup)
+        finally:
+            _m.CNN_FIRST = prev
+
+    def _build(self, net, streams, size, device, warmup):
         T, n, C = net.WINDOW, (size // 8) ** 2, 128
         self.f0 = torch.zeros(streams, 3, size, size, device=device)
         self.f1 = torch.zeros(streams, 3, size, size, device=device)
@@ -118,7 +126,7 @@ class GraphedLong:
         while splits > 1 and streams % splits:
             splits -= 1
         self.net, self.nstreams, self.splits = net, streams, splits
-        self.parts = [_LongPart(net, streams // splits, size, device, warmup) for _ in range(splits)]
+        self.parts = [_LongPart(net, streams // splits, size, device, warmup, cnn_first=i % 2 == 1) for i in range(splits)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(splits)]
         for p in self.parts:
             p.graph.replay()
