@@ -151,7 +151,24 @@ def kernel_breakdown(net, im1, im2, splits=1):
     return agg
 
 
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r02c_bench_kernel_stats.csv")
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
+if not os.path.exists(PROFILE_CSV):
+    PROFILE_CSV = os.path.join(ROOT, "profiles", "r02c_bench_kernel_stats.csv")
+PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+# algorithmic (compulsory) HBM bytes of one 16-pair step, SURVEY.md section 8(d): 18 MB per pair + the 213 MB of bf16 weights once
+COMPULSORY_STEP_BYTES = PAIRS_PER_GPU * 18e6 + 213e6
+
+
+def _file_stamp(path):
+    """name + sha256 prefix of a committed profile file: figures read from it belong to THAT build, not to this run"""
+    import hashlib
+    if not os.path.exists(path):
+        return None
+    return "%s@sha256:%s" % (os.path.relpath(path, ROOT), hashlib.sha256(open(path, "rb").read()).hexdigest()[:12])
+
+
+def _pmc():
+    return json.load(open(PMC_JSON)) if os.path.exists(PMC_JSON) else {}
 
 
 def rocprof_avg(key):
@@ -188,10 +205,7 @@ def named_roofline(agg, key, what):
     tflops, tbs = fl / (ms * 1e-3) / 1e12, byt / (ms * 1e-3) / 1e12
     ai = fl / max(byt, 1.0)
     hbm = ai < PEAK_BF16_TFLOPS / PEAK_HBM_TBS
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf):
-        traffic = json.load(open(tf)).get(key.replace("+scores", ""), {}).get("hbm_bytes_per_launch")
+    traffic = _pmc().get(key.replace("+scores", ""), {}).get("hbm_bytes_per_launch")
     rec = ({"bound": "hbm", "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
             "frac": round(tbs / PEAK_HBM_TBS, 4)} if hbm else
            {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -200,26 +214,88 @@ def named_roofline(agg, key, what):
                 "mfma_frac": round(tflops / PEAK_BF16_TFLOPS, 4), "arithmetic_intensity_flop_per_byte": round(ai, 1),
                 "hbm_bound_ceiling_TFLOPs": round(ai * PEAK_HBM_TBS, 1), "launches": cnt,
                 "algorithmic_bytes_per_launch": round(byt / cnt), "algorithmic_flops_per_launch": round(fl / cnt),
-                "avg_launch_us": round(ms / cnt * 1e3, 2), "rocprofv3_avg_launch_us": rocprof_avg(key)})
+                "avg_launch_us": round(ms / cnt * 1e3, 2), "clock": "HIP events on the launch stream, this run",
+                "committed_profile": {"rocprofv3_avg_launch_us": rocprof_avg(key), "kernel_stats": _file_stamp(PROFILE_CSV),
+                                      "traffic": _file_stamp(PMC_JSON)}})
     return rec
 
 
+def _pct(xs, q):
+    xs = sorted(xs)
+    if not xs:
+        return None
+    k = (len(xs) - 1) * q
+    lo, hi = int(k), min(int(k) + 1, len(xs) - 1)
+    return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
+
+
 def cpu_baseline(sd):
+    """the CPU oracle, batch 1, f32, at 16 threads (the CPU share a one-GPU box gets) and at 8 (the
+    survey container's figure, 0.70 pairs/s, was taken at 8); 3 warm-up forwards, then ~9 s of timed forwards per setting;
+    median and p10 / p90 of the per-forward rate"""
     from emip_amd.filler import synthetic_pair
     from oracle import emip_oracle as O
     im1, im2 = synthetic_pair(1, seed=1234)
+    recs, ref_mask = {}, None
+    ncpu = os.cpu_count() or 1
     with torch.no_grad():
-        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))   # the GPU box gives one GPU a 16-CPU share
-        ref_mask = O.short_forward(im1, im2, sd)[0]          # warm-up; also the reference mask of the parity figures
-        t0 = time.time()
-        n = 0
-        while n < 3 or (time.time() - t0 < 12.0 and n < 12):
-            O.short_forward(im1, im2, sd)
-            n += 1
-        dt = time.time() - t0
-    return {"value": n / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d fp32 batch-1 EMIP-short forwards of the CPU oracle (oracle/emip_oracle.py, PyTorch-CPU, "
-                      "%d threads, host has %d logical CPUs)" % (n, torch.get_num_threads(), os.cpu_count())}, ref_mask
+        for nt in (16, 8):
+            torch.set_num_threads(max(1, min(nt, ncpu)))
+            for _ in range(2 if ref_mask is not None else 3):
+                ref_mask = O.short_forward(im1, im2, sd)[0]  # warm-up; also the reference mask of the parity figures
+            ts, t0 = [], time.time()
+            while len(ts) < 3 or (time.time() - t0 < 9.0 and len(ts) < 12):
+                t1 = time.time()
+                O.short_forward(im1, im2, sd)
+                ts.append(time.time() - t1)
+            rates = [1.0 / t for t in ts]
+            recs[nt] = {"value": len(ts) / sum(ts), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+                        "median": round(_pct(rates, 0.5), 4), "p10": round(_pct(rates, 0.1), 4), "p90": round(_pct(rates, 0.9), 4),
+                        "gflops": round(len(ts) / sum(ts) * F_ALG_PAIR_GFLOP, 1),
+                        "sample": "%d fp32 batch-1 EMIP-short forwards of the CPU oracle (oracle/emip_oracle.py, PyTorch-CPU, "
+                                  "%d threads, host has %d logical CPUs)" % (len(ts), torch.get_num_threads(), ncpu)}
+    return recs[16], recs[8], ref_mask
+
+
+def _iou(a, b):
+    a, b = a > 0, b > 0
+    return float((a & b).sum().item() + 1e-9) / float((a | b).sum().item() + 1e-9)
+
+
+def timed_output_parity(runner, net, margs, sd, im1, im2, dev):
+    """What the timed region computed: the masks left by its LAST graph replays (bf16, two 8-pair graphs, the second one
+    captured GMFlow-CNN-first, free-running on two streams) against (a) the eager bf16 forward of the same sub-batches in the
+    same launch order and (b) the f32 parity mode on the same 16 pairs -- test.py:28's view of the configuration that is timed"""
+    from emip_amd import nn_base
+    from emip_amd.model.EMIP_short import model as M
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    mask = runner.outputs()[0].float()
+    n = im1.shape[0] // runner.splits
+    halves = []
+    with torch.no_grad():
+        for i in range(runner.splits):
+            prev, M.CNN_FIRST = M.CNN_FIRST, bool(i % 2 == 1 and M.STAGGER)
+            try:
+                halves.append(net(im1[i * n:(i + 1) * n], im2[i * n:(i + 1) * n])[0].float())
+            finally:
+                M.CNN_FIRST = prev
+        eager = torch.cat(halves, 0)
+        nn_base.set_default_dtype(torch.float32)
+        try:
+            net32 = CoUpdater(margs)
+            net32.load_state_dict(sd)
+            m32 = net32.to(dev).eval()(im1, im2)[0]
+            del net32
+        finally:
+            nn_base.set_default_dtype(torch.bfloat16)
+    torch.cuda.empty_cache()
+    return {"what": "mask logits of the last timed graph replays, %d pairs" % im1.shape[0],
+            "finite": bool(torch.isfinite(mask).all().item()),
+            "max_abs_dlogit_vs_eager_bf16_same_subbatches": float("%.3g" % (mask - eager).abs().max().item()),
+            "mask_iou_vs_eager_bf16": round(_iou(mask, eager), 5),
+            "max_abs_dlogit_vs_f32_mode": float("%.3g" % (mask - m32).abs().max().item()),
+            "mask_iou_vs_f32_mode": round(_iou(mask, m32), 5),
+            "logit_range_f32_mode": float("%.3g" % m32.abs().max().item())}
 
 
 def parity_figures(net_bf16, margs, sd, ref_mask, dev):
@@ -240,9 +316,7 @@ def parity_figures(net_bf16, margs, sd, ref_mask, dev):
         finally:
             nn_base.set_default_dtype(torch.bfloat16)
 
-    def iou(a, b):
-        a, b = a > 0, b > 0
-        return float((a & b).sum().item() + 1e-9) / float((a | b).sum().item() + 1e-9)
+    iou = _iou
     return {"mask_iou_bf16_vs_cpu_ref": round(iou(m16, ref_mask), 5), "mask_iou_f32_vs_cpu_ref": round(iou(m32, ref_mask), 5),
             "mask_logit_max_abs_err_f32_vs_cpu_ref": float("%.3g" % (m32 - ref_mask).abs().max().item()),
             "mask_logit_max_abs_err_bf16_vs_cpu_ref": float("%.3g" % (m16 - ref_mask).abs().max().item()),
@@ -270,7 +344,10 @@ def _barrier(dist):
 
 
 F_ALG_TRAIN_PAIR_GFLOP = 702.0   # fwd F + dgrad where a trainable consumer exists + wgrad for trainable layers
-F_ALG_LONG_FRAME_GFLOP = 280.63  # F_alg(short) + 10 GF (LTM convs, memory read, long_dr, second injector / decoder)
+# EMIP-long per stream-frame: F_alg(short) + 10 GF (LTM convs, memory read, long_dr, long injector / decoder) MINUS the
+# launches the long step does not make because nobody reads their results (model_long.py:68-117 decodes on its own):
+# flow propagation 2.20, convex upsampler 3.46, the short-term injector1 0.86, its reductions / decoder 1.23
+F_ALG_LONG_FRAME_GFLOP = 270.63 + 10.0 - 2.20 - 3.46 - 0.86 - 1.23
 
 
 def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev):
@@ -395,7 +472,8 @@ def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=Fal
                    "parallelism": "dp%d (independent replicas, no collective)" % world},
         "achieved_TFLOPs_per_gpu": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3, 1),
         "frac_of_bf16_mfma_peak": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
-        "flops_convention": "F_alg(short) 270.63 + 10 GFLOP per stream-frame (SURVEY.md 8d)"}
+        "flops_convention": "%.2f GFLOP per stream-frame = F_alg(short) 270.63 + 10 (SURVEY.md 8d) - 7.75 for the flow "
+                               "head / upsampler / short-term injector1 + decoder the long step never launches" % F_ALG_LONG_FRAME_GFLOP}
     del net
     if not no_graph:
         del runner
@@ -552,19 +630,34 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    # one HIP event per stream behind every step of the timed region (a few us of host time each): the spacing of
+    # consecutive events on a stream is that step's duration in steady state -> median / p10 / p90 beside the contract's figure
+    ev_streams = [torch.cuda.current_stream(dev)] if args.no_graph else runner.streams
+    marks = [[torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] for _ in ev_streams]
     _barrier(dist)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for st, m in zip(ev_streams, marks):
+        m[0].record(st)
+    for i in range(args.steps):
         step()
+        for st, m in zip(ev_streams, marks):
+            m[i + 1].record(st)
     _barrier(dist)
     dt = time.perf_counter() - t0
     dt = edist.max_over_ranks(dt, red_dev)
+    step_ms = [max(m[i].elapsed_time(m[i + 1]) for m in marks) for i in range(args.steps)]
 
     out = None
     if rank == 0:
         pairs = world * B * args.steps
         value = pairs / dt
         nsplit = nsub if args.no_graph else runner.splits
+        timed_parity = None
+        if not args.no_graph:
+            try:
+                timed_parity = timed_output_parity(runner, net, margs, sd, im1, im2, dev)
+            except Exception as e:                               # noqa: BLE001
+                timed_parity = {"error": repr(e)[:300]}
         agg = kernel_breakdown(net, im1, im2, nsplit)
         kernels = {k: v for k, v in agg.items() if v[1] > 0 and "blocker" not in k}
         dom = max(kernels, key=lambda k: kernels[k][0])
@@ -576,15 +669,20 @@ def main():
         hbm_bound = (fl / max(byt, 1.0)) < ridge
         total_ms = sum(v[0] for v in agg.values())
         whole = kernel_breakdown(net, im1, im2, 1).get(dom) if nsplit > 1 else None   # same symbol, unsplit batch
-        traffic = None                      # HBM bytes per launch from the committed rocprofv3 PMC passes, if any
-        tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tf):
-            traffic = json.load(open(tf)).get(dom.replace("+scores", ""), {}).get("hbm_bytes_per_launch")
+        pmc = _pmc()                        # HBM bytes per launch from the committed rocprofv3 PMC passes, if any
+        traffic = pmc.get(dom.replace("+scores", ""), {}).get("hbm_bytes_per_launch")
+        step_traffic = pmc.get("_step", {}).get("hbm_bytes_per_16pair_step")
         out = {
             "metric": "frame_pairs_per_sec_352x352_emip_short_fwd", "value": round(value, 3), "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "per_step": {"what": "rank 0, spacing of per-step HIP events on the replay streams (slowest stream per step)",
+                         "ms_median": round(_pct(step_ms, 0.5), 4), "ms_p10": round(_pct(step_ms, 0.1), 4),
+                         "ms_p90": round(_pct(step_ms, 0.9), 4),
+                         "pairs_per_s_median": round(B / _pct(step_ms, 0.5) * 1e3, 1),
+                         "pairs_per_s_p10": round(B / _pct(step_ms, 0.9) * 1e3, 1),
+                         "pairs_per_s_p90": round(B / _pct(step_ms, 0.1) * 1e3, 1)},
             "config": {"workload": "EMIP-short inference forward (CoUpdater.forward), batch=16 352x352 frame pairs "
                                    "per GPU, bf16 storage / f32 accumulate, random-filled weights",
                        "pairs_per_gpu": B, "parallelism": "dp%d (independent replicas, no collective)" % world,
@@ -604,7 +702,12 @@ def main():
                          "launches": cnt, "avg_launch_us": round(ms / cnt * 1e3, 2),
                          "algorithmic_flops_per_launch": round(fl / cnt), "kernel_ms_per_step": round(ms, 3),
                          "share_of_step_kernel_time": round(ms / total_ms, 3),
-                         "rocprofv3_avg_launch_us": rocprof_avg(dom),
+                         "clock": "HIP events on the launch stream, this run (frac, achieved, avg_launch_us)",
+                         "committed_profile": {"rocprofv3_avg_launch_us": rocprof_avg(dom),
+                                               "kernel_stats": _file_stamp(PROFILE_CSV), "traffic": _file_stamp(PMC_JSON)},
+                         "traffic_bytes_per_step": step_traffic,
+                         "compulsory_bytes_per_step": int(COMPULSORY_STEP_BYTES),
+                         "traffic_over_compulsory": (round(step_traffic / COMPULSORY_STEP_BYTES, 1) if step_traffic else None),
                          "note": "launch durations are per kernel in ISOLATION on the sub-batch shapes the graphs "
                                  "replay; in the timed region %d such streams overlap (sum of isolated kernel time "
                                  "%.1f ms vs %.1f ms wall per step)" % (nsplit, total_ms, dt / args.steps * 1e3),
@@ -623,9 +726,10 @@ def main():
                                           "GMFlow all-pairs correlation + softmax expectation, raw correlation "
                                           "written once as [src][tgt], gmflow/matching.py:13-41")}
         out["kernel_breakdown_ms"] = {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}
+        out["parity"] = {"timed_outputs": timed_parity}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], ref_mask = cpu_baseline(sd)
-            out["parity"] = parity_figures(net, margs, sd, ref_mask, dev)
+            out["cpu_baseline"], out["cpu_baseline_8_threads"], ref_mask = cpu_baseline(sd)
+            out["parity"].update(parity_figures(net, margs, sd, ref_mask, dev))
     # Sub-records (driver-timed beside the headline, same JSON line): BASELINE.json configs[2] / [4] = the training step
     # (every rank takes part: its gradient all-reduce is the one real exchange of the path), configs[3] = EMIP-long, and the
     # f32 parity mode's throughput.  A failure here is recorded, never allowed to lose the headline.

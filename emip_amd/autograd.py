@@ -51,6 +51,7 @@ class LinearFn(Function):
             y = ops.gemm(x, wp, bias=b, res=res)
         ctx.save_for_backward(x, weight)
         ctx.wpt, ctx.has_bias, ctx.has_res = wpt, bias is not None, res is not None
+        ctx.bias_param = bias if (bias is not None and bias.is_leaf) else None
         return y
 
     @staticmethod
@@ -69,12 +70,17 @@ class LinearFn(Function):
         if ctx.needs_input_grad[1]:
             n = weight.shape[0]
             kw = weight.numel() // n                      # x may carry zero-padded columns beyond the weight's K
+            # The grouped launch fills dwf / dbf at flush_wgrads(): only a result autograd receives UNTOUCHED may wait for
+            # it.  With padded rows (the 1-channel mask head) or padded K columns (the 340 -> 344 GDFN hidden width) the
+            # slice below is a copy, so those launch now.
+            exact = dy.shape[-1] == n and x.shape[-1] == kw
+            own = (weight if weight.is_leaf else None, ctx.bias_param)
             if want_db:                                    # bias gradient from the dY tiles the weight-gradient GEMM stages
-                dwf, dbf = ops.gemm_tn(dy, x, with_colsum=True)
-                db = dbf[:n].contiguous()
+                dwf, dbf = ops.gemm_tn(dy, x, with_colsum=True, defer=exact, owners=own)
+                db = dbf if exact else dbf[:n].contiguous()
             else:
-                dwf = ops.gemm_tn(dy, x)
-            dw = dwf[:n, :kw].contiguous().view_as(weight)
+                dwf = ops.gemm_tn(dy, x, defer=exact, owners=own)
+            dw = dwf.view_as(weight) if exact else dwf[:n, :kw].contiguous().view_as(weight)
         elif want_db:
             db = colsum_f32(dy)[:weight.shape[0]].contiguous()
         return dx, dw, db, dres, None, None, None, None
@@ -163,6 +169,7 @@ class QSrFn(Function):
         s = ops.conv2d(h, wsr_p, k, k, k, 0, bias=bsr)
         ctx.save_for_backward(h, wq, wsr)
         ctx.cfg = (wq_t, wsr_d, k, bq is not None, bsr is not None)
+        ctx.bq_param = bq if (bq is not None and bq.is_leaf) else None
         return q, s
 
     @staticmethod
@@ -177,10 +184,11 @@ class QSrFn(Function):
             dh = ops.depatchify(pm.view(-1, k * k * C), B, ds.shape[1], ds.shape[2], k, C)
             dh = ops.gemm(dq, wq_t, res=dh, out=dh)                    # + dq Wq, added in the epilogue
         if ctx.needs_input_grad[1]:
+            own = (wq if wq.is_leaf else None, ctx.bq_param)
             if has_bq and ctx.needs_input_grad[2]:
-                dwq, dbq = ops.gemm_tn(dq, h, with_colsum=True)
+                dwq, dbq = ops.gemm_tn(dq, h, with_colsum=True, defer=True, owners=own)
             else:
-                dwq = ops.gemm_tn(dq, h)
+                dwq = ops.gemm_tn(dq, h, defer=True, owners=own)
             dwq = dwq.view_as(wq)
         elif has_bq and ctx.needs_input_grad[2]:
             dbq = colsum_f32(dq)

@@ -6,6 +6,7 @@ drivers do inline before `load_state_dict` (pure host-side dictionary logic, no 
 
   load_for_inference   /root/reference/test.py:81-89, test_long.py:92-100
   load_short_pretrain  /root/reference/train.py:312-337   (segmentation pre-train + official GMFlow weights)
+  load_short_pretrain_ddp  /root/reference/train.py:280-293 (the --multi_gpu branch: the wrapped model's `module.` keys)
   load_long_pretrain   /root/reference/train_long.py:391-406 (short-term weights into Model_long, then freeze them)
   save                 /root/reference/train.py:90,162 (`torch.save(model.state_dict(), path)`; DDP adds `module.`)
 """
@@ -58,6 +59,25 @@ def load_short_pretrain(model, checkpoint, flow_checkpoint=None):
         model_dict.update(flow_dict)
         loaded_flow = sorted(flow_dict)
     model.load_state_dict(model_dict)
+    return sorted(pretrained), loaded_flow
+
+
+def load_short_pretrain_ddp(wrapped, checkpoint, flow_checkpoint=None):
+    """train.py:280-293, the --multi_gpu branch: `wrapped` is the DistributedDataParallel-wrapped model, whose state_dict
+    keys carry `module.`.  Entries of the file that exist under that prefix are taken AS THEY ARE -- this branch has neither
+    the `backbone.pvtv2_en` rename nor the exclusions of the single-GPU branch -- and the official GMFlow checkpoint goes
+    under `module.GMFlow.`."""
+    checkpoint = _read(checkpoint)
+    model_dict = wrapped.state_dict()
+    pretrained = {'module.' + k: v for k, v in checkpoint.items() if 'module.' + k in model_dict}
+    model_dict.update(pretrained)
+    loaded_flow = []
+    if flow_checkpoint is not None:
+        flow = _read(flow_checkpoint)
+        flow_dict = {'module.GMFlow.' + k: v for k, v in flow['model'].items() if 'module.GMFlow.' + k in model_dict}
+        model_dict.update(flow_dict)
+        loaded_flow = sorted(flow_dict)
+    wrapped.load_state_dict(model_dict)
     return sorted(pretrained), loaded_flow
 
 

@@ -118,6 +118,7 @@ class GradReducer:
         if ref.is_cuda:
             from . import ops
             ops.flush_wgrads()              # weight gradients the step has deferred must be on the compute stream first
+            ops.WGRADS.fixup(b.params)      # ... and be what these parameters' .grad holds
         side = self._stream(ref.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(ref.device))

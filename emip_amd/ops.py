@@ -68,6 +68,7 @@ class GradArena:
     def end(self):
         self.active = False
         WGRADS.flush()                       # nothing deferred outlives the step
+        WGRADS.fixup()                       # ... and every deferred result is what its parameter's .grad holds
 
     def zeros(self, shape, device):
         n = 1
@@ -98,13 +99,43 @@ class WgradQueue:
     MAX = 160
 
     def __init__(self):
-        self.items, self.enabled = [], __import__('os').environ.get('EMIP_WGRAD_DEFER', '1') != '0'
+        self.items, self.enabled = [], True
         self.stage = None
+        self.owners = []                # (arena slice, parameter) of every deferred result of this step
+        self.fixed = 0                  # results fixup() had to add by hand (diagnostics / tests)
 
-    def add(self, a, b, c, db, M, N, K, lda, ldb):
+    def add(self, a, b, c, db, M, N, K, lda, ldb, owners=()):
         self.items.append((a, b, c, db, M, N, K, lda, ldb))
+        self.owners += [(t, p) for t, p in owners if t is not None and p is not None]
         if len(self.items) >= self.MAX:
             self.flush()
+
+    def fixup(self, params=None):
+        """A deferred result is written into its arena slice AFTER autograd has taken that (still zero) slice as the
+        parameter's gradient.  That is only the gradient if AccumulateGrad kept the slice itself as `.grad` -- it does for
+        a parameter used once per backward, but a second use of the same weight, a tensor hook or create_graph make autograd
+        sum or clone the zeros out of place, and the result would land in an orphaned slice.  Call after flush(): every
+        result whose parameter's `.grad` is not the slice is added to that `.grad`.  params: restrict to these parameters
+        (a gradient bucket about to leave); owners whose gradient is not assigned yet stay registered."""
+        if not self.owners:
+            return
+        assert not self.items, "fixup() runs behind flush()"
+        keep = []
+        only = None if params is None else {id(p) for p in params}
+        for t, p in self.owners:
+            if only is not None and id(p) not in only:
+                keep.append((t, p))
+                continue
+            g = p.grad
+            if g is None:
+                if params is None:
+                    raise _lib.EmipLibraryError("a deferred weight gradient has no parameter .grad to live in")
+                keep.append((t, p))
+                continue
+            if g.data_ptr() != t.data_ptr() or g.numel() != t.numel():
+                g.add_(t.view_as(g).to(g.dtype))
+                self.fixed += 1
+        self.owners = keep
 
     def flush(self):
         if not self.items:
@@ -722,18 +753,21 @@ def photometric_loss(im, rec, mask, out, weight=1.0, accumulate=False):
     return out
 
 
-def gemm_tn(a, b, with_colsum=False):
+def gemm_tn(a, b, with_colsum=False, defer=False, owners=(None, None)):
     """c[n, k] = sum_m a[m, n] * b[m, k]  (weight gradient: a = dY, b = X) -> f32 [N, K]
-    with_colsum: also return sum_m a[m, n] (the bias gradient) from the same launch"""
+    with_colsum: also return sum_m a[m, n] (the bias gradient) from the same launch
+    defer: the caller hands the returned tensors to autograd AS THEY ARE (no slice, copy or arithmetic on them), so the
+    launch may wait for flush_wgrads(); owners = (weight parameter, bias parameter) whose .grad they become (WgradQueue.fixup)"""
     M, N, lda = rows(a)
     Mb, K, ldb = rows(b)
     assert M == Mb and a.dtype == b.dtype
     if ARENA.active:                   # training step: accumulate into slices of the step's pre-cleared gradient arena
         c = grad_zeros((N, K), a.device)
         db = grad_zeros((N,), a.device) if with_colsum else None
-        if (WGRADS.enabled and a.dtype == torch.bfloat16 and _lib.load().emip_gemm_tn8_eligible(M, N, K, lda, ldb)
+        if (defer and WGRADS.enabled and a.dtype == torch.bfloat16 and _lib.load().emip_gemm_tn8_eligible(M, N, K, lda, ldb)
                 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
-            WGRADS.add(a, b, c, db, M, N, K, lda, ldb)         # launched with the other layers' by flush_wgrads()
+            # launched with the other layers' by flush_wgrads()
+            WGRADS.add(a, b, c, db, M, N, K, lda, ldb, owners=((c, owners[0]), (db, owners[1])))
         else:
             _lib.call("emip_gemm_tn_into", _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, dt_code(a.dtype), _stream())
         return (c, db) if with_colsum else c

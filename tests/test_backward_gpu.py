@@ -271,7 +271,7 @@ def test_deferred_weight_gradients_grouped_launch():
         outs = []
         try:
             for dy, _, x, _, bias in ops_:
-                outs.append(ops.gemm_tn(dy, x, with_colsum=True) if bias else (ops.gemm_tn(dy, x), None))
+                outs.append(ops.gemm_tn(dy, x, with_colsum=True, defer=True) if bias else (ops.gemm_tn(dy, x, defer=True), None))
             assert len(ops.WGRADS.items) == len(shapes)            # nothing has been launched yet
             ops.flush_wgrads()
         finally:

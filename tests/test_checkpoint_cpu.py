@@ -1,5 +1,72 @@
-"""Checkpoint key handling of the reference drivers (train.py:312-337, test.py:81-89, train_long.py:391-406), host only."""
+"""Checkpoint key handling of the reference drivers (train.py:280-293,312-342, test.py:81-89, test_long.py:92-100,
+train_long.py:391-406), host only.  The pin: tests/golden/ckpt_maps.json.gz holds, per scenario, the key map the
+REFERENCE'S OWN STATEMENTS produced (oracle/make_golden_ckpt.py executes those line ranges on key manifests);
+emip_amd/checkpoint.py must produce the same map, the same frozen set, and fail where the reference fails."""
+import gzip
+import json
+import os
+
+import pytest
 import torch
+
+
+def _golden_maps():
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_maps.json.gz")
+    return json.loads(gzip.open(p).read().decode())
+
+
+def _run_ours(name, s, short_manifest, long_manifest):
+    """emip_amd.checkpoint on the stand-in model of the golden generator (values are source tags, not tensors)"""
+    from emip_amd import checkpoint as C
+    from emip_amd.train import freeze_like_reference, freeze_short_term
+    from oracle.make_golden_ckpt import Model
+    ck = {k: "ckpt:" + k for k in s["ckpt"]}
+    flow = {"model": {k: "flow:" + k for k in s["flow"]}} if s.get("flow") is not None else None
+    if name.startswith("train_single"):
+        m = Model(short_manifest)
+        C.load_short_pretrain(m, ck, flow)
+        freeze_like_reference(m)
+    elif name.startswith("train_ddp"):
+        m = Model(short_manifest, "module.")
+        C.load_short_pretrain_ddp(m, ck, flow)
+        freeze_like_reference(m)
+    elif name.startswith("test_long"):
+        m = Model(long_manifest)
+        C.load_for_inference(m, ck, multi_gpu="multi_gpu" in name)
+    elif name.startswith("test_"):
+        m = Model(short_manifest)
+        C.load_for_inference(m, ck, multi_gpu="multi_gpu" in name)
+    else:
+        m = Model(long_manifest)
+        C.load_long_pretrain(m, ck, freeze=False)
+        freeze_short_term(m)
+    return ({k: v for k, v in m.loaded.items() if not v.startswith("init:")},
+            sorted(n for n, p in m.named_parameters() if not p.requires_grad))
+
+
+def test_key_maps_equal_what_the_reference_statements_produce(short_manifest, long_manifest):
+    from oracle.make_golden_ckpt import scenarios
+    gold = _golden_maps()
+    sc = scenarios(short_manifest, long_manifest)
+    assert set(gold) == set(sc) and len(gold) >= 11
+    for name, s in sc.items():
+        exp = gold[name]
+        if "error" in exp:                       # the reference's strict load_state_dict raises: so must this side
+            with pytest.raises((KeyError, RuntimeError)):
+                _run_ours(name, s, short_manifest, long_manifest)
+            continue
+        got_map, got_frozen = _run_ours(name, s, short_manifest, long_manifest)
+        assert got_map == exp["map"], (name, sorted(set(got_map.items()) ^ set(exp["map"].items()))[:6])
+        assert got_frozen == exp["frozen"], (name, sorted(set(got_frozen) ^ set(exp["frozen"]))[:6])
+    # the scenarios are not vacuous: renames, the GMFlow prefix, the long branch's copies and both freeze rules occur
+    m = gold["train_single_pretrain"]["map"]
+    assert any(v.startswith("ckpt:backbone.pvtv2_en.") and k.startswith("backbone.feat_net.pvtv2_en.") for k, v in m.items())
+    assert any(v.startswith("flow:") and k.startswith("GMFlow.") for k, v in m.items())
+    assert not any("mask_downscaling" in k or "something.else" in k for k in m)
+    lm = gold["train_long_from_short"]["map"]
+    assert lm["decoder.conv5.weight"] == lm["short_term.decoder.conv5.weight"] == "ckpt:decoder.conv5.weight"
+    assert gold["test_plain_given_ddp_file"]["map"] == {} and len(gold["test_multi_gpu"]["map"]) == 1438
+    assert len(gold["train_single_full"]["frozen"]) == 123 and all("GMFlow" in n for n in gold["train_single_full"]["frozen"])
 
 
 def _short(model_args):

@@ -121,3 +121,103 @@ def test_bn_running_update_matches_torch():
     ops.bn_running_update(sums, rm, rv, nt, 4 * 9 * 7, 0.1)
     assert torch.allclose(rm, bn.running_mean, atol=1e-6) and torch.allclose(rv, bn.running_var, rtol=1e-5)
     assert int(nt) == int(bn.num_batches_tracked) == 1
+
+
+def _bf16_train_grads(model_args, short_sd, B, defer, arena, seed=7):
+    """every parameter gradient of one bf16 training step's backward (both losses, DropPath forced to fixed factors)"""
+    from emip_amd import nn_base, ops
+    from emip_amd.loss.loss_flow import unFlowLoss
+    from emip_amd.loss.loss_pred import hybrid_e_loss
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    from emip_amd.train import freeze_like_reference
+    nn_base.set_default_dtype(torch.bfloat16)
+    try:
+        net = CoUpdater(model_args)
+        net.load_state_dict(short_sd)
+        net = freeze_like_reference(net.to("cuda:0").train())
+        for m in net.modules():
+            if hasattr(m, "drop_path_rate"):
+                m.drop_path_rate = 0.0
+        im1, im2 = synthetic_pair(B, seed=seed)
+        gt = synthetic_gt(B, seed=seed).cuda()
+        im1, im2 = im1.cuda(), im2.cuda()
+        fl = unFlowLoss()
+        prev, ops.WGRADS.enabled = ops.WGRADS.enabled, defer
+        out = None
+        try:
+            for rep in range(2 if arena else 1):          # the first arena pass only sizes it
+                net.zero_grad(set_to_none=True)
+                if arena:
+                    ops.ARENA.begin(im1.device)
+                try:
+                    with torch.enable_grad():
+                        preds = net(im1, im2)
+                        pair = [torch.cat((preds[1][i], preds[2][i]), 1) for i in range(len(preds[1]))]
+                        loss = hybrid_e_loss(preds[0], gt) + fl.compute_loss(pair, torch.cat((im1, im2), 1))[0]
+                        loss.backward()
+                        ops.flush_wgrads()
+                finally:
+                    ops.ARENA.end()
+            out = {n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None}
+            req = {n for n, p in net.named_parameters() if p.requires_grad}
+        finally:
+            ops.WGRADS.enabled = prev
+        del net
+        torch.cuda.empty_cache()
+        return out, req
+    finally:
+        nn_base.set_default_dtype(torch.float32)
+
+
+def test_bf16_deferred_weight_gradients_equal_the_immediate_ones(model_args, short_sd):
+    """bf16, batch 2 (the default training path: gradient arena, grouped deferred weight gradients, padded GDFN width):
+    EVERY parameter gradient with deferral equals the one without it up to the run-to-run noise of the bf16 path, no
+    trainable gradient that the plain path produces is missing or all zero, and nothing needed a fix-up (every deferred
+    result was the parameter's .grad)."""
+    from emip_amd import ops
+    plain, req = _bf16_train_grads(model_args, short_sd, 2, defer=False, arena=False)
+    plain2, _ = _bf16_train_grads(model_args, short_sd, 2, defer=False, arena=True)
+    ops.WGRADS.fixed = 0
+    got, _ = _bf16_train_grads(model_args, short_sd, 2, defer=True, arena=True)
+    assert ops.WGRADS.fixed == 0 and not ops.WGRADS.owners and not ops.WGRADS.items
+    assert set(got) == set(plain) == set(plain2)
+    zero = [n for n in got if not got[n].any() and plain[n].any()]
+    assert not zero, zero                                   # the advisor's case: ...ffn.project_out.weight stayed zero
+    for n in ("injector.transformer.ffn.project_out.weight", "injector1.transformer.ffn.project_out.weight"):
+        assert got[n].abs().max() > 0, n
+
+    def rel(a, b):
+        return {n: ((a[n] - b[n]).abs().max() / (b[n].abs().max() + 1e-30)).item() for n in b}
+    noise, dev = rel(plain2, plain), rel(got, plain)
+    worst = sorted(((dev[n] / (4.0 * noise[n] + 2e-2), dev[n], noise[n], n) for n in plain), reverse=True)[:3]
+    print("  largest deferred-vs-immediate deviations (ratio to the bound, deviation, run-to-run noise, name):", worst)
+    assert all(dev[n] <= 4.0 * noise[n] + 2e-2 for n in plain), worst
+
+
+def test_deferred_result_of_a_weight_used_twice_is_fixed_up():
+    """WgradQueue.fixup: a Linear weight used TWICE in one backward makes autograd sum the two (still zero) arena slices out
+    of place; the deferred results are then added to the parameter's .grad when the arena ends"""
+    from emip_amd import ops
+    from emip_amd.autograd import LinearFn
+    from emip_amd.nn_base import lin_packs
+    torch.manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(128, 256, device="cuda") * 0.05)
+    b = torch.nn.Parameter(torch.randn(128, device="cuda") * 0.05)
+    x1 = (torch.randn(4096, 256, device="cuda")).to(torch.bfloat16).requires_grad_(True)
+    x2 = (torch.randn(4096, 256, device="cuda")).to(torch.bfloat16).requires_grad_(True)
+    wp, wpt = lin_packs(w, torch.bfloat16)
+    ops.WGRADS.fixed = 0
+    for rep in range(2):
+        w.grad = b.grad = None
+        ops.ARENA.begin(w.device)
+        try:
+            y = LinearFn.apply(x1, w, b, None, wp, wpt) .float().sum() + 2.0 * LinearFn.apply(x2, w, b, None, wp, wpt).float().sum()
+            y.backward()
+        finally:
+            ops.ARENA.end()
+    wf = w.detach().to(torch.bfloat16).float()
+    ref_w = (torch.ones(4096, 128, device="cuda").t() @ x1.detach().float()) + 2.0 * (torch.ones(4096, 128, device="cuda").t() @ x2.detach().float())
+    assert ops.WGRADS.fixed > 0
+    assert ((w.grad - ref_w).abs().max() / ref_w.abs().max()).item() < 1e-2
+    assert ((b.grad - 3.0 * 4096).abs().max() / (3.0 * 4096)).item() < 1e-2
+    del wf

@@ -2,7 +2,11 @@
 """Turn two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; --output-format csv) of `bench.py --no-graph` into
 profiles/pmc_traffic.json: HBM bytes per launch for every kernel symbol, keyed the way bench.py names kernels.
 
-  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> profiles/pmc_traffic.json
+  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> profiles/pmc_traffic.json [forwards]
+
+forwards: the number of 16-pair forwards the profiled command issued (timed + warm-up steps + bench.py's eager measurement
+passes: --steps 2 --warmup 1 -> 3 + 2 = 5); the blocker GEMMs of the measurement passes (the 256x256-tile gemm8 instance on
+8192^3) are taken out, and "_step" = bytes of one 16-pair forward.
 
 gfx950 correction (MI355X_MICROARCH.md, HBM / rocprofv3 section): FETCH_SIZE under-counts wide coalesced reads by 2x,
 so bytes = (2 * FETCH_SIZE_KB + WRITE_SIZE_KB) * 1024.  The first launches of every symbol (warm-up) are included;
@@ -47,6 +51,7 @@ def per_kernel(path, counter):
 
 def main():
     fetch, write, out = sys.argv[1:4]
+    forwards = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     fe, wr = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     res = {}
     for k in sorted(set(fe) | set(wr)):
@@ -67,6 +72,12 @@ def main():
         e["note"] = "(2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts half of wide coalesced reads"
     total = sum(e["hbm_bytes_per_launch"] * e["launches_profiled"] for e in res.values())
     res["_total"] = {"hbm_bytes_all_profiled_launches": int(total), "note": "divide by the forwards profiled (warm-up included)"}
+    if forwards:
+        blockers = sum(e["hbm_bytes_per_launch"] * e["launches_profiled"] for k, e in res.items()
+                       if k.startswith("gemm8_kernel<256, 256") and ", false, false, false, false>" in k and not k.startswith("_"))
+        res["_step"] = {"hbm_bytes_per_16pair_step": int((total - blockers) / forwards), "forwards_profiled": forwards,
+                        "blocker_bytes_removed": int(blockers),
+                        "note": "(_total - blocker GEMMs of bench.py's measurement passes) / forwards"}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out, len(res), "kernels")
 
