@@ -280,6 +280,7 @@ def timed_output_parity(runner, net, margs, sd, im1, im2, dev):
             finally:
                 M.CNN_FIRST = prev
         eager = torch.cat(halves, 0)
+        again = torch.cat([net(im1[i * n:(i + 1) * n], im2[i * n:(i + 1) * n])[0].float() for i in range(runner.splits)], 0)
         nn_base.set_default_dtype(torch.float32)
         try:
             net32 = CoUpdater(margs)
@@ -293,6 +294,11 @@ def timed_output_parity(runner, net, margs, sd, im1, im2, dev):
             "finite": bool(torch.isfinite(mask).all().item()),
             "max_abs_dlogit_vs_eager_bf16_same_subbatches": float("%.3g" % (mask - eager).abs().max().item()),
             "mask_iou_vs_eager_bf16": round(_iou(mask, eager), 5),
+            "eager_bf16_run_to_run": {"max_abs_dlogit": float("%.3g" % (again - eager).abs().max().item()),
+                                      "mask_iou": round(_iou(again, eager), 5),
+                                      "note": "two eager bf16 forwards of the same pairs: f32-atomic statistics move bf16 roundings"},
+            "max_abs_dlogit_eager_bf16_vs_f32_mode": float("%.3g" % (eager - m32).abs().max().item()),
+            "mask_iou_eager_bf16_vs_f32_mode": round(_iou(eager, m32), 5),
             "max_abs_dlogit_vs_f32_mode": float("%.3g" % (mask - m32).abs().max().item()),
             "mask_iou_vs_f32_mode": round(_iou(mask, m32), 5),
             "logit_range_f32_mode": float("%.3g" % m32.abs().max().item())}
@@ -578,11 +584,6 @@ def main():
         raise SystemExit("--gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ["WORLD_SIZE"]))
     if args.dry_run:
         return main_dry(args)
-    if os.environ.get("EMIP_KV_SPLIT"):
-        from emip_amd import ops
-        ops.KV_SPLIT = os.environ["EMIP_KV_SPLIT"] != "0"
-        if int(os.environ["EMIP_KV_SPLIT"]) > 1:
-            ops.KV_SPLIT_MIN_KEYS = int(os.environ["EMIP_KV_SPLIT"])
     if args.workload == "train":
         return main_train(args)
     if args.workload == "long":
@@ -607,7 +608,7 @@ def main():
     net.load_state_dict(sd)
     net = net.to(dev).eval()
 
-    B = int(os.environ.get("EMIP_DIAG_PAIRS", PAIRS_PER_GPU))     # diagnosis only: the reported config is 16
+    B = PAIRS_PER_GPU
     im1, im2 = synthetic_pair(B, seed=edist.pair_seed(1234, rank))
     im1, im2 = im1.to(dev), im2.to(dev)
 

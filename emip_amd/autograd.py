@@ -241,7 +241,7 @@ class SraAttentionFn(Function):
         B, N, C = q.shape
         Lk = kv.shape[1]
         out = torch.empty_like(q)
-        fused = SRA_FUSED_BWD and q.dtype == torch.bfloat16 and Lk <= 128 and q.is_contiguous() and kv.is_contiguous()
+        fused = q.dtype == torch.bfloat16 and Lk <= 128 and q.is_contiguous() and kv.is_contiguous()
         if fused:
             L = ops.sra_attention_lse(q, kv, out, B, heads, N, Lk, scale)
             ctx.save_for_backward(q, kv, out, L)
@@ -267,7 +267,6 @@ class SraAttentionFn(Function):
         return _sra_backward_unfused(ctx, do)
 
 
-SRA_FUSED_BWD = __import__("os").environ.get("EMIP_SRA_FUSED_BWD", "1") != "0"
 
 
 def _sra_backward_unfused(ctx, do):

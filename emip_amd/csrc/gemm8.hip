@@ -646,23 +646,15 @@ extern "C" int emip_gemm8_cfg_stages(int cfg, int lnt) {
 }
 
 // ---- dispatch hooks of emip_gemm_ln / emip_conv2d_splitk (gemm.hip): > 0 = not eligible, the 4-wave body runs -----------
-static int g8_enabled() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("EMIP_GEMM8");      // EMIP_GEMM8=0: A/B against the 4-wave bodies in one process tree
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v;
-}
 namespace emip_internal {
 int gemm8_choice(int M, int N, long K, long lda, long ldw, int K1, bool has_a2, long lda2) {
-    if (!g8_enabled() || M < 1024 || N < 64 || (K % 64) != 0 || (lda % 8) != 0 || (ldw % 8) != 0) return 0;
+    if (M < 1024 || N < 64 || (K % 64) != 0 || (lda % 8) != 0 || (ldw % 8) != 0) return 0;
     if (has_a2 && ((K1 % 64) != 0 || (lda2 % 8) != 0)) return 0;
     if (((long)(M - 1) * lda + K) * 2 >= (1L << 31) || ((long)(N - 1) * ldw + K) * 2 >= (1L << 31)) return 0;
     return pick_cfg(M, N, K);
 }
 int conv8_choice(int M, int Cout, int Cin, int KH, int KW, long a_elems) {
-    if (!g8_enabled() || M < 2048 || Cout < 64 || Cin < 64 || (Cin % 8) != 0 || a_elems * 2 >= (1L << 31) ||
+    if (M < 2048 || Cout < 64 || Cin < 64 || (Cin % 8) != 0 || a_elems * 2 >= (1L << 31) ||
         (long)Cout * KH * KW * Cin * 2 >= (1L << 31))
         return 0;
     return pick_cfg(M, Cout, (long)KH * KW * Cin);

@@ -7,8 +7,6 @@ embed to the stage output (no permutes), every Linear is the MFMA GEMM with bias
 its epilogue, the spatial-reduction conv is an implicit GEMM over non-overlapping patches, and
 softmax(q k^T) v runs in one fused attention kernel whose 121-key K/V tile lives in LDS.
 """
-import os
-
 import torch
 import torch.nn as nn
 
@@ -21,48 +19,20 @@ from ..nn_base import EmipModule, conv_dgrad_pack, f32, lin_packs, pack_conv, pa
 # LayerNorm elimination on the inference path: the three LayerNorms of a block (norm1, norm2 and the one
 # behind the spatial-reduction conv) are not launched at all.  The producer of the residual stream (proj / fc2 GEMM, the sr
 # conv, the patch-embed LayerNorm) accumulates per-row (sum, sum of squares) in its epilogue, gamma is folded into the
-# consumer's weights and beta into its bias when the weights are packed, and the consumer's operand loader feeds
-# (x - mean) * rstd to the MFMA.
+# consumer's weights and beta into its bias when the weights are packed, and the consumer applies the normalisation on its
+# OUTPUT side: LN(x) W^T = rstd (x W^T) - rstd mean colsum(W) (emip_gemm_lne; per tap for the spatial-reduction conv), so the
+# main loops multiply raw rows.  The f32 parity mode keeps the operand-side form (emip_gemm_ln / emip_conv2d_ln).
+# What was measured and dropped along the way (pair launch of q + sr conv, two split-K forms of the sr conv, the encoder on a
+# forked stream, the generic attention kernel for the bf16 stages) lives in tools/experiments/README.md, not here.
 FUSED_LN = True
-# Split-K for the 121-token spatial-reduction convs (emip_conv2d_splitk + emip_rows_finalize): parity-tested, but the f32
-# atomics, the 1.2 MB accumulator to clear and the extra launch cost more than the shorter K walk saves end to end
-# (948 -> 886 pairs/s), so it stays off.
-SPLITK_SR = False
-# ... per stage: split K for the spatial-reduction convs with a reduction ratio >= this (0 = never).  The 8 x 8 conv of stage 1
-# is 31 workgroups walking 64 K tiles (73 us for 2 GFLOP): the one launch of the forward where the shorter walk might pay
-SPLITK_SR_MIN = int(os.environ.get("EMIP_SPLITK_SR_MIN", "0"))
-
-
-def _splitk_sr(sr):
-    return sr > 1 and (SPLITK_SR or (SPLITK_SR_MIN > 0 and sr >= SPLITK_SR_MIN))
-# q projection + spatial-reduction conv of a block hosted by one launch (emip_conv2d_pair)
-PAIR_Q_SR = True
-# ... with the sr conv's long K walk split over workgroups INSIDE that launch: partial tiles meet in an f32 accumulator, the
-# last split of a tile to arrive (a ticket counter) takes the sum back out and runs the epilogue (bias, bf16 store, row
-# statistics).  No finalize launch, no zero-fill: accumulator and tickets are left zero by every launch.  Parity-tested
-# (tests/test_ops_gpu.py::test_conv_pair_with_fused_split_k) but OFF: in an in-call A/B the 16-pair step went from 970 to
-# 900 pairs/s -- the launch gets shorter in isolation, but under four-stream replay the 1.3 M extra f32 atomics and the
-# 4x workgroups per launch cost more than the shorter dependency chain returns (same verdict as the unfused variant; a cap
-# of 2 splits still loses 4 %, 1012 -> 968).  The value is the maximum number of splits.
-PAIR_KSPLIT = int(os.environ.get("EMIP_PAIR_KSPLIT", "0"))        # 0 = off, n = at most n splits
-# Dense GEMMs behind a folded LayerNorm (fc1, kv, the stage-4 q) apply it on the OUTPUT side (emip_gemm_lne):
-# LN(x) W^T = rstd (x W^T) - rstd mean colsum(W).  The operand loader no longer normalises every staged element once per
-# N tile (10x per element for fc1), and the main loop becomes the LDS-DMA one.
-LN_EPILOGUE = os.environ.get("EMIP_LN_EPILOGUE", "1") != "0"
-# bf16: q projection and spatial-reduction conv as two launches of the 8-wave body (emip_gemm8 / emip_conv8 with the per-tap
-# output-side LayerNorm) instead of the pair launch of the 4-wave bodies
-SR_CONV8 = os.environ.get("EMIP_SR_CONV8", "1") != "0"
-# bf16 inference: the dedicated spatial-reduction attention kernel (emip_sra_attention) instead of the generic flash kernel
-SRA_KERNEL = os.environ.get("EMIP_SRA_KERNEL", "1") != "0"
-
+# widest stage whose attention half runs as ONE launch (emip_sra_block: q + attention + proj + residual); the 320-channel
+# stage has too few 128-query workgroups for it at 16 images and takes emip_sra_qattn + the proj GEMM
+SRA_BLOCK_MAXC = 128
+# q projection inside the attention launch (emip_sra_block / emip_sra_qattn).  False = q GEMM + emip_sra_attention, the form
+# stage 4 (sr_ratio 1) always takes; tests/test_sra_block_gpu.py runs a block both ways and compares
+SRA_FUSED = True
 
 _lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
-# fc1 + depthwise + GELU as one kernel where an image fits one workgroup (stages 3 and 4); EMIP_MLP_FC1DW=0: two launches
-MLP_FC1DW = os.environ.get("EMIP_MLP_FC1DW", "1") != "0"
-# q projection + spatial-reduction attention + proj + residual of the inference block in one launch (emip_sra_block)
-SR_CFG = int(os.environ.get("EMIP_SR_CFG", "0"))       # gemm8 configuration of the spatial-reduction conv (0 = the library's choice)
-SRA_BLOCK = os.environ.get("EMIP_SRA_BLOCK", "1") != "0"
-SRA_BLOCK_MAXC = int(os.environ.get("EMIP_SRA_BLOCK_MAXC", "128"))      # wider stages: emip_sra_qattn + the proj GEMM
 
 
 class DWConv(EmipModule):
@@ -164,7 +134,7 @@ class Attention(EmipModule):
         kv = ops.gemm(s, wkv, bias=bkv)                      # [B,h,w,2C]: k = [:C], v = [C:], head hd at hd*64
         N = H * W
         a = torch.empty((B, H, W, C), dtype=dt, device=h.device)
-        if dt == torch.bfloat16 and Lk <= 128 and SRA_KERNEL:
+        if dt == torch.bfloat16 and Lk <= 128:
             ops.sra_attention(q, kv, a, B, heads, N, Lk, self.scale)
         else:
             ops.attention(q, kv, kv[..., C:], a, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
@@ -226,7 +196,7 @@ class Block(EmipModule):
             # column sums of the packed (rounded) weights: the output-side form of the folded LayerNorm (emip_gemm_lne)
             for k in ("q", "kv", "w1"):
                 out["s" + k] = out[k].float().sum(1).contiguous()
-            if sr > 1 and SRA_BLOCK and dt == torch.bfloat16 and ops.sra_block_eligible(a.dim, 121):
+            if sr > 1 and dt == torch.bfloat16 and ops.sra_block_eligible(a.dim, 121):
                 # emip_sra_block reads the q / proj weights in the order its MFMA accumulators have (bits 2, 3 of the row
                 # index swapped inside every 16; for proj also of the column index); the vectors stay in channel order
                 sw = ops.swap23(a.dim, wq.device)
@@ -244,20 +214,12 @@ class Block(EmipModule):
 
     @staticmethod
     def scratch_floats(B, H, W, C, sr):
-        """f32 words of statistics scratch one block needs: [sr-conv rows | x1 rows | x2 rows] x 2 (+ split-K accumulator)"""
+        """f32 words of statistics scratch one block needs: [sr-conv rows | x1 rows | x2 rows] x 2"""
         M = B * H * W
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
-        return (Ms * C if _splitk_sr(sr) else 0) + 2 * (Ms + 2 * M)
+        return 2 * (Ms + 2 * M)
 
-    @staticmethod
-    def shared_scratch_floats(B, H, W, C, sr):
-        """f32 words the blocks of a stage share for the fused split-K of the sr conv: accumulator + one ticket per tile"""
-        if not (sr > 1 and PAIR_Q_SR and PAIR_KSPLIT and not _splitk_sr(sr)):
-            return 0
-        Ms = B * (H // sr) * (W // sr)
-        return Ms * C + ((Ms + 63) // 64) * ((C + 63) // 64)
-
-    def run_fused(self, x, stats, buf, shared=None):
+    def run_fused(self, x, stats, buf):
         """Inference block without LayerNorm launches.  x [B,H,W,C] (updated in place), stats f32 [B*H*W, 2] = (sum, sum of
         squares) of its rows, buf: this block's slice of the stage's ZEROED scratch -> (x, stats of the new rows)."""
         a = self.attn
@@ -266,87 +228,50 @@ class Block(EmipModule):
         N = H * W
         M = B * N
         w = self._folded()
+        bf = dt == torch.bfloat16
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
-        # scratch of the block, one allocation: [split-K accumulator of the sr conv | its row stats | stats of x1 | of x2]
-        o = Ms * C if _splitk_sr(sr) else 0
-        acc_sr = buf[:o].view(Ms, C) if o else None
-        st_sr, st1, st2 = buf[o:o + 2 * Ms], buf[o + 2 * Ms:o + 2 * Ms + 2 * M], buf[o + 2 * Ms + 2 * M:]
-        use_conv8 = sr > 1 and SR_CONV8 and dt == torch.bfloat16 and LN_EPILOGUE and ops.gemm8_enabled() and not _splitk_sr(sr)
-        use_pair = sr > 1 and PAIR_Q_SR and not _splitk_sr(sr) and not use_conv8
-        use_block = SRA_BLOCK and use_conv8 and "qf" in w and ops.sra_block_eligible(C, (H // sr) * (W // sr))
-        if use_block:
-            # spatial-reduction conv -> kv, then q projection + attention + proj + residual in ONE launch (emip_sra_block)
-            s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
-                          out_stats=st_sr, cfg=SR_CFG if C > 64 else 0)
-            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"])
-            if C <= SRA_BLOCK_MAXC:
-                ops.sra_block(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), w["pf"], w["bp"], heads,
-                              a.scale, out_stats=st1)
-            else:       # too few 128-query workgroups at C = 320: q + attention per (image, queries, head), proj as it was
-                att = ops.sra_qattn(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), heads, a.scale)
-                ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)
-        elif use_conv8:
-            # both on the 8-wave LDS-DMA body with the LayerNorm on the output side: q over the raw tokens (column sums),
-            # the spatial-reduction conv over the raw patches (per-tap sums; the statistics ride the operand ring)
-            q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["sq"])
-            s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
-                          out_stats=st_sr, cfg=SR_CFG if C > 64 else 0)
-            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"])
-        elif use_pair:
-            # q projection (as a 1x1 conv over the tokens) and the spatial-reduction conv in ONE launch
-            q = torch.empty((B, H, W, C), dtype=dt, device=x.device)
-            s = torch.empty((B, H // sr, W // sr, C), dtype=dt, device=x.device)
-            ksplit, acc, ticket = 1, None, None
-            if PAIR_KSPLIT and shared is not None and shared.numel() > 0:
-                tiles = ((Ms + 63) // 64) * ((C + 63) // 64)
-                nk = sr * sr * C // (64 if dt == torch.bfloat16 else 32)
-                ksplit = max(1, min(nk // 4, (256 + tiles - 1) // tiles, PAIR_KSPLIT))      # >= 4 K tiles per split, ~256 workgroups
-                acc, ticket = shared[:Ms * C], shared[Ms * C:].view(torch.int32)
-            ops.conv2d_pair(ops.conv_desc(x, w["q"], 1, 1, 0, w["bq"], q, stats, self.norm1.eps,
-                                          colsum=w["sq"] if LN_EPILOGUE else None),
-                            ops.conv_desc(x, w["sr"], sr, sr, 0, w["bsr"], s, stats, self.norm1.eps, out_stats=st_sr,
-                                          acc=acc, ticket=ticket, ksplit=ksplit), dt)
-            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"] if LN_EPILOGUE else None)
-        else:
-            q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["sq"] if LN_EPILOGUE else None)
-        if use_conv8 or use_pair:
-            pass
-        elif sr > 1:
-            # 121 output tokens per image against K = sr*sr*C: split K over workgroups (about 256 in total), f32 atomics
-            tiles = ((Ms + 63) // 64) * ((C + 63) // 64)
-            nk = sr * sr * C // (64 if dt == torch.bfloat16 else 32)
-            ksplit = max(1, min(nk // 2, (256 + tiles - 1) // tiles, 64)) if _splitk_sr(sr) else 1
-            if ksplit > 1:
-                ops.conv2d_splitk(x, w["sr"], sr, sr, sr, 0, w["bsr"], acc_sr, ksplit, ln_stats=stats,
-                                  ln_eps=self.norm1.eps)
-                s = ops.rows_finalize(acc_sr, dt, (B, H // sr, W // sr, C), out_stats=st_sr)
-            else:            # enough output tiles to fill the chip on their own
-                s = ops.conv2d(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps,
-                               out_stats=st_sr)
-            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=w["skv"] if LN_EPILOGUE else None)
+        st_sr, st1, st2 = buf[:2 * Ms], buf[2 * Ms:2 * Ms + 2 * M], buf[2 * Ms + 2 * M:]
+        cs = (lambda k: w["s" + k]) if bf else (lambda k: None)       # bf16: output-side LayerNorm (column sums); f32: loader
+        # ---- attention half: x += proj(softmax(q k^T scale) v)
+        if sr > 1:
+            if bf:   # raw patches on the LDS-DMA ring, LayerNorm per tap on the output side (the statistics ride the ring)
+                s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
+                              out_stats=st_sr)
+            else:
+                s = ops.conv2d(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps, out_stats=st_sr)
+            kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=cs("kv"))
         else:
             s = x
-            kv = ops.gemm(x, w["kv"], bias=w["bkv"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=w["skv"] if LN_EPILOGUE else None)
+            kv = ops.gemm(x, w["kv"], bias=w["bkv"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=cs("kv"))
         Lk = s.shape[1] * s.shape[2]
-        att = None if use_block else torch.empty((B, H, W, C), dtype=dt, device=x.device)
-        if use_block:
-            pass
-        elif dt == torch.bfloat16 and Lk <= 128 and SRA_KERNEL:
-            ops.sra_attention(q, kv, att, B, heads, N, Lk, a.scale)      # keys resident in registers, queries streamed
+        fused = SRA_FUSED and "qf" in w and ops.sra_block_eligible(C, Lk)
+        if fused and C <= SRA_BLOCK_MAXC:
+            # q projection + attention + proj + residual in ONE launch
+            ops.sra_block(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), w["pf"], w["bp"], heads,
+                          a.scale, out_stats=st1)
         else:
-            ops.attention(q, kv, kv[..., C:], att, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
-                          k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
-                          k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
-        if not use_block:
-            ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)                      # x += proj(attn)
+            if fused:
+                # q + attention per (image, queries, head), the proj GEMM as a launch of its own
+                att = ops.sra_qattn(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), heads, a.scale)
+            else:
+                q = ops.gemm(x, w["q"], bias=w["bq"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=cs("q"))
+                att = torch.empty((B, H, W, C), dtype=dt, device=x.device)
+                if bf and Lk <= 128:
+                    ops.sra_attention(q, kv, att, B, heads, N, Lk, a.scale)      # keys resident in registers, queries streamed
+                else:
+                    ops.attention(q, kv, kv[..., C:], att, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
+                                  k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
+                                  k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
+            ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)
+        # ---- Mlp half: x += fc2(GELU(dwconv(fc1(LN(x)))))
         hid = w["w1"].shape[0]
-        if MLP_FC1DW and dt == torch.bfloat16 and LN_EPILOGUE and ops.mlp_fc1dw_eligible(B, H, W, C, hid):
+        if bf and ops.mlp_fc1dw_eligible(B, H, W, C, hid):
             # fc1 + depthwise 3x3 + GELU in one launch, one whole image per workgroup: the fc1 output never leaves the CU
             t = ops.mlp_fc1dw(x, w["w1"], w["b1"], w["sw1"], st1, self.norm2.eps, w["wd"], w["bd"])
         else:
-            t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, colsum=w["sw1"] if LN_EPILOGUE else None)
+            t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, colsum=cs("w1"))
             t = ops.dwconv3x3(t, w["wd"], w["bd"], act=ops.ACT_GELU)
-        ops.gemm(t, w["w2"], bias=w["b2"], res=x, out=x, out_stats=st2)                           # x += mlp(...)
+        ops.gemm(t, w["w2"], bias=w["b2"], res=x, out=x, out_stats=st2)
         return x, st2
 
     def run(self, x):
@@ -461,12 +386,10 @@ class PyramidVisionTransformerV2(EmipModule):
                 # statistics scratch of the whole stage: one allocation, cleared by the patch-embed conv's workgroups
                 a0 = blocks[0].attn
                 per = Block.scratch_floats(x.shape[0], Ho, Wo, a0.dim, a0.sr_ratio)
-                nshared = Block.shared_scratch_floats(x.shape[0], Ho, Wo, a0.dim, a0.sr_ratio)
-                scratch = torch.empty(len(blocks) * per + nshared, dtype=torch.float32, device=x.device)
+                scratch = torch.empty(len(blocks) * per, dtype=torch.float32, device=x.device)
                 x = pe.run(x, out_stats=stats, zero=scratch)
-                shared = scratch[len(blocks) * per:]
                 for j, blk in enumerate(blocks):
-                    x, stats = blk.run_fused(x, stats, scratch[j * per:(j + 1) * per], shared)
+                    x, stats = blk.run_fused(x, stats, scratch[j * per:(j + 1) * per])
             else:
                 x = pe.run(x)
                 if self.training:

@@ -22,16 +22,12 @@ from .motion.gmflow.gmflow import GMFlow
 from .motion.PromptInteract import Injector
 
 
-import os as _os
-# inference: GMFlow's CNN encoder on a side stream beside the PVT backbone.  Measured on MI355X (16 pairs, bf16): one graph
-# 1007 -> 1029 pairs/s, two sub-batch graphs 1073 -> 1056: the two-graph replay already fills the idle phases, so it is off
-# by default (EMIP_FORK_CNN=1 turns it on)
-FORK_CNN = _os.environ.get("EMIP_FORK_CNN", "0") != "0"
 # Order of the two independent encoders at the head of the forward.  emip_amd.graph captures every second sub-batch graph
-# with the GMFlow CNN first (EMIP_STAGGER=0 turns that off): the concurrent streams then do not walk the same phases in
-# lockstep -- one is in the bandwidth-bound CNN while the other is in the PVT stages.
+# with the GMFlow CNN first: the concurrent streams then do not walk the same phases in lockstep -- one is in the
+# bandwidth-bound CNN while the other is in the PVT stages (+1.4 %).  STAGGER = False captures every graph in
+# the same order (tests/test_timed_config_gpu.py runs both orders against each other).
 CNN_FIRST = False
-STAGGER = _os.environ.get("EMIP_STAGGER", "1") != "0"
+STAGGER = True
 
 class CoUpdater(EmipModule):
     def __init__(self, args=None):
@@ -88,13 +84,6 @@ class CoUpdater(EmipModule):
             y = ops.conv2d(x, w0, 3, 3, 1, 1, bias=b0, act=ops.ACT_RELU)
         return ops.conv2d(y, w3, 3, 3, 1, 1, bias=b3)
 
-    def _side_stream(self, device):
-        st = getattr(self, "_side", None)
-        if st is None or st.device != device:
-            st = torch.cuda.Stream(device=device)
-            object.__setattr__(self, "_side", st)
-        return st
-
     def run(self, image1, image2, tail=True):
         """Planar images [B,3,H,W] -> (mask planar f32, flow predictions [2B,2,H,W] list, intermediates).
         tail=False: stop behind the motion collector (`conv_corr`) -- EMIP-long reads the backbone features and the
@@ -108,18 +97,7 @@ class CoUpdater(EmipModule):
             imgs = torch.empty((2 * B,) + tuple(image1.shape[2:]) + (8,), dtype=dt, device=image1.device)
             ops.planar_to_cl(image1.contiguous(), dt, 8, out=imgs[:B])
             ops.planar_to_cl(image2.contiguous(), dt, 8, out=imgs[B:])
-        if FORK_CNN and not torch.is_grad_enabled() and imgs.is_cuda:
-            # The GMFlow CNN encoder does not depend on the PVT backbone: run it on a side stream next to it (ONE fork / join
-            # per forward -- also inside a captured hipGraph), so that the phases of one chain fill the idle ones of the other
-            cur = torch.cuda.current_stream(imgs.device)
-            side = self._side_stream(imgs.device)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                gm = self.GMFlow.backbone.run(imgs)                    # [2B,44,44,128]
-            fea = self.backbone.feat_net.run(imgs)                     # stages 2..4 of both frames
-            cur.wait_stream(side)
-            gm.record_stream(cur)
-        elif CNN_FIRST:
+        if CNN_FIRST:
             gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
             fea = self.backbone.feat_net.run(imgs)
         else:

@@ -67,8 +67,6 @@ class TransformerLayer(EmipModule):
         return LinearFn.apply(x, mod.weight, mod.bias, res, wp, wpt)
 
 
-# inference: the five input projections of a block as one GEMM, the cross attention reading the other half of the batch in place
-FUSED_IN = __import__("os").environ.get("EMIP_GMF_FUSED_IN", "1") != "0"
 
 
 class TransformerBlock(EmipModule):
@@ -152,15 +150,8 @@ class FeatureTransformer(EmipModule):
             shift = blk.self_attn.with_shift
             # one GEMM: q | k | v of the self attention and k | v of the cross attention, whose source is the OTHER frame as it
             # is at block start -- read in place from the other half of the batch (kv_rot = B)
-            if FUSED_IN:
-                big = ops.gemm(c0, blk.fused_in())                               # [2B, n, 5C]
-                ck, cv, ldc5, rot = big[..., 3 * C:], big[..., 4 * C:], 5 * C, B
-            else:                       # three launches: the swapped halves projected separately, then q | k | v
-                kvx = torch.empty((B2, n, 2 * C), dtype=dt, device=c0.device)
-                ops.gemm(c0[:B], wc["kv"], out=kvx[B:])
-                ops.gemm(c0[B:], wc["kv"], out=kvx[:B])
-                big = ops.gemm(c0, ws["qkv"])
-                ck, cv, ldc5, rot = kvx, kvx[..., C:], 2 * C, 0
+            big = ops.gemm(c0, blk.fused_in())                                   # [2B, n, 5C]
+            ck, cv, ldc5, rot = big[..., 3 * C:], big[..., 4 * C:], 5 * C, B
             ldb = big.shape[-1]
             # ---- self attention (no FFN): c0 += LN(merge(attn))
             msg = _window_attention(big, big[..., C:], big[..., 2 * C:], B2, h, w, C, ldb, ldb, ldb, shift,

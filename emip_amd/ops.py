@@ -225,16 +225,12 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=No
     return out
 
 
-DROP_EPILOGUE = __import__('os').environ.get('EMIP_DROP_EPILOGUE', '1') != '0'
-
-
 def gemm_rowscale(a, w, bias, res, rowscale, rs_rows):
     """res + rowscale[m // rs_rows] * (a w^T + bias): the branch of a residual block scaled per sample in the GEMM's epilogue
     (stochastic depth).  Returns None when the launch is not one the 8-wave body takes (the caller then scales separately)."""
     M, K, lda = rows(a)
     N = w.shape[0]
-    if not (DROP_EPILOGUE and a.dtype == torch.bfloat16 and gemm8_enabled()
-            and _lib.load().emip_gemm8_dispatch(M, N, K, lda, K, K, 0, 0)):
+    if not (a.dtype == torch.bfloat16 and _lib.load().emip_gemm8_dispatch(M, N, K, lda, K, K, 0, 0)):
         return None
     out = torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
     _, _, ldr = rows(res)
@@ -242,12 +238,6 @@ def gemm_rowscale(a, w, bias, res, rowscale, rs_rows):
     _lib.call("emip_gemm8_rs", _p(a), None, _p(w), _p(out), _p(bias), _p(res), M, N, K, K, lda, 0, K, N, ldr, ACT_NONE, None,
               None, 0.0, None, None, 0, _p(rowscale), int(rs_rows), 0, _stream())
     return out
-
-
-def gemm8_enabled():
-    """False when EMIP_GEMM8=0 keeps every launch on the 4-wave bodies (A/B calibration)"""
-    import os
-    return os.environ.get("EMIP_GEMM8", "1") != "0"
 
 
 def gemm8(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=None, ln_eps=0.0, colsum=None,
@@ -413,9 +403,6 @@ def layernorm(x, gamma, beta, eps, out=None, res=None, out_stats=None):
     return out
 
 
-GEMM_LN_OUT = __import__('os').environ.get('EMIP_GEMM_LN_OUT', '1') != '0'
-
-
 def gemm_ln_out(a, w, gamma, beta, eps, bias=None, res=None, out=None):
     """res + LayerNorm(a w^T + bias) * gamma + beta over the N <= 128 output columns -- a post-norm Linear: the norm runs in
     the GEMM epilogue (emip_gemm8_lno) where the shape allows, else GEMM + emip_layernorm.  out may alias res."""
@@ -423,7 +410,7 @@ def gemm_ln_out(a, w, gamma, beta, eps, bias=None, res=None, out=None):
     N = w.shape[0]
     if out is None:
         out = torch.empty(a.shape[:-1] + (N,), dtype=a.dtype, device=a.device)
-    if (GEMM_LN_OUT and a.dtype == torch.bfloat16 and gemm8_enabled() and N <= 128 and N % 8 == 0 and K % 64 == 0 and M >= 1024
+    if (a.dtype == torch.bfloat16 and N <= 128 and N % 8 == 0 and K % 64 == 0 and M >= 1024
             and w.is_contiguous() and lda % 8 == 0):
         _, _, ldc = rows(out)
         ldr = rows(res)[2] if res is not None else 0
@@ -435,9 +422,9 @@ def gemm_ln_out(a, w, gamma, beta, eps, bias=None, res=None, out=None):
     return layernorm(msg, gamma, beta, eps, out=out, res=res)
 
 
-KV_SPLIT = True      # emip_attention_splitkv for >= KV_SPLIT_MIN_KEYS keys on grids of < KV_SPLIT_TARGET workgroups
-KV_SPLIT_MIN_KEYS = int(__import__('os').environ.get('EMIP_KV_MIN', '1024'))
-KV_SPLIT_TARGET = int(__import__('os').environ.get('EMIP_KV_TARGET', '512'))      # workgroups to aim at (two per CU)
+# emip_attention_splitkv for >= KV_SPLIT_MIN_KEYS keys on grids of < KV_SPLIT_TARGET workgroups (two per CU)
+KV_SPLIT_MIN_KEYS = 1024
+KV_SPLIT_TARGET = 512
 
 
 def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_bs, o_bs, ldq, ldk, ldv, ldo,
@@ -454,7 +441,7 @@ def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_
     wgs = ((Lq + 127) // 128) * heads * batch * nwin
     if ksplit is not None:
         pass
-    elif not (KV_SPLIT and Lk >= KV_SPLIT_MIN_KEYS and wgs < KV_SPLIT_TARGET):
+    elif not (Lk >= KV_SPLIT_MIN_KEYS and wgs < KV_SPLIT_TARGET):
         ksplit = 1
     else:
         ksplit = max(1, min(ntile // 4, (KV_SPLIT_TARGET + wgs - 1) // wgs, 32))

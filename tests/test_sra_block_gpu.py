@@ -133,7 +133,7 @@ def test_pvt_block_fused_path_uses_it_and_matches_the_unfused_launches():
     x0 = (torch.randn(B, H, W, C, device="cuda") * 1.2).to(torch.bfloat16)
     outs = []
     for flag in (True, False):
-        pvt_v2.SRA_BLOCK = flag
+        pvt_v2.SRA_FUSED = flag
         try:
             x = x0.clone()
             xf = x.float().view(-1, C)
@@ -148,7 +148,7 @@ def test_pvt_block_fused_path_uses_it_and_matches_the_unfused_launches():
             assert ("emip_sra_qattn" in names) == flag and ("emip_sra_attention" in names) != flag, names
             outs.append((y.float().clone(), st.clone()))
         finally:
-            pvt_v2.SRA_BLOCK = True
+            pvt_v2.SRA_FUSED = True
             _lib.profile(None)
     nn_base.set_default_dtype(prev)
     (a, sa), (b, sb) = outs

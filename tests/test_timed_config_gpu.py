@@ -57,19 +57,24 @@ def test_timed_graph_replay_outputs(model_args, short_sd):
         torch.cuda.synchronize()
         mask, fw, bw = runner.outputs()
         mask = mask.float()
-        jitter = (e1 - e2).abs().max().item()
+        jitter, iou_jit = (e1 - e2).abs().max().item(), _iou(e1, e2)
         d_eager = (mask - halves).abs().max().item()
         d_batch = (mask - e1).abs().max().item()
-        d32 = (mask - m32).abs().max().item()
-        iou32, iou_e = _iou(mask, m32), _iou(mask, halves)
-        print(f"  timed replay vs eager 8-pair halves: max |dlogit| {d_eager:.4f} (eager run-to-run {jitter:.4f}), IoU {iou_e:.5f}; "
-              f"vs eager 16-pair batch {d_batch:.4f}; vs f32 mode: max |dlogit| {d32:.3f} on logits up to "
-              f"{m32.abs().max().item():.1f}, IoU {iou32:.4f}")
+        d32, d32_eager = (mask - m32).abs().max().item(), (e1 - m32).abs().max().item()
+        iou32, iou_e, iou32_eager = _iou(mask, m32), _iou(mask, halves), _iou(e1, m32)
+        top = max(1.0, m32.abs().max().item())
+        print(f"  timed replay vs eager 8-pair halves: max |dlogit| {d_eager:.4f}, IoU {iou_e:.5f} (two eager runs of the same "
+              f"batch: {jitter:.4f}, IoU {iou_jit:.5f}); vs eager 16-pair batch {d_batch:.4f}; vs f32 mode: max |dlogit| {d32:.3f} "
+              f"on logits up to {top:.1f}, IoU {iou32:.4f} (eager bf16 vs f32: {d32_eager:.3f}, IoU {iou32_eager:.4f})")
         assert torch.isfinite(mask).all() and mask.shape == (16, 1, 352, 352)
         assert len(fw) == 1 and fw[0].shape == (16, 2, 352, 352) and torch.isfinite(fw[0]).all()
-        # same kernels on the same shapes: what is left is the atomics' summation order feeding bf16 roundings
-        assert d_eager <= max(4.0 * jitter, 0.02) and iou_e > 0.998
-        assert iou32 > 0.985 and d32 < 0.04 * max(1.0, m32.abs().max().item())
+        # Same kernels on the same shapes.  The bf16 mode is not bit-reproducible from run to run: the row statistics of the
+        # residual stream and the MDTA Gram matrices are summed with f32 atomics, their last bits move bf16 roundings, and 52
+        # residual blocks decorrelate the rounding noise (measured: two EAGER runs of one batch differ by ~0.3 on logits of
+        # +-8, IoU ~0.985).  So the replay must sit inside that band -- as close to an eager run as eager runs are to each
+        # other -- and as close to the f32 parity mode as the eager bf16 forward is.
+        assert d_eager <= 1.5 * jitter + 0.05 and iou_e >= iou_jit - 0.01
+        assert iou32 >= iou32_eager - 0.01 and iou32 > 0.96 and d32 <= 1.5 * d32_eager + 0.05 and d32 < 0.08 * top
     finally:
         nn_base.set_default_dtype(torch.float32)
 
@@ -101,21 +106,25 @@ BF16_STAGE_BOUNDS = {"pvt_s2": 0.08, "pvt_s3": 0.08, "pvt_s4": 0.08, "gm": 0.08,
 
 
 def test_bf16_stage_error_table(model_args, short_sd, golden):
-    """where the bf16 mode's 0.2 on the mask logits comes from: every stage against the reference's fixture"""
+    """where the bf16 mode's 0.2 on the mask logits comes from: every stage against the reference's fixture (relative to the
+    stage's largest value), the same for a second bf16 run (run-to-run spread of the bf16 mode itself) and for the f32 mode"""
     import json
     import os
     from emip_amd import nn_base
     try:
         g = golden("short_eval_b1.npz")
         im1, im2 = synthetic_pair(1, seed=1234)
-        t16 = stage_table(_net(model_args, short_sd, torch.bfloat16), g, im1, im2)
+        n16 = _net(model_args, short_sd, torch.bfloat16)
+        t16 = stage_table(n16, g, im1, im2)
+        t16b = stage_table(n16, g, im1, im2)
         t32 = stage_table(_net(model_args, short_sd, torch.float32), g, im1, im2)
-        print("  stage        bf16      f32")
+        print("  stage        bf16    bf16 (2nd run)   f32")
         for k in t16:
-            print(f"  {k:10s} {t16[k]:.5f}  {t32[k]:.2e}")
+            print(f"  {k:10s} {t16[k]:.5f}  {t16b[k]:.5f}  {t32[k]:.2e}")
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         if os.path.isdir(out):
-            json.dump({"bf16": t16, "f32": t32}, open(os.path.join(out, "bf16_stage_errors.json"), "w"), indent=1)
+            json.dump({"bf16": t16, "bf16_second_run": t16b, "f32": t32}, open(os.path.join(out, "bf16_stage_errors.json"), "w"),
+                      indent=1)
         assert all(v < 1e-3 for v in t32.values()), t32
         bad = {k: (v, BF16_STAGE_BOUNDS[k]) for k, v in t16.items() if v >= BF16_STAGE_BOUNDS[k]}
         assert not bad, bad
