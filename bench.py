@@ -356,7 +356,7 @@ F_ALG_TRAIN_PAIR_GFLOP = 702.0   # fwd F + dgrad where a
 F_ALG_LONG_FRAME_GFLOP = 270.63 + 10.0 - 2.20 - 3.46 - 0.86 - 1.23
 
 
-def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev):
+def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allreduce", comm="f32"):
     """BASELINE.json configs[2] / configs[4]: one EMIP-short training step (forward, hybrid_e_loss + unFlowLoss, backward,
     bucketed gradient all-reduce over RCCL when N > 1, fused clamp + AdamW) on B synthetic pairs per GPU in bf16."""
     from emip_amd import _lib, dist as edist, nn_base
@@ -374,7 +374,8 @@ def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev):
     net = freeze_like_reference(net.to(dev).train())
     broadcast_parameters(net)
     opt = build_optimizer(net)
-    red = GradReducer(trainable(net)) if world > 1 else None
+    red = (GradReducer(trainable(net), algo=algo, comm_dtype=torch.bfloat16 if comm == "bf16" else None)
+           if world > 1 else None)
     im1, im2 = synthetic_pair(B, seed=edist.pair_seed(1234, rank))
     gt = synthetic_gt(B, seed=edist.pair_seed(99, rank))
     im1, im2, gt = im1.to(dev), im2.to(dev), gt.to(dev)
@@ -397,7 +398,10 @@ def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev):
         "config": {"workload": "EMIP-short training step (fwd + hybrid_e_loss + unFlowLoss + bwd + clamp/AdamW), "
                                "batch=%d 352x352 pairs per GPU, bf16 storage / f32 accumulate and f32 master "
                                "weights, DropPath 0.1, GMFlow frozen" % B,
-                   "pairs_per_gpu": B, "parallelism": "dp%d (bucketed all-reduce over RCCL)" % world},
+                   "pairs_per_gpu": B,
+                   "parallelism": "dp%d (bucketed gradient exchange over RCCL: %s, %s on the wire)" % (
+                       world, "one all-reduce per 64-MB bucket" if algo == "allreduce" else
+                       "direct reduce-scatter + all-gather on the xGMI mesh", comm)},
         "achieved_TFLOPs_per_gpu": round(value / world * F_ALG_TRAIN_PAIR_GFLOP / 1e3, 1),
         "frac_of_bf16_mfma_peak": round(value / world * F_ALG_TRAIN_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
         "flops_convention": "702 GFLOP per pair (SURVEY.md 8d)",
@@ -413,7 +417,7 @@ def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev):
 def main_train(args):
     """--workload train: reported beside, never instead of, the inference headline."""
     world, rank, dev, dist, red_dev = _dist_setup()
-    rec = measure_train(args.pairs or 32, args.steps, args.warmup, world, rank, dev, dist, red_dev)
+    rec = measure_train(args.pairs or 32, args.steps, args.warmup, world, rank, dev, dist, red_dev, args.dp_algo, args.dp_comm)
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if dist is not None:
@@ -576,6 +580,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="sub-batches replayed concurrently on separate HIP streams")
     ap.add_argument("--no-sub", action="store_true", help="skip the train / long / f32 sub-records of the default run")
+    ap.add_argument("--dp-algo", choices=("allreduce", "direct"), default="allreduce",
+                    help="train workload, N > 1: gradient exchange of emip_amd.dp.GradReducer")
+    ap.add_argument("--dp-comm", choices=("f32", "bf16"), default="f32", help="... and its transport dtype")
     ap.add_argument("--dry-run", action="store_true", help="no GPU: exercise the N-rank launch and timing plumbing only")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -740,7 +747,7 @@ def main():
             del runner
         torch.cuda.empty_cache()
         try:
-            sub["train"] = measure_train(32, 6, 4, world, rank, dev, dist, red_dev)
+            sub["train"] = measure_train(32, 6, 4, world, rank, dev, dist, red_dev, args.dp_algo, args.dp_comm)
         except Exception as e:                                   # noqa: BLE001
             sub["train"] = {"error": repr(e)[:300]}
         if world == 1:

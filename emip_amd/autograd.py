@@ -77,9 +77,11 @@ class LinearFn(Function):
             own = (weight if weight.is_leaf else None, ctx.bias_param)
             if want_db:                                    # bias gradient from the dY tiles the weight-gradient GEMM stages
                 dwf, dbf = ops.gemm_tn(dy, x, with_colsum=True, defer=exact, owners=own)
-                db = dbf if exact else dbf[:n].contiguous()
+                db = dbf[:n] if exact else dbf[:n].contiguous()       # (a fresh view object: see below)
             else:
                 dwf = ops.gemm_tn(dy, x, defer=exact, owners=own)
+            # autograd keeps a returned gradient AS the parameter's .grad only if nothing else holds the tensor object; the
+            # deferral queue holds dwf / dbf themselves, so fresh views go out (a held object would be cloned -- of zeros)
             dw = dwf.view_as(weight) if exact else dwf[:n, :kw].contiguous().view_as(weight)
         elif want_db:
             db = colsum_f32(dy)[:weight.shape[0]].contiguous()
@@ -190,6 +192,7 @@ class QSrFn(Function):
             else:
                 dwq = ops.gemm_tn(dq, h, defer=True, owners=own)
             dwq = dwq.view_as(wq)
+            dbq = dbq[:] if dbq is not None else None          # fresh view objects, as in LinearFn.backward
         elif has_bq and ctx.needs_input_grad[2]:
             dbq = colsum_f32(dq)
         if ctx.needs_input_grad[3]:

@@ -134,7 +134,105 @@ __global__ __launch_bounds__(256) void bn_running_kernel(const double* __restric
     rvar[c] = rvar[c] * (1.f - momentum) + (float)unb * momentum;
 }
 
+// ---- data-parallel gradient buckets ----------------------------------------------------------------------------------------
+// The gradient all-reduce of the training step (/root/reference/train.py:279: DDP's flat buckets) moves CONTIGUOUS buckets;
+// the gradients are ~1 300 separate f32 tensors.  One launch per bucket gathers them into its slice of the flat transport
+// buffer (f32, or bf16 on the wire), one launch per step scatters the reduced values back into the .grad tensors times
+// 1 / world.  Tables as above: GradRec per tensor, blockmap (record, chunk), the gradient pointers in their own array.
+struct GradRec {
+    long off;             // element offset of the tensor inside the flat buffer
+    long n;
+};
+
+template <bool PACK, bool BF>
+__global__ __launch_bounds__(256) void grad_bucket_kernel(const GradRec* __restrict__ recs, const int2* __restrict__ blockmap,
+                                                          float* const* __restrict__ gptrs, void* __restrict__ flat,
+                                                          float scale) {
+    const int2 bm = blockmap[blockIdx.x];
+    const GradRec r = recs[bm.x];
+    float* g = gptrs[bm.x];
+    if (!PACK && g == nullptr) return;                    // a parameter without a gradient this step keeps none
+    const long base = (long)bm.y * CHUNK;
+#pragma unroll
+    for (int it = 0; it < CHUNK / 1024; ++it) {
+        const long i = base + it * 1024 + threadIdx.x * 4;
+        if (i >= r.n) return;
+        const long f = r.off + i;
+        float v[4];
+        if (PACK) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (g != nullptr && i + j < r.n) ? g[i + j] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i + j < r.n) {
+                    if (BF) reinterpret_cast<bf16_t*>(flat)[f + j] = (bf16_t)v[j];
+                    else reinterpret_cast<float*>(flat)[f + j] = v[j];
+                }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i + j < r.n)
+                    g[i + j] = scale * (BF ? (float)reinterpret_cast<const bf16_t*>(flat)[f + j]
+                                           : reinterpret_cast<const float*>(flat)[f + j]);
+        }
+    }
+}
+
+// out[i] = sum_w in[w][i] with f32 accumulation (the reduce step of the direct reduce-scatter: shard i of every rank)
+template <bool BF>
+__global__ __launch_bounds__(256) void shard_sum_kernel(const void* __restrict__ in, void* __restrict__ out, int world,
+                                                        long chunk) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < chunk; i += (long)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int w = 0; w < world; ++w)
+            a += BF ? (float)reinterpret_cast<const bf16_t*>(in)[w * chunk + i] : reinterpret_cast<const float*>(in)[w * chunk + i];
+        if (BF) reinterpret_cast<bf16_t*>(out)[i] = (bf16_t)a;
+        else reinterpret_cast<float*>(out)[i] = a;
+    }
+}
+
 }  // namespace
+
+// recs: device array of {element offset inside flat, element count} (2 x 8 bytes) per gradient tensor, blockmap: device int2
+// [nblocks] = (record, chunk of emip_adamw_chunk() elements), gptrs: device array of the tensors' f32 pointers (null = no
+// gradient: packs zeros / is skipped on the way back).  flat: the transport buffer, f32 or (flat_bf16) bf16.
+extern "C" int emip_grad_pack(const void* recs, const void* blockmap, const void* gptrs, int nblocks, void* flat,
+                              int flat_bf16, void* stream) {
+    EMIP_REQUIRE(recs && blockmap && gptrs && flat && nblocks > 0);
+    static_assert(sizeof(GradRec) == 16, "host-side table layout");
+    if (flat_bf16)
+        hipLaunchKernelGGL((grad_bucket_kernel<true, true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const GradRec*)recs,
+                           (const int2*)blockmap, (float* const*)gptrs, flat, 1.f);
+    else
+        hipLaunchKernelGGL((grad_bucket_kernel<true, false>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream, (const GradRec*)recs,
+                           (const int2*)blockmap, (float* const*)gptrs, flat, 1.f);
+    return emip_launch_status();
+}
+
+// the way back: gradient tensor <- scale * flat slice (scale = 1 / world: the mean of the replicas' gradients)
+extern "C" int emip_grad_unpack(const void* recs, const void* blockmap, const void* gptrs, int nblocks, const void* flat,
+                                int flat_bf16, float scale, void* stream) {
+    EMIP_REQUIRE(recs && blockmap && gptrs && flat && nblocks > 0);
+    if (flat_bf16)
+        hipLaunchKernelGGL((grad_bucket_kernel<false, true>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream,
+                           (const GradRec*)recs, (const int2*)blockmap, (float* const*)gptrs, const_cast<void*>(flat), scale);
+    else
+        hipLaunchKernelGGL((grad_bucket_kernel<false, false>), dim3(nblocks), dim3(256), 0, (hipStream_t)stream,
+                           (const GradRec*)recs, (const int2*)blockmap, (float* const*)gptrs, const_cast<void*>(flat), scale);
+    return emip_launch_status();
+}
+
+// out [chunk] = sum over the `world` rows of in [world, chunk], accumulated in f32; both in f32 or both in bf16
+extern "C" int emip_shard_sum(const void* in, void* out, int world, long chunk, int is_bf16, void* stream) {
+    EMIP_REQUIRE(in && out && world > 0 && chunk > 0);
+    long blocks = (chunk + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (is_bf16)
+        hipLaunchKernelGGL((shard_sum_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, world, chunk);
+    else
+        hipLaunchKernelGGL((shard_sum_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, in, out, world, chunk);
+    return emip_launch_status();
+}
 
 // recs: device array of RepackRec (see above; 88 bytes each), blockmap: device int2 [nblocks] = (record, chunk) with chunks
 // of emip_repack_chunk() dst elements.

@@ -591,6 +591,22 @@ int emip_repack_chunk(void);
 int emip_bn_running_update(const double* sums, float* running_mean, float* running_var, long long* tracked, long n,
                            float momentum, int C, void* stream);
 
+/* ---- data-parallel gradient buckets (train.py:279: DistributedDataParallel's flat gradient buckets; here the exchange is
+ * emip_amd/dp.py over torch.distributed = RCCL) ------------------------------------------------------------------------------
+ * emip_grad_pack: gather the f32 gradient tensors of one bucket into their slices of the flat transport buffer (f32, or bf16
+ * when flat_bf16) in one launch.  recs: device array of 16-byte records {long offset_in_flat; long n;}, blockmap: device
+ * int2[nblocks] = (record, chunk of emip_adamw_chunk() elements), gptrs: device array of the tensors' f32 pointers (a null
+ * pointer packs zeros: a parameter that took no part in this step).
+ * emip_grad_unpack: the way back after the collective, gradient <- scale * flat slice (scale = 1 / world: DDP's mean); null
+ * pointers are skipped.  One launch for all buckets.
+ * emip_shard_sum: out[chunk] = sum over the rows of in[world][chunk] accumulated in f32 (both f32, or both bf16): the reduce
+ * step of the direct reduce-scatter (all-to-all, local sum, all-gather) on the fully connected xGMI mesh. */
+int emip_grad_pack(const void* recs, const void* blockmap, const void* gptrs, int nblocks, void* flat, int flat_bf16,
+                   void* stream);
+int emip_grad_unpack(const void* recs, const void* blockmap, const void* gptrs, int nblocks, const void* flat, int flat_bf16,
+                     float scale, void* stream);
+int emip_shard_sum(const void* in, void* out, int world, long chunk, int is_bf16, void* stream);
+
 /* ---- calibration switches: libemip_hip_tuning.so ONLY (make -C emip_amd/csrc tuning, -DEMIP_TUNING) ----------------------
  * Tile / ring-depth overrides and work-skipping ablations (no stores / no MFMA / no loads) for tools/.  The product
  * library libemip_hip.so does not contain them (bench.py checks), so nothing a benchmark runs can skip work. */
