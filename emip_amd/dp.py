@@ -141,8 +141,10 @@ class GradReducer:
             self._tables = dict(
                 recs=torch.frombuffer(recs, dtype=torch.uint8).clone().to(dev),
                 bmap=torch.tensor(bmap, dtype=torch.int32).to(dev), nrec=rec,
-                gdev=torch.zeros(rec, dtype=torch.int64, device=dev), ghost=torch.zeros(rec, dtype=torch.int64).pin_memory(),
-                gev=None)
+                gdev=torch.zeros(rec, dtype=torch.int64, device=dev),
+                # pinned staging of the gradient addresses, two copies used in turn per bucket: the upload that last read a
+                # copy is two uploads old when it is rewritten, so waiting for its event never stalls the host
+                ghost=[torch.zeros(rec, dtype=torch.int64).pin_memory() for _ in range(2)], gev={}, turn={})
 
     def _ensure(self, dev):
         if self._flat is None or self._flat.device != dev:
@@ -189,12 +191,15 @@ class GradReducer:
         ptrs = [0 if p.grad is None else p.grad.data_ptr() for p in b.params]
         if ptrs != b.ptrs:                  # steady state: the gradient arena hands out the same addresses every step
             assert all(p.grad is None or (p.grad.dtype == torch.float32 and p.grad.is_contiguous()) for p in b.params)
-            if t["gev"] is not None:
-                t["gev"].synchronize()      # the previous upload has read the pinned staging array (long done)
-            t["ghost"][b.rec0:b.rec0 + len(ptrs)] = torch.tensor(ptrs, dtype=torch.int64)
-            t["gdev"][b.rec0:b.rec0 + len(ptrs)].copy_(t["ghost"][b.rec0:b.rec0 + len(ptrs)], non_blocking=True)
-            t["gev"] = torch.cuda.Event()
-            t["gev"].record()
+            k = t["turn"][b.rec0] = t["turn"].get(b.rec0, 0) ^ 1
+            ev = t["gev"].get((b.rec0, k))
+            if ev is not None:
+                ev.synchronize()            # the upload that read this copy two uploads ago (long done)
+            host = t["ghost"][k][b.rec0:b.rec0 + len(ptrs)]
+            host.copy_(torch.tensor(ptrs, dtype=torch.int64))
+            t["gdev"][b.rec0:b.rec0 + len(ptrs)].copy_(host, non_blocking=True)
+            ev = t["gev"][(b.rec0, k)] = torch.cuda.Event()
+            ev.record()
             b.ptrs = ptrs
         if b.nblk:
             _lib.call("emip_grad_pack", t["recs"].data_ptr(), t["bmap"].data_ptr() + 8 * b.blk0, t["gdev"].data_ptr(), b.nblk,

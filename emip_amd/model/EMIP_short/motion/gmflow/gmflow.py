@@ -88,8 +88,17 @@ class GMFlow(EmipModule):
         c0 = self.transformer.run(c0, h, w, splits)
 
         # ---- global correlation + softmax -> correspondence (both directions)
-        grid = grid_values(h, w, dt, a.device)
         corr = torch.empty((B, n, n), dtype=dt, device=a.device)
+        if dt == torch.bfloat16 and C == 128:
+            # one launch for both directions (emip_match): batch z < B = frame 1 against frame 2 with the raw correlation written
+            # out, z >= B the reverse; the flow leaves the kernel as f32 [2B, h, w, 2]
+            if not flows:
+                ops.match(c0[:B], c0[B:], w, C ** -0.5, scores=corr)
+                self.last = dict(tokens=c0)
+                return [], corr
+            flow = ops.match(c0, c0, w, C ** -0.5, scores=corr, kv_rot=B).view(2 * B, h, w, 2)
+            return self._finish(c0, flow, corr, B, h, w, C)
+        grid = grid_values(h, w, dt, a.device)
         o = torch.empty((2 * B, n, 32), dtype=torch.float32, device=a.device)
         common = dict(batch=B, heads=1, nwin=1, Lq=n, Lk=n, D=C, DV=32, q_bs=n * C, k_bs=n * C, v_bs=0, o_bs=n * 32,
                       ldq=C, ldk=C, ldv=32, ldo=32, scale=C ** -0.5)
@@ -99,6 +108,11 @@ class GMFlow(EmipModule):
             return [], corr
         ops.attention(c0[B:], c0[:B], grid, o[B:], **common)
         flow = ops.corresp_to_flow(o, 2 * B, h, w, True)      # f32 [2B,h,w,2]
+        return self._finish(c0, flow, corr, B, h, w, C)
+
+    def _finish(self, c0, flow, corr, B, h, w, C):
+        """flow propagation + convex upsampling behind the matching (gmflow.py:130-155)"""
+        dt = self.cdtype
         preds = []
         if self.training:
             preds.append(ops.bilinear_planar(flow, 0, 2, 8 * h, 8 * w, True, mul=8.0))
@@ -112,7 +126,7 @@ class GMFlow(EmipModule):
                    self.upsampler[2].bias),
             lambda p, q, r, s: (pack_conv(p, dt, cin_pad=cin, perm=perm), f32(q),
                                 pack_linear(r.reshape(r.shape[0], -1), dt), f32(s)))
-        u = torch.empty((2 * B, h, w, cin), dtype=dt, device=a.device)
+        u = torch.empty((2 * B, h, w, cin), dtype=dt, device=c0.device)
         ops.copy_cols(c0, 0, C, u, 0)
         ops.copy_cols(flow, 0, 2, u, C, 8)
         u = ops.conv2d(u, w0, 3, 3, 1, 1, bias=b0, act=ops.ACT_RELU)

@@ -193,6 +193,8 @@ class FeatureFlowAttention(EmipModule):
                                      lambda a, b, c, d: (pack_linear(a, dt), f32(b), pack_linear(c, dt), f32(d)))
         q = ops.gemm(feat, wq, bias=bq)
         k = ops.gemm(q, wk, bias=bk)
+        if dt == torch.bfloat16 and C == 128:       # the flow itself is the value: one launch, no padded value / output buffers
+            return ops.match(q, k, w, C ** -0.5, v=flow.reshape(N, n, 2), sub_grid=False).view(N, h, w, 2)
         v = torch.empty((N, n, 32), dtype=dt, device=feat.device)
         ops.copy_cols(flow.view(N * n, 2), 0, 2, v.view(N * n, 32), 0, 32)
         o = torch.empty((N, n, 32), dtype=torch.float32, device=feat.device)

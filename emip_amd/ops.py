@@ -458,6 +458,25 @@ def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_
     return out
 
 
+def match(q, k, W, scale, v=None, scores=None, kv_rot=0, sub_grid=True):
+    """emip_match: q, k bf16 [Z, n, 128] (unit channel stride), v f32 [Z, n, 2] or None (= the pixel grid of width W),
+    scores bf16 [Zs, n, n] or None -> f32 [Z, n, 2]; keys / values of batch z come from batch (z + kv_rot) mod Z"""
+    _dev(q)
+    Z, n, C = q.shape
+    assert C == 128 and k.shape == q.shape and q.dtype == k.dtype == torch.bfloat16
+    assert q.stride(2) == 1 and k.stride(2) == 1
+    out = torch.empty((Z, n, 2), dtype=torch.float32, device=q.device)
+    Zs = 0
+    if scores is not None:
+        Zs = scores.shape[0]
+        assert scores.shape == (Zs, n, n) and scores.dtype == torch.bfloat16 and scores.is_contiguous()
+    if v is not None:
+        assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == Z * n * 2
+    _lib.call("emip_match", _p(q), _p(k), _p(v), _p(scores), _p(out), Z, Zs, n, int(W), q.stride(1), k.stride(1), q.stride(0),
+              k.stride(0), int(kv_rot), float(scale), int(sub_grid), _stream())
+    return out
+
+
 def sra_attention(q, kv, out, batch, heads, Lq, Lk, scale):
     """emip_sra_attention (bf16): q [B,Lq,C], kv [B,Lk,2C] (k | v), out [B,Lq,C], C = heads * 64, Lk <= 128"""
     _dev(q)

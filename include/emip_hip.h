@@ -236,6 +236,16 @@ int emip_attention_rot(const void* Q, const void* K, const void* V, void* O, voi
                        const int* k_rows, const int* q_gid, const int* k_gid, float scale, int o_f32, int ksplit, float* ws,
                        int kv_batch_rot, int dtype, void* stream);
 
+/* GMFlow global matching (gmflow/matching.py:8-41) and flow propagation (gmflow/transformer.py:503-533) on one kernel built
+ * for the shape (bf16, D = 128, two value columns): Out[z][q] = sum_k softmax_k(scale <Q[z][q], K[zk][k]>) v[k] (- the query's
+ * own pixel when sub_grid), zk = (z + kv_rot) mod Z.  Q, K: bf16 [Z][n][128] with row strides ldq / ldk and batch strides
+ * q_bs / k_bs (elements); V: f32 [Z][n][2] indexed like the keys, or NULL = the pixel grid (x = k mod W, y = k / W:
+ * geometry.py:5-21); S: bf16 [Zs][n][n] receives the raw correlation scale * q.k of the batches z < Zs, row q, column k -- the
+ * volume matching.py:18-20 returns (permuted) and model.py:96 hands to conv_corr; Out: f32 [Z][n][2].  Both matching
+ * directions are ONE launch (Z = 2B, kv_rot = B, Zs = B).  64 <= ... n <= 2048, n % 4 == 0. */
+int emip_match(const void* Q, const void* K, const float* V, void* S, float* Out, int Z, int Zs, int n, int W, long ldq,
+               long ldk, long q_bs, long k_bs, int kv_rot, float scale, int sub_grid, void* stream);
+
 /* MDTA channel attention matrix: L2-normalise q,k over pixels, 64x64 Gram per head, * temperature, softmax.
  * PromptInteract.py:423-428.  ws: f32 [B*heads*(4096+128)] scratch; attn out: T [B][heads][64][64]. */
 int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K, long ldk, long k_bs, const float* temperature,

@@ -98,9 +98,13 @@ def test_gradients_do_not_depend_on_the_arena(model_args, short_sd):
     # a row; a conv bias in front of a BatchNorm), so the yardstick is the run-to-run deviation of the SAME path (f32 atomics
     # order only), taken as the largest of three plain-path pairs: a single pair under-estimates it for some parameter in
     # about one run out of five
-    worst = sorted(((dev[n] / (5.0 * noise[n] + 5e-3), dev[n], noise[n], n) for n in ref), reverse=True)[:3]
+    # ... and the floor is what ONE flipped ReLU / BatchNorm mask behind conv_corr.0 moves a gradient by: the plain runs repeat
+    # their allocation addresses (hence, mostly, their atomic orders), an arena run does not, so a flip can show in the arena
+    # run alone -- seen once at 9.6e-3 on a PVT norm weight whose three plain runs agreed to 1e-5 (tools/dbg_arena.py: in
+    # isolation every deviating parameter deviates by its own run-to-run noise, none systematically)
+    worst = sorted(((dev[n] / (5.0 * noise[n] + 1.5e-2), dev[n], noise[n], n) for n in ref), reverse=True)[:3]
     print("  largest arena-vs-plain deviations (ratio to the bound, relative deviation, run-to-run noise, name):", worst)
-    assert all(dev[n] <= 5.0 * noise[n] + 5e-3 for n in ref), worst
+    assert all(dev[n] <= 5.0 * noise[n] + 1.5e-2 for n in ref), worst
     # views handed out are zero on arrival even right after a step that filled them
     ops.ARENA.begin(im1.device)
     z = ops.grad_zeros((1000, 777), im1.device)
