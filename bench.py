@@ -71,6 +71,11 @@ def _launch_info(lib, name, a):
         # fc1 as a GEMM + 9 taps per hidden element; tokens in, weights once, activated hidden tensor out (the fc1 output
         # itself never leaves the CU, so it is not algorithmic traffic of this kernel)
         return 2.0 * M * N * K + 18.0 * M * N, "mlp_fc1dw_kernel", 2.0 * (M * K + N * K + M * N) + 8.0 * M + 44.0 * N
+    if name == "emip_match":              # (Q, K, V, S, Out, Z, Zs, n, W, ldq, ldk, q_bs, k_bs, rot, scale, sub, stream)
+        Z, Zs, n = a[5], a[6], a[7]
+        # features in once as queries and once as keys, the raw correlation of the forward direction out once, flows out
+        byt = 2.0 * (2 * Z * n * 128 + Zs * n * n) + 8.0 * Z * n * (2 if a[2] else 1)
+        return 2.0 * Z * n * n * (128 + 2), "match_kernel" + ("+scores" if Zs else ""), byt
     if name in ("emip_attention", "emip_attention_splitkv", "emip_attention_rot"):      # splitkv: + (ksplit, workspace); rot: + kv_rot
         batch, heads, nwin, Lq, Lk, D, DV = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
         dv = 2 if DV == 32 else DV                          # DV=32 carries a 2-channel value (flow / pixel grid)
@@ -178,6 +183,8 @@ def rocprof_avg(key):
     import re
     if not os.path.exists(PROFILE_CSV):
         return None
+    if key.startswith("match_kernel"):
+        key = "match_kernel<true>" if key.endswith("+scores") else "match_kernel<false>"
     key = key.replace("+scores", "")
     m = re.match(r"(gemm|attn)_kernel<bf16,(.*)>", key)
     if m:        # 4-wave bodies: mangled names in the summary
@@ -205,7 +212,8 @@ def named_roofline(agg, key, what):
     tflops, tbs = fl / (ms * 1e-3) / 1e12, byt / (ms * 1e-3) / 1e12
     ai = fl / max(byt, 1.0)
     hbm = ai < PEAK_BF16_TFLOPS / PEAK_HBM_TBS
-    traffic = _pmc().get(key.replace("+scores", ""), {}).get("hbm_bytes_per_launch")
+    pm = _pmc()
+    traffic = (pm.get(key) or pm.get(key.replace("+scores", ""), {})).get("hbm_bytes_per_launch")
     rec = ({"bound": "hbm", "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_TBS * 1e3, "unit": "GB/s",
             "frac": round(tbs / PEAK_HBM_TBS, 4)} if hbm else
            {"bound": "mfma", "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -730,9 +738,10 @@ def main():
                                         "lib/pvt_v2.py:95-127,165-168 (emip_sra_block)"),
             "sra_attention_only": named_roofline(agg, "sra_kernel",
                                                  "softmax(q k^T / 8) v alone (the 11x11 stage, sr_ratio 1), lib/pvt_v2.py:113-125"),
-            "correlation": named_roofline(agg, "attn_kernel<bf16,128,32,64>+scores",
-                                          "GMFlow all-pairs correlation + softmax expectation, raw correlation "
-                                          "written once as [src][tgt], gmflow/matching.py:13-41")}
+            "correlation": named_roofline(agg, "match_kernel+scores",
+                                          "GMFlow all-pairs correlation + softmax expectation of BOTH matching directions in "
+                                          "one launch, raw correlation of the forward direction written once as [src][tgt], "
+                                          "gmflow/matching.py:13-41 (emip_match)")}
         out["kernel_breakdown_ms"] = {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}
         out["parity"] = {"timed_outputs": timed_parity}
         if world == 1 and not args.no_cpu_baseline:

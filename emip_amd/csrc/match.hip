@@ -11,11 +11,14 @@
 // The generic attention kernel spent 86 us on the two matching launches of an 8-pair sub-batch: register-staged K / V tiles
 // behind index tables, a 32-column V of which 2 columns are used, the score matrix stored 8 bytes per lane from a kernel
 // that waits for all of its memory traffic once per tile.  This kernel is built for the shape:
-//   * a workgroup = 4 waves x 32 queries; a wave keeps its 32 query rows as MFMA B-operand fragments for the whole launch;
+//   * a workgroup = 128 queries x 8 waves: wave w and wave w + 4 hold the SAME 32 query rows (MFMA B-operand fragments, kept
+//     for the whole launch) and split the key tiles between them (even / odd), so every SIMD has two waves whose MFMA and
+//     softmax phases overlap -- the problem has fewer than 1024 32-query blocks, one wave per SIMD ran at half this speed --
+//     and their (max, sum p v, sum p) partials meet in LDS at the end;
 //   * the keys stream through a 3-slot LDS ring by LDS-DMA (buffer_load ... lds, 16 B per lane, the XOR swizzle of the
 //     ds_read_b128 row reads applied on the per-lane SOURCE chunk, rows beyond n read as zeros through the range check), ONE
 //     s_barrier and ONE counted s_waitcnt vmcnt per 64-key tile: the score stores of the two previous tiles and the next
-//     tile's DMA stay in flight across it (every store is an unconditional buffer store, so the counts are exact);
+//     tile's DMA stay in flight across it (every store is an unconditional 16-byte buffer store, so the counts are exact);
 //   * S^T = K Q^T with the key on the MFMA row: a lane holds scores of ONE query, the row maximum needs one lane exchange,
 //     and the exponentiated accumulators are the B operand of  O^T += V^T P  as they stand;
 //   * V^T has three live rows -- v_x, v_y and ONES, so the softmax denominator comes out of the same MFMA -- kept for all keys
@@ -29,6 +32,7 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ i32x4 mt_rsrc(const void* ptr, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
@@ -42,9 +46,9 @@ __device__ __forceinline__ void mt_dma16(unsigned lds_dst, unsigned voff, i32x4 
         : "s"(lds_dst), "v"(voff), "s"(rs)
         : "memory");
 }
-// 8 bytes per lane, unconditional: lanes whose offset lies outside the descriptor's range store nothing
-__device__ __forceinline__ void mt_store8(u32x2 v, unsigned voff, i32x4 rs) {
-    asm volatile("buffer_store_dwordx2 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rs) : "memory");
+// 16 bytes per lane, unconditional: lanes whose offset lies outside the descriptor's range store nothing
+__device__ __forceinline__ void mt_store16(u32x4 v, unsigned voff, i32x4 rs) {
+    asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" : : "v"(v), "v"(voff), "s"(rs) : "memory");
 }
 
 struct MatchArgs {
@@ -60,15 +64,16 @@ struct MatchArgs {
 };
 
 constexpr unsigned MT_OOB = 0x80000000u;
-constexpr int MT_BK = 64, MT_NST = 3, MT_TILE = MT_BK * 256, MT_NPAD = 2048;
-constexpr int MT_RING = MT_NST * MT_TILE;                 // 49 152 B
-constexpr int MT_LDS = MT_RING + 3 * MT_NPAD * 2;         // + V^T rows (x, y, 1) for every key: 61 440 B
+constexpr int MT_BK = 64, MT_NST = 6, MT_TILE = MT_BK * 256, MT_NPAD = 2048;
+constexpr int MT_RING = MT_NST * MT_TILE;                 // 3 rounds of 2 tiles: 98 304 B
+constexpr int MT_LDS = MT_RING + 4 * MT_NPAD * 2;         // + V^T rows (x, y, 1, 0) for every key: 114 688 B
 
 template <bool SC>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void match_kernel(const MatchArgs p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void match_kernel(const MatchArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qw = wave & 3, half = wave >> 2;             // query block of the wave; which tile of a round it multiplies
     const int lq = lane & 31, h = lane >> 5;
     int z, qt;
     if (p.xcd_map) {        // ids are dealt round-robin over the 8 XCDs: the query tiles of a batch element share its keys in one L2
@@ -89,7 +94,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     bf16_t* vt = reinterpret_cast<bf16_t*>(smem + MT_RING);
 
     // ---- this lane's query row as B-operand fragments (k-step i: channels 16 i + 8 h .. + 7)
-    const int q = qt * 128 + wave * 32 + lq;
+    const int q = qt * 128 + qw * 32 + lq;
     const bool q_ok = q < p.n;
     uint4 qf[8];
     {
@@ -98,30 +103,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const uint4*>(Qp + qr * p.ldq + (2 * i + h) * 8);
     }
 
-    // ---- key tiles: a 1-KB DMA piece = 4 key rows x 16 chunks; lane l sits at row l >> 4, slot l & 15 and fetches source
-    // chunk slot ^ (row & 15); wave w moves pieces w, w + 4, w + 8, w + 12 of a tile
+    // ---- key tiles, two per round: a 1-KB DMA piece = 4 key rows x 16 chunks; lane l sits at row l >> 4, slot l & 15 and
+    // fetches source chunk slot ^ (row & 15); wave w moves pieces w, w + 8, w + 16, w + 24 of a round's 32 (128 key rows)
     unsigned koff[4];
     int krow[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        krow[j] = 4 * (wave + 4 * j) + (lane >> 4);
+        krow[j] = 4 * (wave + 8 * j) + (lane >> 4);        // key row inside the round
         koff[j] = (unsigned)((krow[j] * p.ldk + 8 * ((lane & 15) ^ (krow[j] & 15))) * 2);
     }
-    const unsigned tile_stride = (unsigned)(MT_BK * p.ldk * 2);
-    auto issue = [&](int t) {
-        const unsigned base = lds0 + (t % MT_NST) * MT_TILE;
+    const unsigned round_stride = (unsigned)(2 * MT_BK * p.ldk * 2);
+    auto issue = [&](int r) {                              // round r = tiles 2 r, 2 r + 1 -> ring slots (2 r) % 6, + 1
+        const unsigned base = lds0 + ((2 * r) % MT_NST) * MT_TILE;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const unsigned off = (t * MT_BK + krow[j] < p.n) ? koff[j] + (unsigned)t * tile_stride : MT_OOB;
-            mt_dma16(base + (wave + 4 * j) * 1024, off, rsK);
+            const unsigned off = (r * 2 * MT_BK + krow[j] < p.n) ? koff[j] + (unsigned)r * round_stride : MT_OOB;
+            mt_dma16(base + (wave + 8 * j) * 1024, off, rsK);
         }
     };
-    const int ntile = (p.n + MT_BK - 1) / MT_BK;
+    const int ntile = (p.n + MT_BK - 1) / MT_BK, nround = (ntile + 1) >> 1;
     issue(0);
-    issue(1);
+    if (nround > 1) issue(1);
 
     // ---- V^T for every key: rows x, y, ones (zeros beyond n)
-    for (int k = tid; k < MT_NPAD; k += 256) {
+    for (int k = tid; k < MT_NPAD; k += 512) {
         float x = 0.f, y = 0.f, o = 0.f;
         if (k < p.n) {
             if (p.V) {
@@ -136,6 +141,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
         vt[k] = (bf16_t)x;
         vt[MT_NPAD + k] = (bf16_t)y;
         vt[2 * MT_NPAD + k] = (bf16_t)o;
+        vt[3 * MT_NPAD + k] = (bf16_t)0.f;                 // the row every lane >= 3 reads: V^T rows 3..31 are zero
     }
     __syncthreads();                                       // the table is read by every wave from tile 0 on
 
@@ -144,28 +150,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
     for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
     float m_run = -INFINITY;
     const float sc2 = p.scale * 1.4426950408889634f;       // scores in log2 units
-    const unsigned vmask = lq < 3 ? 0xFFFFFFFFu : 0u;      // V^T rows >= 3 are zero
-    const int vrow = lq < 3 ? lq : 0;
+    const int vrow = lq < 3 ? lq : 3;
     const char* vt_row = smem + MT_RING + (vrow * MT_NPAD + 4 * h) * 2;
     const unsigned s_q = q_ok ? (unsigned)q * (unsigned)p.n * 2u : MT_OOB;    // byte offset of this query's score row
 
-    for (int t = 0; t < ntile; ++t) {
-        // tile t has landed for this wave once all but the younger operations are done: in issue order behind its 4 DMA
-        // pieces sit [8 score stores of tile t - 2] 4 pieces of tile t + 1 [8 score stores of tile t - 1]
-        if (t + 1 < ntile) {
+    for (int r = 0; r < nround; ++r) {
+        // round r has landed for this wave once all but the younger operations are done: in issue order behind its 4 DMA
+        // pieces sit [4 score stores of round r - 2] 4 pieces of round r + 1 [4 score stores of round r - 1]
+        if (r + 1 < nround) {
             if (SC) {
-                if (t == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else if (t == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                if (r == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else if (r == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             } else {
                 asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             }
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // last tile: nothing younger was issued that may stay
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // last round: nothing younger was issued that may stay
         }
-        __builtin_amdgcn_s_barrier();                      // ... and for every wave; everyone has left tile t - 1's slot
+        __builtin_amdgcn_s_barrier();                      // ... and for every wave; everyone has left round r - 1's slots
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < ntile) issue(t + 2);                   // into the slot tile t - 1 has just left
+        if (r + 2 < nround) issue(r + 2);                  // into the slots round r - 1 has just left
+        const int t = 2 * r + half;                        // this wave's tile of the round
+        if (t >= ntile) {                                  // (odd tile count: the last round has one tile)
+            if (SC) {                                      // keep the per-round store count of the waits above
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mt_store16(u32x4{0u, 0u, 0u, 0u}, MT_OOB, rsS);
+            }
+            continue;
+        }
 
         const char* sb = smem + (t % MT_NST) * MT_TILE;
         // ---- S^T = K Q^T for the tile's two 32-key blocks
@@ -183,18 +196,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                                                                 s[kt], 0, 0, 0);
             }
         }
-        // ---- raw correlation out: register 4 g + j of block kt = key t 64 + 32 kt + 8 g + 4 h + j of query q
+        // ---- raw correlation out: register 4 g + j of block kt = key t 64 + 32 kt + 8 g + 4 h + j of query q.  The two lanes of a
+        // query trade halves (v_permlane32_swap) so that each stores 16 contiguous bytes: lane half 0 the 8 keys of group g,
+        // lane half 1 those of group g + 1
         if (SC) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int kb = t * MT_BK + 32 * kt + 8 * g + 4 * h;
-                    bf16x4 v4;
+                for (int g = 0; g < 4; g += 2) {
+                    bf16x4 va, vb;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v4[j] = (bf16_t)(s[kt][4 * g + j] * p.scale);
-                    const unsigned off = (kb + 3 < p.n) ? s_q + (unsigned)kb * 2u : MT_OOB;
-                    mt_store8(__builtin_bit_cast(u32x2, v4), off, rsS);
+                    for (int j = 0; j < 4; ++j) {
+                        va[j] = (bf16_t)(s[kt][4 * g + j] * p.scale);
+                        vb[j] = (bf16_t)(s[kt][4 * g + 4 + j] * p.scale);
+                    }
+                    u32x2 a2 = __builtin_bit_cast(u32x2, va), b2 = __builtin_bit_cast(u32x2, vb);
+                    const auto r0 = __builtin_amdgcn_permlane32_swap(a2.x, b2.x, false, false);
+                    const auto r1 = __builtin_amdgcn_permlane32_swap(a2.y, b2.y, false, false);
+                    const int kb = t * MT_BK + 32 * kt + 8 * (g + h);
+                    const unsigned off = (kb + 7 < p.n) ? s_q + (unsigned)kb * 2u : MT_OOB;
+                    mt_store16(u32x4{r0[0], r1[0], r0[1], r1[1]}, off, rsS);
                 }
         }
         // ---- softmax: keys beyond n (last tile only) out, running maximum raised only when some query needs it
@@ -227,17 +248,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
                 for (int j = 0; j < 8; ++j) pf[j] = (bf16_t)__builtin_amdgcn_exp2f(fmaf(s[kt][8 * sp + j], sc2, -m_run));
                 // A fragment: element j = V^T[row lq][key t 64 + 32 kt + 16 sp + 8 (j >> 2) + 4 h + (j & 3)]
                 const char* vp = vt_row + (t * MT_BK + 32 * kt + 16 * sp) * 2;
-                uint2 a0 = *reinterpret_cast<const uint2*>(vp), a1 = *reinterpret_cast<const uint2*>(vp + 16);
-                uint4 vf = make_uint4(a0.x & vmask, a0.y & vmask, a1.x & vmask, a1.y & vmask);
+                const uint2 a0 = *reinterpret_cast<const uint2*>(vp), a1 = *reinterpret_cast<const uint2*>(vp + 16);
+                const uint4 vf = make_uint4(a0.x, a0.y, a1.x, a1.y);
                 oacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), pf, oacc, 0, 0, 0);
             }
         }
     }
 
-    // ---- lanes of half 0 hold (sum p v_x, sum p v_y, sum p) of their query in registers 0..2
-    if (h == 0 && q_ok) {
-        const float inv = 1.0f / oacc[2];
-        float ox = oacc[0] * inv, oy = oacc[1] * inv;
+    // ---- lanes of lane half 0 hold (sum p v_x, sum p v_y, sum p) of their query in registers 0..2, relative to m_run; the odd
+    // tiles' wave hands its four numbers to the even tiles' wave through the (drained) ring
+    __syncthreads();
+    float4* part = reinterpret_cast<float4*>(smem);
+    if (half == 1 && h == 0) part[qw * 32 + lq] = make_float4(oacc[0], oacc[1], oacc[2], m_run);
+    __syncthreads();
+    if (half == 0 && h == 0 && q_ok) {
+        const float4 o2 = part[qw * 32 + lq];
+        const float m = fmaxf(m_run, o2.w);                // (o2.w = -inf with an all-zero partial when there was a single tile)
+        const float fa = __builtin_amdgcn_exp2f(m_run - m), fb = __builtin_amdgcn_exp2f(o2.w - m);
+        const float inv = 1.0f / (oacc[2] * fa + o2.z * fb);
+        float ox = (oacc[0] * fa + o2.x * fb) * inv, oy = (oacc[1] * fa + o2.y * fb) * inv;
         if (p.sub) {
             const int qy = q / p.W;
             ox -= (float)(q - qy * p.W);
@@ -256,10 +285,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void m
 extern "C" int emip_match(const void* Q, const void* K, const float* V, void* S, float* Out, int Z, int Zs, int n, int W,
                           long ldq, long ldk, long q_bs, long k_bs, int kv_rot, float scale, int sub_grid, void* stream) {
     EMIP_REQUIRE(Q && K && Out && Z > 0 && Zs >= 0 && Zs <= Z && (Zs == 0 || S));
-    EMIP_REQUIRE(n >= 2 * MT_BK && n <= MT_NPAD && (n & 3) == 0 && W > 0 && kv_rot >= 0 && kv_rot < Z);
+    EMIP_REQUIRE(n >= 2 * MT_BK && n <= MT_NPAD && (n & 7) == 0 && W > 0 && kv_rot >= 0 && kv_rot < Z);
     EMIP_REQUIRE(ldq >= 128 && ldk >= 128 && (ldq & 7) == 0 && (ldk & 7) == 0 && (q_bs & 7) == 0 && (k_bs & 7) == 0);
     EMIP_REQUIRE(aligned16(Q) && aligned16(K) && (reinterpret_cast<uintptr_t>(Out) & 7u) == 0 &&
-                 (reinterpret_cast<uintptr_t>(V) & 7u) == 0 && (reinterpret_cast<uintptr_t>(S) & 7u) == 0);
+                 (reinterpret_cast<uintptr_t>(V) & 7u) == 0 && aligned16(S));
     EMIP_REQUIRE(((long)(n - 1) * ldk + 128) * 2 < 0x7FFF0000L && (long)n * n * 2 < 0x7FFF0000L);
     EMIP_REQUIRE(q_bs >= (long)(n - 1) * ldq + 128 || Z == 1);
     MatchArgs a{};
@@ -279,8 +308,8 @@ extern "C" int emip_match(const void* Q, const void* K, const float* V, void* S,
     }
     const dim3 grid((unsigned)(Z * a.qtiles));
     if (Zs > 0)
-        hipLaunchKernelGGL(match_kernel<true>, grid, dim3(256), MT_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(match_kernel<true>, grid, dim3(512), MT_LDS, (hipStream_t)stream, a);
     else
-        hipLaunchKernelGGL(match_kernel<false>, grid, dim3(256), MT_LDS, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(match_kernel<false>, grid, dim3(512), MT_LDS, (hipStream_t)stream, a);
     return emip_launch_status();
 }

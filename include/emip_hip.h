@@ -242,7 +242,7 @@ int emip_attention_rot(const void* Q, const void* K, const void* V, void* O, voi
  * q_bs / k_bs (elements); V: f32 [Z][n][2] indexed like the keys, or NULL = the pixel grid (x = k mod W, y = k / W:
  * geometry.py:5-21); S: bf16 [Zs][n][n] receives the raw correlation scale * q.k of the batches z < Zs, row q, column k -- the
  * volume matching.py:18-20 returns (permuted) and model.py:96 hands to conv_corr; Out: f32 [Z][n][2].  Both matching
- * directions are ONE launch (Z = 2B, kv_rot = B, Zs = B).  64 <= ... n <= 2048, n % 4 == 0. */
+ * directions are ONE launch (Z = 2B, kv_rot = B, Zs = B).  128 <= n <= 2048, n % 8 == 0. */
 int emip_match(const void* Q, const void* K, const float* V, void* S, float* Out, int Z, int Zs, int n, int W, long ldq,
                long ldk, long q_bs, long k_bs, int kv_rot, float scale, int sub_grid, void* stream);
 

@@ -22,6 +22,9 @@ def bench_key(name):
     m = re.search(r"(gemm8_kernel<[^>]*>)", name)          # demangled template instance: exactly bench.py's key
     if m:
         return m.group(1)
+    m = re.search(r"match_kernel<(true|false)>", name) or re.search(r"match_kernelILb([01])E", name)
+    if m:
+        return "match_kernel" + ("+scores" if m.group(1) in ("true", "1") else "")
     for k in ("sra_q_kernel", "sra_block_kernel", "sra_kernel"):
         if k in name:
             return k
