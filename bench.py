@@ -271,24 +271,28 @@ def _iou(a, b):
 
 
 def timed_output_parity(runner, net, margs, sd, im1, im2, dev):
-    """What the timed region computed: the masks left by its LAST graph replays (bf16, two 8-pair graphs, the second one
-    captured GMFlow-CNN-first, free-running on two streams) against (a) the eager bf16 forward of the same sub-batches in the
-    same launch order and (b) the f32 parity mode on the same 16 pairs -- test.py:28's view of the configuration that is timed"""
+    """What the timed region computed: the masks left by the LAST replay of every graph it used (bf16; sub-batch graphs of one
+    step, or whole-batch graphs of consecutive steps in flight; every second one captured GMFlow-CNN-first; free-running on
+    their streams) against (a) the eager bf16 forward of the same pairs in the same launch order and (b) the f32 parity mode
+    on the same 16 pairs -- test.py:28's view of the configuration that is timed"""
     from emip_amd import nn_base
     from emip_amd.model.EMIP_short import model as M
     from emip_amd.model.EMIP_short.model import CoUpdater
-    mask = runner.outputs()[0].float()
-    n = im1.shape[0] // runner.splits
-    halves = []
+    parts = runner.parts
+    n = parts[0].batch
+    whole = n == im1.shape[0]                  # whole-batch graphs (steps in flight) or sub-batch graphs (one step split)
+    spans = [(0, n)] * len(parts) if whole else [(i * n, (i + 1) * n) for i in range(len(parts))]
+    masks = [p.mask.float() for p in parts]
+    eager, again = [], []
     with torch.no_grad():
-        for i in range(runner.splits):
+        for i, (lo, hi) in enumerate(spans):
             prev, M.CNN_FIRST = M.CNN_FIRST, bool(i % 2 == 1 and M.STAGGER)
             try:
-                halves.append(net(im1[i * n:(i + 1) * n], im2[i * n:(i + 1) * n])[0].float())
+                eager.append(net(im1[lo:hi], im2[lo:hi])[0].float())
             finally:
                 M.CNN_FIRST = prev
-        eager = torch.cat(halves, 0)
-        again = torch.cat([net(im1[i * n:(i + 1) * n], im2[i * n:(i + 1) * n])[0].float() for i in range(runner.splits)], 0)
+        for lo, hi in spans[:2]:
+            again.append(net(im1[lo:hi], im2[lo:hi])[0].float())
         nn_base.set_default_dtype(torch.float32)
         try:
             net32 = CoUpdater(margs)
@@ -298,17 +302,20 @@ def timed_output_parity(runner, net, margs, sd, im1, im2, dev):
         finally:
             nn_base.set_default_dtype(torch.bfloat16)
     torch.cuda.empty_cache()
-    return {"what": "mask logits of the last timed graph replays, %d pairs" % im1.shape[0],
-            "finite": bool(torch.isfinite(mask).all().item()),
-            "max_abs_dlogit_vs_eager_bf16_same_subbatches": float("%.3g" % (mask - eager).abs().max().item()),
-            "mask_iou_vs_eager_bf16": round(_iou(mask, eager), 5),
-            "eager_bf16_run_to_run": {"max_abs_dlogit": float("%.3g" % (again - eager).abs().max().item()),
-                                      "mask_iou": round(_iou(again, eager), 5),
+    ref32 = [m32[lo:hi] for lo, hi in spans]
+    mx = lambda xs, ys: max((x - y).abs().max().item() for x, y in zip(xs, ys))
+    mn = lambda xs, ys: min(_iou(x, y) for x, y in zip(xs, ys))
+    return {"what": "mask logits left by the last timed replay of each of the %d graphs (%d pairs each)" % (len(parts), n),
+            "finite": bool(all(torch.isfinite(m).all().item() for m in masks)),
+            "max_abs_dlogit_vs_eager_bf16_same_batches": float("%.3g" % mx(masks, eager)),
+            "mask_iou_vs_eager_bf16": round(mn(masks, eager), 5),
+            "eager_bf16_run_to_run": {"max_abs_dlogit": float("%.3g" % mx(again, eager[:2])),
+                                      "mask_iou": round(mn(again, eager[:2]), 5),
                                       "note": "two eager bf16 forwards of the same pairs: f32-atomic statistics move bf16 roundings"},
-            "max_abs_dlogit_eager_bf16_vs_f32_mode": float("%.3g" % (eager - m32).abs().max().item()),
-            "mask_iou_eager_bf16_vs_f32_mode": round(_iou(eager, m32), 5),
-            "max_abs_dlogit_vs_f32_mode": float("%.3g" % (mask - m32).abs().max().item()),
-            "mask_iou_vs_f32_mode": round(_iou(mask, m32), 5),
+            "max_abs_dlogit_eager_bf16_vs_f32_mode": float("%.3g" % mx(eager, ref32)),
+            "mask_iou_eager_bf16_vs_f32_mode": round(mn(eager, ref32), 5),
+            "max_abs_dlogit_vs_f32_mode": float("%.3g" % mx(masks, ref32)),
+            "mask_iou_vs_f32_mode": round(mn(masks, ref32), 5),
             "logit_range_f32_mode": float("%.3g" % m32.abs().max().item())}
 
 
@@ -586,7 +593,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--streams", type=int, default=2, help="sub-batches replayed concurrently on separate HIP streams")
+    ap.add_argument("--streams", type=int, default=2, help="--inflight 1: sub-batches of the step replayed concurrently on separate HIP streams")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="consecutive 16-pair steps in flight, each ONE whole-batch graph on its own stream (1 = one step at "
+                         "a time, its batch split into --streams sub-batch graphs)")
     ap.add_argument("--no-sub", action="store_true", help="skip the train / long / f32 sub-records of the default run")
     ap.add_argument("--dp-algo", choices=("allreduce", "direct"), default="allreduce",
                     help="train workload, N > 1: gradient exchange of emip_amd.dp.GradReducer")
@@ -639,7 +649,11 @@ def main():
                 for i in range(nsub):
                     net.run(im1[i * n:(i + 1) * n], im2[i * n:(i + 1) * n])
     else:
-        runner = GraphedShort(net, B, device=dev, splits=args.streams)
+        if args.inflight > 1:
+            from emip_amd.graph import PipelinedShort
+            runner = PipelinedShort(net, B, inflight=args.inflight, device=dev)
+        else:
+            runner = GraphedShort(net, B, device=dev, splits=args.streams)
         runner.load(im1, im2)
         torch.cuda.synchronize()
         step = runner.replay_free
@@ -652,16 +666,22 @@ def main():
     marks = [[torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] for _ in ev_streams]
     _barrier(dist)
     t0 = time.perf_counter()
+    pipelined = (not args.no_graph) and args.inflight > 1
     for st, m in zip(ev_streams, marks):
         m[0].record(st)
     for i in range(args.steps):
-        step()
-        for st, m in zip(ev_streams, marks):
-            m[i + 1].record(st)
+        slot = step()
+        for j, (st, m) in enumerate(zip(ev_streams, marks)):
+            if not pipelined or j == slot:
+                m[i + 1].record(st)
     _barrier(dist)
     dt = time.perf_counter() - t0
     dt = edist.max_over_ranks(dt, red_dev)
-    step_ms = [max(m[i].elapsed_time(m[i + 1]) for m in marks) for i in range(args.steps)]
+    if pipelined:      # completion events of consecutive steps (on their own streams): spacing = the step time in steady state
+        done = [marks[i % args.inflight][i + 1] for i in range(args.steps)]
+        step_ms = [done[i - 1].elapsed_time(done[i]) for i in range(1, args.steps)]
+    else:
+        step_ms = [max(m[i].elapsed_time(m[i + 1]) for m in marks) for i in range(args.steps)]
 
     out = None
     if rank == 0:
@@ -669,11 +689,23 @@ def main():
         value = pairs / dt
         nsplit = nsub if args.no_graph else runner.splits
         timed_parity = None
+        latency_ms = None
         if not args.no_graph:
             try:
                 timed_parity = timed_output_parity(runner, net, margs, sd, im1, im2, dev)
             except Exception as e:                               # noqa: BLE001
                 timed_parity = {"error": repr(e)[:300]}
+            lat = []
+            for _ in range(7):                                   # one step alone, from an idle device to its results
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                if pipelined:
+                    step()
+                else:
+                    runner.replay()
+                torch.cuda.synchronize()
+                lat.append((time.perf_counter() - t1) * 1e3)
+            latency_ms = round(_pct(lat, 0.5), 3)
         agg = kernel_breakdown(net, im1, im2, nsplit)
         kernels = {k: v for k, v in agg.items() if v[1] > 0 and "blocker" not in k}
         dom = max(kernels, key=lambda k: kernels[k][0])
@@ -698,11 +730,20 @@ def main():
                          "ms_p90": round(_pct(step_ms, 0.9), 4),
                          "pairs_per_s_median": round(B / _pct(step_ms, 0.5) * 1e3, 1),
                          "pairs_per_s_p10": round(B / _pct(step_ms, 0.9) * 1e3, 1),
-                         "pairs_per_s_p90": round(B / _pct(step_ms, 0.1) * 1e3, 1)},
+                         "pairs_per_s_p90": round(B / _pct(step_ms, 0.1) * 1e3, 1),
+                         "latency_ms": latency_ms,
+                         "pairs_per_s_one_step_at_a_time": (round(B / latency_ms * 1e3, 1) if latency_ms else None)},
             "config": {"workload": "EMIP-short inference forward (CoUpdater.forward), batch=16 352x352 frame pairs "
                                    "per GPU, bf16 storage / f32 accumulate, random-filled weights",
                        "pairs_per_gpu": B, "parallelism": "dp%d (independent replicas, no collective)" % world,
-                       "hipgraph": not args.no_graph, "concurrent_streams": 1 if args.no_graph else args.streams},
+                       "hipgraph": not args.no_graph,
+                       "steps_in_flight": (args.inflight if pipelined else 1),
+                       "graphs_per_step": (1 if pipelined or args.no_graph else args.streams),
+                       "concurrent_streams": 1 if args.no_graph else (args.inflight if pipelined else args.streams),
+                       "note": ("every step is one whole 16-pair forward (one hipGraph); consecutive steps are enqueued on %d "
+                                "streams in turn and overlap, like independent requests of a serving loop; per_step.latency_ms "
+                                "is one such step alone" % args.inflight) if pipelined else
+                               "one step at a time, its batch split into sub-batch graphs on concurrent streams"},
             "end_to_end": {"achieved_TFLOPs": round(value / world * F_ALG_PAIR_GFLOP / 1e3, 2),
                            "frac_of_bf16_mfma_peak": round(value / world * F_ALG_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4)},
             "roofline": ({"bound": "hbm", "kernel": dom, "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_TBS * 1e3,

@@ -79,6 +79,44 @@ def test_timed_graph_replay_outputs(model_args, short_sd):
         nn_base.set_default_dtype(torch.float32)
 
 
+def test_timed_pipelined_replay_outputs(model_args, short_sd):
+    """bench.py's default arrangement: every step ONE 16-pair graph, three consecutive steps in flight on three streams (every
+    second graph captured CNN-first): after free-running replays each slot holds the masks of an eager bf16 forward of the
+    same 16 pairs, up to the eager run-to-run band"""
+    from emip_amd import nn_base
+    from emip_amd.graph import PipelinedShort
+    from emip_amd.model.EMIP_short import model as M
+    try:
+        im1, im2 = synthetic_pair(16, seed=1234)
+        im1, im2 = im1.cuda(), im2.cuda()
+        net = _net(model_args, short_sd, torch.bfloat16)
+        with torch.no_grad():
+            e1 = net(im1, im2)[0].float()
+            e2 = net(im1, im2)[0].float()
+            prev, M.CNN_FIRST = M.CNN_FIRST, True
+            try:
+                e3 = net(im1, im2)[0].float()
+            finally:
+                M.CNN_FIRST = prev
+        jitter, iou_jit = (e1 - e2).abs().max().item(), _iou(e1, e2)
+        runner = PipelinedShort(net, 16, inflight=3)
+        runner.load(im1, im2)
+        torch.cuda.synchronize()
+        slots = [runner.replay_free() for _ in range(11)]            # 11 steps: the slots end on different step counts
+        torch.cuda.synchronize()
+        assert slots[:4] == [0, 1, 2, 0]
+        for i in range(3):
+            mask, fw, bw = runner.outputs(i)
+            mask = mask.float()
+            ref = e3 if i % 2 == 1 else e1
+            d, iou = (mask - ref).abs().max().item(), _iou(mask, ref)
+            print(f"  slot {i}: timed replay vs eager bf16 max |dlogit| {d:.4f}, IoU {iou:.5f} (two eager runs: {jitter:.4f}, {iou_jit:.5f})")
+            assert torch.isfinite(mask).all() and mask.shape == (16, 1, 352, 352) and fw[0].shape == (16, 2, 352, 352)
+            assert d <= 1.5 * jitter + 0.05 and iou >= iou_jit - 0.01
+    finally:
+        nn_base.set_default_dtype(torch.float32)
+
+
 def stage_table(net, g, im1, im2):
     """relative max-abs error per stage of a forward against the reference fixture short_eval_b1.npz"""
     from emip_amd import ops
