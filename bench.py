@@ -669,8 +669,10 @@ def main():
     pipelined = (not args.no_graph) and args.inflight > 1
     for st, m in zip(ev_streams, marks):
         m[0].record(st)
+    slots = []
     for i in range(args.steps):
         slot = step()
+        slots.append(slot)
         for j, (st, m) in enumerate(zip(ev_streams, marks)):
             if not pipelined or j == slot:
                 m[i + 1].record(st)
@@ -678,7 +680,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = edist.max_over_ranks(dt, red_dev)
     if pipelined:      # completion events of consecutive steps (on their own streams): spacing = the step time in steady state
-        done = [marks[i % args.inflight][i + 1] for i in range(args.steps)]
+        done = [marks[slots[i]][i + 1] for i in range(args.steps)]
         step_ms = [done[i - 1].elapsed_time(done[i]) for i in range(1, args.steps)]
     else:
         step_ms = [max(m[i].elapsed_time(m[i + 1]) for m in marks) for i in range(args.steps)]

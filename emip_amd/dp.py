@@ -49,7 +49,7 @@ class _Bucket:
         self.offsets, n = [], 0
         for p in params:
             self.offsets.append(n)
-            n += p.numel()
+            n += (p.numel() + 3) & ~3         # every tensor starts on a 16-byte boundary of the flat buffer (vector accesses)
         self.numel = n
         unit = world * ALIGN
         self.padded = (n + unit - 1) // unit * unit
