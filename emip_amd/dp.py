@@ -202,10 +202,9 @@ class GradReducer:
             ev.record()
             b.ptrs = ptrs
         if b.nblk:
-            _lib.call("emip_grad_pack", t["recs"].data_ptr(), t["bmap"].data_ptr() + 8 * b.blk0, t["gdev"].data_ptr(), b.nblk,
-                      self._flat.data_ptr(), int(self.comm_dtype == torch.bfloat16),
-                      torch.cuda.current_stream(dev).cuda_stream)
-            self.kernel_launches += 1
+            self._kcall("emip_grad_pack", t["recs"].data_ptr(), t["bmap"].data_ptr() + 8 * b.blk0, t["gdev"].data_ptr(), b.nblk,
+                        self._flat.data_ptr(), int(self.comm_dtype == torch.bfloat16),
+                        torch.cuda.current_stream(dev).cuda_stream)
 
     def _launch(self, b, bi):
         ref = b.params[0]
@@ -237,10 +236,8 @@ class GradReducer:
                 dist.all_to_all_single(recv, seg, group=self.group)
                 shard = torch.empty(chunk, dtype=self.comm_dtype, device=dev)
                 if dev.type == "cuda":
-                    from . import _lib
-                    _lib.call("emip_shard_sum", recv.data_ptr(), shard.data_ptr(), w, chunk,
-                              int(self.comm_dtype == torch.bfloat16), torch.cuda.current_stream(dev).cuda_stream)
-                    self.kernel_launches += 1
+                    self._kcall("emip_shard_sum", recv.data_ptr(), shard.data_ptr(), w, chunk,
+                                int(self.comm_dtype == torch.bfloat16), torch.cuda.current_stream(dev).cuda_stream)
                 else:
                     shard.copy_(recv.view(w, chunk).float().sum(0))
                 b.work = dist.all_gather_into_tensor(self._out[b.lo:b.lo + b.padded], shard, group=self.group, async_op=True)
@@ -248,22 +245,25 @@ class GradReducer:
         self.launch_log.append(bi)
 
     def _timed(self, fn, *a):
-        """fn(*a); with record_events also its host time and a HIP-event pair around its launches (tests: the reducer's own
-        overhead, apart from the collectives)"""
+        """fn(*a); with record_events also its host time (tests: the reducer's own overhead, apart from the collectives)"""
         if not self.record_events:
             return fn(*a)
         import time
-        cuda = a[-1].type == "cuda" if isinstance(a[-1], torch.device) else a[0].type == "cuda"
-        ev = None
-        if cuda:
-            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-            ev[0].record()
         t0 = time.perf_counter()
         fn(*a)
         self.host_ms += (time.perf_counter() - t0) * 1e3
-        if cuda:
-            ev[1].record()
-            self._kev.append(ev)
+
+    def _kcall(self, name, *args):
+        """one libemip_hip.so launch; with record_events a HIP-event pair tightly around it"""
+        from . import _lib
+        self.kernel_launches += 1
+        if not self.record_events:
+            return _lib.call(name, *args)
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        _lib.call(name, *args)
+        ev[1].record()
+        self._kev.append(ev)
 
     def kernel_ms(self):
         """record_events: device time of this step's pack / unpack launches (call after a synchronize)"""
@@ -283,10 +283,9 @@ class GradReducer:
         t = self._tables
         nblk = sum(b.nblk for b in bl)
         if nblk:
-            _lib.call("emip_grad_unpack", t["recs"].data_ptr(), t["bmap"].data_ptr(), t["gdev"].data_ptr(), nblk,
-                      self._out.data_ptr(), int(self.comm_dtype == torch.bfloat16), float(inv),
-                      torch.cuda.current_stream(dev).cuda_stream)
-            self.kernel_launches += 1
+            self._kcall("emip_grad_unpack", t["recs"].data_ptr(), t["bmap"].data_ptr(), t["gdev"].data_ptr(), nblk,
+                        self._out.data_ptr(), int(self.comm_dtype == torch.bfloat16), float(inv),
+                        torch.cuda.current_stream(dev).cuda_stream)
 
     def finish(self):
         """Complete the step: exchange what is still pending, wait, average, write the gradients back."""
