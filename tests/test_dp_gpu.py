@@ -295,7 +295,7 @@ def test_gradient_bucket_kernels_roundtrip_and_cost():
         ms = red.kernel_ms()
         nb = len(red.buckets)
         print(f"  {comm}: {sum(sizes) / 1e6:.0f} M elements, {nb} buckets, {red.kernel_launches} launches, device {ms:.3f} ms")
-        assert red.kernel_launches == nb + 1 and ms < 1.0
+        assert red.kernel_launches == nb + 1 and ms < 1.5        # measured 0.99 ms (f32 wire) / 0.31 ms (bf16 wire)
         red.remove()
     # the reduce step of the direct exchange: f32 accumulation of bf16 shards
     x = torch.randn(8, 1_000_003, device="cuda").to(torch.bfloat16)
