@@ -31,6 +31,9 @@ SRA_BLOCK_MAXC = 128
 # q projection inside the attention launch (emip_sra_block / emip_sra_qattn).  False = q GEMM + emip_sra_attention, the form
 # stage 4 (sr_ratio 1) always takes; tests/test_sra_block_gpu.py runs a block both ways and compares
 SRA_FUSED = True
+# the Mlp half of a block as ONE launch where the shape fits (emip_mlp_block: the 22 x 22 stage).  False = emip_mlp_fc1dw + the
+# fc2 GEMM; tests/test_mlp_block_gpu.py runs a block both ways and compares
+MLP_BLOCK = True
 
 _lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
 
@@ -204,6 +207,9 @@ class Block(EmipModule):
                 out["pf"] = f(wp).to(dt)[sw][:, sw].contiguous()
             if sr > 1:      # ... and per tap for the spatial-reduction conv (emip_conv8 with ln_stats): [sr*sr, C]
                 out["tsr"] = out["sr"].float().view(out["sr"].shape[0], sr * sr, -1).sum(2).t().contiguous()
+            if dt == torch.bfloat16 and out["w1"].shape == (1280, 320):
+                # emip_mlp_block: the per-chunk constant blocks (taps, depthwise bias, fc1 bias, column sums of the packed W1)
+                out["mcst"] = ops.mlp_block_consts(out["wd"], out["bd"], out["b1"], out["sw1"])
             return out
         params = (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, a.q.weight, a.q.bias,
                   a.kv.weight, a.kv.bias, a.proj.weight, a.proj.bias, m.fc1.weight, m.fc1.bias,
@@ -219,9 +225,10 @@ class Block(EmipModule):
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
         return 2 * (Ms + 2 * M)
 
-    def run_fused(self, x, stats, buf):
+    def run_fused(self, x, stats, buf, alt=None):
         """Inference block without LayerNorm launches.  x [B,H,W,C] (updated in place), stats f32 [B*H*W, 2] = (sum, sum of
-        squares) of its rows, buf: this block's slice of the stage's ZEROED scratch -> (x, stats of the new rows)."""
+        squares) of its rows, buf: this block's slice of the stage's ZEROED scratch, alt: a second token buffer of x's shape
+        (the one-launch Mlp half writes out of place) -> (new x, stats of its rows, the token buffer that is free now)."""
         a = self.attn
         dt, C, heads, sr = self.cdtype, a.dim, a.num_heads, a.sr_ratio
         B, H, W, _ = x.shape
@@ -265,6 +272,10 @@ class Block(EmipModule):
             ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)
         # ---- Mlp half: x += fc2(GELU(dwconv(fc1(LN(x)))))
         hid = w["w1"].shape[0]
+        if MLP_BLOCK and alt is not None and "mcst" in w and ops.mlp_block_eligible(B, H, W, C, hid):
+            # the whole Mlp half in one launch: the hidden tensor never leaves the CU (out of place: bands read halo rows)
+            ops.mlp_block(x, w["w1"], w["w2"], w["mcst"], w["b2"], st1, self.norm2.eps, alt, out_stats=st2)
+            return alt, st2, x
         if bf and ops.mlp_fc1dw_eligible(B, H, W, C, hid):
             # fc1 + depthwise 3x3 + GELU in one launch, one whole image per workgroup: the fc1 output never leaves the CU
             t = ops.mlp_fc1dw(x, w["w1"], w["b1"], w["sw1"], st1, self.norm2.eps, w["wd"], w["bd"])
@@ -272,7 +283,7 @@ class Block(EmipModule):
             t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, colsum=cs("w1"))
             t = ops.dwconv3x3(t, w["wd"], w["bd"], act=ops.ACT_GELU)
         ops.gemm(t, w["w2"], bias=w["b2"], res=x, out=x, out_stats=st2)
-        return x, st2
+        return x, st2, alt
 
     def run(self, x):
         if self.training and self.drop_path_rate > 0:
@@ -388,8 +399,9 @@ class PyramidVisionTransformerV2(EmipModule):
                 per = Block.scratch_floats(x.shape[0], Ho, Wo, a0.dim, a0.sr_ratio)
                 scratch = torch.empty(len(blocks) * per, dtype=torch.float32, device=x.device)
                 x = pe.run(x, out_stats=stats, zero=scratch)
+                alt = torch.empty_like(x)
                 for j, blk in enumerate(blocks):
-                    x, stats = blk.run_fused(x, stats, scratch[j * per:(j + 1) * per])
+                    x, stats, alt = blk.run_fused(x, stats, scratch[j * per:(j + 1) * per], alt)
             else:
                 x = pe.run(x)
                 if self.training:

@@ -585,6 +585,32 @@ def mlp_fc1dw(x, w1, b1, colsum, ln_stats, eps, wd, bd):
     return out
 
 
+def mlp_block_eligible(B, H, W, C, N):
+    return bool(_lib.load().emip_mlp_block_eligible(B, H, W, C, N))
+
+
+def mlp_block_consts(wd, bd, b1, colsum):
+    """the per-chunk constant blocks of emip_mlp_block: f32 [N / 64][12][64] = 9 depthwise taps | bd | b1 | colsum(W1)
+    from wd f32 [9, N] and the three f32 [N] vectors"""
+    N = wd.shape[1]
+    rows = torch.cat((wd.float(), bd.float().view(1, N), b1.float().view(1, N), colsum.float().view(1, N)), 0)     # [12, N]
+    return rows.view(12, N // 64, 64).permute(1, 0, 2).contiguous()
+
+
+def mlp_block(x, w1, w2, cst, b2, ln_stats, eps, out, out_stats=None):
+    """out = x + fc2(GELU(dwconv3x3(LN(x) w1^T + b1) + bd)) + b2, one launch (bf16, C = 320, N = 1280); out must not alias x"""
+    B, H, W, C = x.shape
+    M, _, ldx = rows(x)
+    _, _, ldo = rows(out)
+    N = w1.shape[0]
+    assert x.dtype == w1.dtype == w2.dtype == out.dtype == torch.bfloat16 and w1.is_contiguous() and w2.is_contiguous()
+    assert w1.shape == (N, C) and w2.shape == (C, N) and cst.shape == (N // 64, 12, 64) and cst.is_contiguous()
+    assert out.shape == x.shape and out.data_ptr() != x.data_ptr()
+    _lib.call("emip_mlp_block", _p(x), ldx, _p(w1), _p(w2), _p(cst), _p(b2), _p(ln_stats), float(eps), _p(out), ldo,
+              _p(out_stats), B, H, W, C, N, _stream())
+    return out
+
+
 def dwconv3x3_dual(x, wt, bias, act):
     """-> (act(dwconv(x)), dwconv(x)): activation output and pre-activation values from one pass"""
     B, H, W, C = x.shape

@@ -377,6 +377,19 @@ int emip_conv2d_wgrad_into(const void* dY, const void* X, float* dW, int B, int 
 int emip_mlp_fc1dw(const void* X, long ldx, const void* W1, const float* b1, const float* colsum, const float* ln_stats,
                    float eps, const float* Wdw, const float* bd, void* G, long ldg, int B, int H, int Wd, int K, int N,
                    void* stream);
+
+/* The whole Mlp half of a PVTv2 block in one launch (bf16 inference, the 22 x 22 stage: C = 320, hidden N = 1280):
+ * Out = X + fc2(GELU(dwconv3x3(LN(X) W1^T + b1) + bd)) + b2 per image (lib/pvt_v2.py:45-54,165-169,316-327), out_stats =
+ * (sum, sum of squares) of the rows of Out for the next block's LayerNorm (may be NULL).  The hidden tensor never leaves
+ * the CU: a workgroup owns a band of image rows (+ one halo row each side) for all hidden channels.  X, Out: bf16
+ * [B, H, W, C], Out must NOT overlap X (a band's halo rows are another band's outputs).  W1: bf16 [N][C] with the norm's
+ * scale folded in; W2: bf16 [C][N]; cst: f32 [N / 64][12][64] = per 64-channel chunk of the hidden tensor its 9 depthwise
+ * taps, the depthwise bias, fc1's bias (+ W1 beta) and the row sums of the packed W1; b2: f32 [C]; ln_stats: f32 [B H W][2]
+ * (sum, sum of squares) of the rows of X. */
+int emip_mlp_block_eligible(int B, int H, int W, int C, int N);
+int emip_mlp_block(const void* X, long ldx, const void* W1, const void* W2, const float* cst, const float* b2,
+                   const float* ln_stats, float eps, void* Out, long ldo, float* out_stats, int B, int H, int W, int C,
+                   int N, void* stream);
 int emip_mlp_fc1dw_eligible(int B, int H, int Wd, int K, int N);
 
 /* The large-launch body of the weight gradients (bf16, dense operands, M >= 2048): the same contraction as emip_gemm_tn on a

@@ -141,7 +141,7 @@ def test_pvt_block_fused_path_uses_it_and_matches_the_unfused_launches():
             buf = torch.zeros(pvt_v2.Block.scratch_floats(B, H, W, C, 2), device="cuda")
             rec = []
             _lib.profile(rec)
-            y, st = blk.run_fused(x, stats, buf)
+            y, st, _ = blk.run_fused(x, stats, buf)
             _lib.profile(None)
             torch.cuda.synchronize()
             names = [r[0] for r in rec]
