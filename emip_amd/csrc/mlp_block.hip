@@ -54,7 +54,15 @@ struct MbArgs {
     int B, H, W, nbands, xcd_map;
     float eps;
     unsigned x_bytes, w1_bytes, w2_bytes, cst_bytes;
+#ifdef EMIP_TUNING
+    int skip;               // calibration build only: 1 no fc1 MFMAs, 2 no depthwise pass, 4 no fc2 MFMAs, 8 no weight DMA, 16 no H store
+#endif
 };
+#ifdef EMIP_TUNING
+#define MB_SKIP(bit) (p.skip & (bit))
+#else
+#define MB_SKIP(bit) false
+#endif
 
 constexpr int MB_C = 320, MB_N = 1280, MB_NC = 64, MB_NCHUNK = MB_N / MB_NC;
 constexpr int MB_T1 = 10, MB_T2 = 7;                       // 16-token tiles: fc1 rows (band + halo), fc2 rows (band)
@@ -147,13 +155,14 @@ __global__ __launch_bounds__(640) void mlp_block_kernel(const MbArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        issue_w2(c);
+        if (!MB_SKIP(8)) issue_w2(c);
         const float* cs = reinterpret_cast<const float*>(smem + MB_CST + (c & 1) * 3072);    // [12][64]: taps 0..8, bd, b1, colsum
 
         // ---- fc1: H^T tile = W1c (A: 16 channels x 32 k) x tokens (B), 4 channel tiles x 10 k-steps
         f32x4 acc1[4];
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) acc1[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!MB_SKIP(1))
 #pragma unroll
         for (int s = 0; s < 10; ++s) {
             const char* slab = smem + MB_W1 + s * 4096;
@@ -167,6 +176,7 @@ __global__ __launch_bounds__(640) void mlp_block_kernel(const MbArgs p) {
         }
         // ---- output-side LayerNorm + bias -> H (bf16 [halo token][64 ch], 128-B rows, chunk ^ (token & 7))
         // acc1[ct][j] = channel 16 ct + 4 fq + j of token th
+        if (!MB_SKIP(16))
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             const int col = 16 * ct + 4 * fq;
@@ -181,13 +191,13 @@ __global__ __launch_bounds__(640) void mlp_block_kernel(const MbArgs p) {
         }
         // ---- (C) H is complete (so every wave is through with W1 chunk c): fetch the next one, run the depthwise pass
         __syncthreads();
-        if (c + 1 < MB_NCHUNK) issue_w1(c + 1);
+        if (c + 1 < MB_NCHUNK && !MB_SKIP(8)) issue_w1(c + 1);
         int tt = tid;
         asm volatile("" : "+v"(tt));
         const int cg = tt & 7, pr = tt >> 3;
         const int py = pr < npair ? y0 + pr / W2p : -4;     // image row of the pair (-4: none)
         const int px = 2 * (pr - (pr / W2p) * W2p);
-        if (py >= 0) {
+        if (py >= 0 && !MB_SKIP(2)) {
             float o[2][8];
 #pragma unroll
             for (int j = 0; j < 8; j += 4) {
@@ -254,6 +264,7 @@ __global__ __launch_bounds__(640) void mlp_block_kernel(const MbArgs p) {
         }
         __syncthreads();
         // ---- fc2: out^T tiles += W2c (A: 16 output channels x 32 k) x G (B: 32 k x 16 own tokens)
+        if (!MB_SKIP(4))
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2) {
             uint4 af[2];
@@ -316,6 +327,11 @@ __global__ __launch_bounds__(640) void mlp_block_kernel(const MbArgs p) {
 
 }  // namespace
 
+#ifdef EMIP_TUNING
+static int g_mb_skip = 0;
+extern "C" int emip_debug_set_mb(int flags) { g_mb_skip = flags; return 0; }
+#endif
+
 // bands per image so that band + halo <= 160 tokens and band <= 112 tokens; 0 = the shape does not fit this kernel
 static int mb_bands(int H, int W) {
     for (int nb = 1; nb <= H; ++nb) {
@@ -364,6 +380,9 @@ extern "C" int emip_mlp_block(const void* X, long ldx, const void* W1, const voi
     a.w1_bytes = (unsigned)((long)MB_N * MB_C * 2);
     a.w2_bytes = (unsigned)((long)MB_C * MB_N * 2);
     a.cst_bytes = (unsigned)(MB_NCHUNK * 12 * 64 * 4);
+#ifdef EMIP_TUNING
+    a.skip = g_mb_skip;
+#endif
     static bool attr = false;
     if (!attr) {
         attr = true;

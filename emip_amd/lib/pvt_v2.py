@@ -31,9 +31,13 @@ SRA_BLOCK_MAXC = 128
 # q projection inside the attention launch (emip_sra_block / emip_sra_qattn).  False = q GEMM + emip_sra_attention, the form
 # stage 4 (sr_ratio 1) always takes; tests/test_sra_block_gpu.py runs a block both ways and compares
 SRA_FUSED = True
-# the Mlp half of a block as ONE launch where the shape fits (emip_mlp_block: the 22 x 22 stage).  False = emip_mlp_fc1dw + the
-# fc2 GEMM; tests/test_mlp_block_gpu.py runs a block both ways and compares
-MLP_BLOCK = True
+# the Mlp half of a block as ONE launch where the shape fits (emip_mlp_block: the 22 x 22 stage; bit-identical to
+# emip_mlp_fc1dw + the fc2 GEMM, tests/test_mlp_block_gpu.py runs a block both ways).  OFF: measured on MI355X at 32 images
+# the launch takes 119 us against 49 + 30 us for the two it replaces -- its fc1 / depthwise / fc2 phases run one after the
+# other on 10 waves per CU (phase ablation: depthwise + GELU 43 us, fc2 26, fc1 18, H stores 8, 60 barriers + prologue 24) --
+# and with three steps in flight the throughput follows the SUM of the kernels' isolated times, not the CUs a launch leaves
+# free: 1401 against 1536 pairs/s (tools/flag_ab.py).  What it would take: DESIGN.md section 7d.
+MLP_BLOCK = False
 
 _lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
 

@@ -90,7 +90,7 @@ def test_block_run_fused_with_and_without_the_one_launch_mlp():
                 assert ("emip_mlp_block" in names) == flag and ("emip_mlp_fc1dw" in names) != flag, names
                 outs.append((y.float().clone(), st.clone()))
             finally:
-                pvt_v2.MLP_BLOCK = True
+                pvt_v2.MLP_BLOCK = False
                 _lib.profile(None)
         (a, sa), (b, sb) = outs
         top = max(1.0, b.abs().max().item())
