@@ -96,6 +96,8 @@ def _window_attention(q, k, v, B2, h, w, C, ldq, ldk, ldv, shift, splits, kv_rot
     L = (h // splits) * (w // splits)
     out = torch.empty((B2, h * w, C), dtype=q.dtype, device=q.device)
     n = h * w
+    if q.dtype == torch.bfloat16 and C == 128 and 64 <= L <= 512:
+        return ops.window_attention(q[..., :C], k[..., :C], v[..., :C], out, rows, gid if shift else None, n, C ** -0.5, kv_rot)
     ops.attention(q, k, v, out, batch=B2, heads=1, nwin=splits * splits, Lq=L, Lk=L, D=C, DV=C, q_bs=n * ldq,
                   k_bs=n * ldk, v_bs=n * ldv, o_bs=n * C, ldq=ldq, ldk=ldk, ldv=ldv, ldo=C, q_rows=rows, k_rows=rows,
                   q_gid=gid if shift else None, k_gid=gid if shift else None, scale=C ** -0.5, kv_rot=kv_rot)

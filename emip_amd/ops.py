@@ -458,6 +458,21 @@ def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_
     return out
 
 
+def window_attention(q, k, v, out, rows, gid, tokens, scale, kv_rot=0):
+    """emip_window_attention: q / k / v / out [B, tokens, >=128] bf16 views (unit channel stride), rows / gid int32 [nwin, L]"""
+    _dev(q)
+    B = q.shape[0]
+    nwin, L = rows.shape
+    assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16 and rows.dtype == torch.int32 and rows.is_contiguous()
+    assert gid is None or (gid.dtype == torch.int32 and gid.shape == rows.shape and gid.is_contiguous())
+    for t in (q, k, v, out):
+        assert t.dim() == 3 and t.shape[0] == B and t.shape[1] == tokens and t.stride(2) == 1
+    _lib.call("emip_window_attention", _p(q), _p(k), _p(v), _p(out), B, nwin, L, q.stride(1), k.stride(1), v.stride(1),
+              out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0), _p(rows), _p(gid), int(tokens), int(kv_rot),
+              float(scale), _stream())
+    return out
+
+
 def match(q, k, W, scale, v=None, scores=None, kv_rot=0, sub_grid=True):
     """emip_match: q, k bf16 [Z, n, 128] (unit channel stride), v f32 [Z, n, 2] or None (= the pixel grid of width W),
     scores bf16 [Zs, n, n] or None -> f32 [Z, n, 2]; keys / values of batch z come from batch (z + kv_rot) mod Z"""

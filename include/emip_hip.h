@@ -246,6 +246,15 @@ int emip_attention_rot(const void* Q, const void* K, const void* V, void* O, voi
 int emip_match(const void* Q, const void* K, const float* V, void* S, float* Out, int Z, int Zs, int n, int W, long ldq,
                long ldk, long q_bs, long k_bs, int kv_rot, float scale, int sub_grid, void* stream);
 
+/* GMFlow split-window attention (gmflow/transformer.py:46-105, masks :19-43) on a kernel built for the shape (bf16, one head,
+ * D = DV = 128, windows of L <= 512 tokens): O[rows[win][q]] = softmax_k(scale <Q[rows[win][q]], K[rows[win][k]]> - 100
+ * [gid[win][q] != gid[win][k]]) V[rows[win][k]].  Q, K, V, O: token matrices of B frames of `tokens` tokens (row strides
+ * ld*, batch strides *_bs, in elements); rows / gid: int [nwin][L] (gid NULL: no mask); keys / values of frame b come from
+ * frame (b + kv_rot) mod B (cross attention between the two frames of a pair). */
+int emip_window_attention(const void* Q, const void* K, const void* V, void* O, int B, int nwin, int L, long ldq, long ldk,
+                          long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs, const int* rows, const int* gid,
+                          int tokens, int kv_rot, float scale, void* stream);
+
 /* MDTA channel attention matrix: L2-normalise q,k over pixels, 64x64 Gram per head, * temperature, softmax.
  * PromptInteract.py:423-428.  ws: f32 [B*heads*(4096+128)] scratch; attn out: T [B][heads][64][64]. */
 int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K, long ldk, long k_bs, const float* temperature,
