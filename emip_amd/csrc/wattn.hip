@@ -49,7 +49,15 @@ struct WaArgs {
     int B, nwin, L, rot, qblocks;
     float scale;
     unsigned k_bytes, v_bytes;
+#ifdef EMIP_TUNING
+    int skip;      // calibration build only: 1 no S MFMAs, 2 no softmax, 4 no PV, 8 no DMA, 16 no V reads (PV MFMAs on stale registers)
+#endif
 };
+#ifdef EMIP_TUNING
+#define WA_SKIP(bit) (p.skip & (bit))
+#else
+#define WA_SKIP(bit) false
+#endif
 
 constexpr unsigned WA_OOB = 0x80000000u;
 constexpr int WA_BK = 64, WA_NST = 3, WA_KT = WA_BK * 256, WA_STAGE = 2 * WA_KT, WA_LMAX = 512;
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                      // ... for every wave; everyone has left tile t - 1's slot
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < ntile) issue(t + 2);
+        if (t + 2 < ntile && !WA_SKIP(8)) issue(t + 2);
 
         const char* kt_ = smem + (t % WA_NST) * WA_STAGE;
         const char* vt_ = kt_ + WA_KT;
@@ -136,6 +144,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
             const int row = 32 * kt + lq;
             const char* rp = kt_ + row * 256;
+            if (!WA_SKIP(1))
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const uint4 kf = *reinterpret_cast<const uint4*>(rp + (((2 * i + h) ^ (row & 15)) * 16));
@@ -144,6 +153,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
             }
         }
         // ---- scale, mask (register 4 g + j of block kt = key t 64 + 32 kt + 8 g + 4 h + j), keys beyond L out
+        if (!WA_SKIP(2)) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -192,7 +202,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
                 psum += e;
             }
         l_run += psum;
+        }
         // ---- O^T += V^T P
+        if (!WA_SKIP(4))
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -238,6 +250,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
 
 }  // namespace
 
+#ifdef EMIP_TUNING
+static int g_wa_skip = 0;
+extern "C" int emip_debug_set_wa(int flags) { g_wa_skip = flags; return 0; }
+#endif
+
 // Q, K, V, O: bf16 token matrices of B frames (batch strides q_bs ... o_bs, row strides ldq ... ldo, in elements; 128
 // channels at the pointer); rows: int [nwin][L] frame token of every window-local token, gid: int [nwin][L] region ids of the
 // shifted layout or NULL (no mask); keys / values of frame b are read from frame (b + kv_rot) mod B.  L <= 512.
@@ -257,6 +274,9 @@ extern "C" int emip_window_attention(const void* Q, const void* K, const void* V
     a.qblocks = (L + 255) / 256;
     a.k_bytes = (unsigned)(((long)(tokens - 1) * ldk + 128) * 2);
     a.v_bytes = (unsigned)(((long)(tokens - 1) * ldv + 128) * 2);
+#ifdef EMIP_TUNING
+    a.skip = g_wa_skip;
+#endif
     static bool attr = false;
     if (!attr) {
         attr = true;

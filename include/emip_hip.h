@@ -648,6 +648,7 @@ int emip_debug_set_tn(int target_workgroups);   /* 0 = heuristic split count of 
 int emip_debug_set_lnb(int wide);               /* 0 = the narrow LayerNorm-backward kernel */
 int emip_debug_set_dww(int chunks);             /* row chunks per image of the depthwise weight gradient (0 = auto) */
 int emip_debug_set_tn8(int ring_depth, int target_workgroups);   /* emip_gemm_tn8: 2..4 stages; 0 = heuristic split count */
+int emip_debug_set_wa(int flags);              /* emip_window_attention ablations: 1 no S MFMAs, 2 no softmax, 4 no PV, 8 no DMA */
 int emip_debug_set_mb(int flags);              /* emip_mlp_block ablations: 1 no fc1 MFMAs, 2 no depthwise pass, 4 no fc2 MFMAs, 8 no weight DMA, 16 no H store */
 int emip_tuning_gemm8_dbg(int flags);           /* gemm8 ablations: 1 no epilogue stores, 2 no MFMA, 4 no operand loads, 8 bare launch */
 #endif
