@@ -947,6 +947,45 @@ extern "C" int emip_conv2d_splitk(const void* X, const void* W, void* Y, const f
     return dtype == EMIP_F32 ? dispatch<float, true>(a, 1, s) : dispatch<bf16_t, true>(a, 1, s);
 }
 
+// Split-K with the reduction INSIDE the launch: ksplit workgroups share every output tile, each walks 1/ksplit of the K tiles
+// and adds its partial tile into acc (f32 [B*Ho*Wo][Cout], ZERO on entry) with atomics; the last of them to arrive at the
+// tile's ticket (u32 per 64x64 tile, ZERO on entry) takes the sums back out (leaving acc and ticket zero again) and runs the
+// normal epilogue: bias, activation, storage type, row statistics.  For the launches of this network with few output tiles
+// and a long K walk -- the 3x3 reductions to 32 channels in front of the decoder (create_backbone.py:199-208: 11 x 11 x 512
+// -> 32 is 31 tiles walking 72 K tiles, 73 us) and the 8 x 8 / 4 x 4 spatial-reduction convs (lib/pvt_v2.py:106-108).
+extern "C" int emip_conv2d_ksplit(const void* X, const void* W, void* Y, const float* bias, int B, int H, int Wd, int Cin,
+                                  long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, int act,
+                                  const float* ln_stats, float ln_eps, float* out_stats, float* acc, void* ticket, int ksplit,
+                                  int dtype, void* stream) {
+    EMIP_REQUIRE(X && W && Y && acc && ticket && B > 0 && H > 0 && Wd > 0 && Cin > 0 && Cout > 0);
+    EMIP_REQUIRE(ksplit >= 2 && ksplit <= 64 && (reinterpret_cast<uintptr_t>(acc) & 3) == 0 &&
+                 (reinterpret_cast<uintptr_t>(ticket) & 3) == 0);
+    EMIP_REQUIRE(dtype == EMIP_F32 || dtype == EMIP_BF16);
+    EMIP_REQUIRE(KH > 0 && KW > 0 && stride > 0 && pad >= 0);
+    const int vec = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(Cin % vec == 0 && ldx % vec == 0 && ldx >= Cin && ldy >= Cout);
+    EMIP_REQUIRE(aligned16(X) && aligned16(W));
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
+    EMIP_REQUIRE(Ho > 0 && Wo > 0);
+    EMIP_REQUIRE((long)B * Ho * Wo < 2147483647L && (long)KH * KW * Cin < 2147483647L && (long)H * Wd * ldx < 2147483647L);
+    EMIP_REQUIRE(act >= EMIP_ACT_NONE && act <= EMIP_ACT_GELU);
+    GemmArgs a{};
+    a.A = X; a.W = W; a.C = Y; a.bias = bias; a.R = nullptr;
+    a.M = B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin; a.K1 = a.K;
+    a.lda = ldx; a.ldw = a.K; a.ldc = ldy; a.ldr = 0; a.act = act;
+    a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.ln_stats = ln_stats; a.ln_C = Cin; a.ln_eps = ln_eps; a.out_stats = out_stats;
+    a.acc_out = acc; a.ldacc = Cout; a.ksplit = ksplit; a.ticket = static_cast<unsigned*>(ticket);
+    a.heads = 1;
+    {
+        const bool fast = (ldy % vec) == 0 && aligned16(Y) && Cout % vec == 0;
+        if (check_ln(a, 1, fast) != EMIP_OK) return EMIP_E_INVALID;
+    }
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    // the ticket protocol is written for 64 x 64 tiles (one counter per tile of that grid)
+    return dtype == EMIP_F32 ? launch<float, 64, 64, true>(a, 1, s) : launch<bf16_t, 64, 64, true>(a, 1, s);
+}
+
 // ---- two convs in one launch -------------------------------------------------------------------------------------------
 struct emip_conv_desc_t {      // mirrors emip_conv_desc of include/emip_hip.h
     const void* X; const void* W; void* Y; const float* bias; const void* R;

@@ -25,9 +25,12 @@ from ..nn_base import EmipModule, conv_dgrad_pack, f32, lin_packs, pack_conv, pa
 # What was measured and dropped along the way (pair launch of q + sr conv, two split-K forms of the sr conv, the encoder on a
 # forked stream, the generic attention kernel for the bf16 stages) lives in tools/experiments/README.md, not here.
 FUSED_LN = True
-# widest stage whose attention half runs as ONE launch (emip_sra_block: q + attention + proj + residual); the 320-channel
-# stage has too few 128-query workgroups for it at 16 images and takes emip_sra_qattn + the proj GEMM
+# widest stage whose attention half ALWAYS runs as one launch (emip_sra_block: q + attention + proj + residual).  The
+# 320-channel stage has too few 128-query workgroups for it at 16 images (35.8 us against 30.3 for emip_sra_qattn + the proj
+# GEMM) and takes it from SRA_BLOCK_WIDE_ROWS token rows on: at the 32 images of a whole 16-pair step it is
+# ahead (1587 against 1580 pairs/s in-process, tools/flag_ab.py) and 40 launches fewer
 SRA_BLOCK_MAXC = 128
+SRA_BLOCK_WIDE_ROWS = 12000
 # q projection inside the attention launch (emip_sra_block / emip_sra_qattn).  False = q GEMM + emip_sra_attention, the form
 # stage 4 (sr_ratio 1) always takes; tests/test_sra_block_gpu.py runs a block both ways and compares
 SRA_FUSED = True
@@ -38,6 +41,9 @@ SRA_FUSED = True
 # and with three steps in flight the throughput follows the SUM of the kernels' isolated times, not the CUs a launch leaves
 # free: 1401 against 1536 pairs/s (tools/flag_ab.py).  What it would take: DESIGN.md section 7d.
 MLP_BLOCK = False
+# the spatial-reduction convs with few output tiles and a long K walk (stages 1-2: 61 tiles x 64 / 32 K tiles at 32 images)
+# split K inside the launch (emip_conv2d_ksplit, the normalising loader) instead of the per-tap ring body
+SR_KSPLIT = True
 
 _lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
 
@@ -245,7 +251,11 @@ class Block(EmipModule):
         cs = (lambda k: w["s" + k]) if bf else (lambda k: None)       # bf16: output-side LayerNorm (column sums); f32: loader
         # ---- attention half: x += proj(softmax(q k^T scale) v)
         if sr > 1:
-            if bf:   # raw patches on the LDS-DMA ring, LayerNorm per tap on the output side (the statistics ride the ring)
+            ks = ops.ksplit_for(Ms, C, sr * sr * C, dt) if (SR_KSPLIT and bf) else 0
+            if ks:   # 8 x 8 / 4 x 4 reductions: few output tiles walking 32-64 K tiles -> K split inside the launch
+                s = ops.conv2d_ksplit(x, w["sr"], sr, sr, sr, 0, ks, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps,
+                                      out_stats=st_sr)
+            elif bf:   # raw patches on the LDS-DMA ring, LayerNorm per tap on the output side (the statistics ride the ring)
                 s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
                               out_stats=st_sr)
             else:
@@ -256,7 +266,7 @@ class Block(EmipModule):
             kv = ops.gemm(x, w["kv"], bias=w["bkv"], ln_stats=stats, ln_eps=self.norm1.eps, colsum=cs("kv"))
         Lk = s.shape[1] * s.shape[2]
         fused = SRA_FUSED and "qf" in w and ops.sra_block_eligible(C, Lk)
-        if fused and C <= SRA_BLOCK_MAXC:
+        if fused and (C <= SRA_BLOCK_MAXC or M >= SRA_BLOCK_WIDE_ROWS):
             # q projection + attention + proj + residual in ONE launch
             ops.sra_block(x, stats, self.norm1.eps, w["qf"], w["bq"], w["sq"], kv.view(B, -1, 2 * C), w["pf"], w["bp"], heads,
                           a.scale, out_stats=st1)

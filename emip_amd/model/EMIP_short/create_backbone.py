@@ -14,6 +14,11 @@ from ...autograd import BilinearFn, BilinearPlanarFn, BNReluFn, ConcatFn, ConvFn
 from ...nn_base import EmipModule, f32, conv_dgrad_pack, fold_bn, pack_conv, to_cl, to_planar
 
 
+# eval-mode ConvBR launches with few output tiles and a long K walk split K inside the launch (emip_conv2d_ksplit);
+# tests/test_ops_gpu.py compares both forms
+KSPLIT = True
+
+
 class ConvBR(EmipModule):
     """conv3x3 (no bias) + BatchNorm2d + ReLU (create_backbone.py:22-42)."""
 
@@ -37,6 +42,12 @@ class ConvBR(EmipModule):
         w, b = self.packed("w", (self.conv.weight, self.bn.weight, self.bn.bias, self.bn.running_mean,
                                  self.bn.running_var),
                            lambda cw, *_: (lambda wb: (pack_conv(wb[0], dt), wb[1]))(fold_bn(cw, None, self.bn)))
+        if KSPLIT and out is None and x.is_cuda:
+            B, H, W, Cin = x.shape
+            Ho, Wo = (H + 2 * self.p - self.k) // self.s + 1, (W + 2 * self.p - self.k) // self.s + 1
+            ks = ops.ksplit_for(B * Ho * Wo, w.shape[0], self.k * self.k * Cin, dt)
+            if ks:      # few output tiles, long K walk (the reductions of the 11 x 11 / 22 x 22 stages to 32 channels)
+                return ops.conv2d_ksplit(x, w, self.k, self.k, self.s, self.p, ks, bias=b, act=ops.ACT_RELU)
         return ops.conv2d(x, w, self.k, self.k, self.s, self.p, bias=b, act=ops.ACT_RELU, out=out)
 
     def forward(self, x):

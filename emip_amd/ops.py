@@ -318,6 +318,38 @@ def conv2d_splitk(x, w, kh, kw, stride, pad, bias, acc, ksplit, ln_stats=None, l
     return acc
 
 
+def ksplit_for(M, Cout, K, dtype):
+    """split count of emip_conv2d_ksplit for an [M, Cout] output over K: 0 = enough tiles / too short a walk to split"""
+    tiles = ((M + 63) // 64) * ((Cout + 63) // 64)
+    nk = K // (64 if dtype == torch.bfloat16 else 32)
+    if tiles >= 192 or nk < 16:
+        return 0
+    return max(2, min(nk // 4, (256 + tiles - 1) // tiles, 16))
+
+
+def conv2d_ksplit(x, w, kh, kw, stride, pad, ksplit, bias=None, act=ACT_NONE, ln_stats=None, ln_eps=0.0, out_stats=None, out=None):
+    """conv2d / conv2d_ln with the K walk split over `ksplit` workgroups per tile and reduced inside the launch; the zeroed
+    accumulator + tickets are one fresh allocation (inside a graph capture it is private to that graph, so concurrent replays
+    do not share it; the launch leaves it zero)"""
+    _dev(x)
+    B, H, W, Cin = x.shape
+    Cout = w.shape[0]
+    assert w.shape[1] == kh * kw * Cin and w.is_contiguous() and w.dtype == x.dtype
+    Ho = (H + 2 * pad - kh) // stride + 1
+    Wo = (W + 2 * pad - kw) // stride + 1
+    M = B * Ho * Wo
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=x.dtype, device=x.device)
+    Mo, No, ldy = rows(out)
+    assert Mo == M and No == Cout
+    ntick = ((M + 63) // 64) * ((Cout + 63) // 64)
+    scratch = torch.zeros(M * Cout + ntick, dtype=torch.float32, device=x.device)
+    _lib.call("emip_conv2d_ksplit", _p(x), _p(w), _p(out), _p(bias), B, H, W, Cin, x.stride(2), Cout, kh, kw, stride, pad, ldy,
+              act, _p(ln_stats), float(ln_eps), _p(out_stats), _p(scratch), scratch.data_ptr() + 4 * M * Cout, int(ksplit),
+              dt_code(x.dtype), _stream())
+    return out
+
+
 def rows_finalize(acc, dtype, shape, out_stats=None):
     """complete f32 rows [M, C] -> tensor of `shape` (last dim C) in `dtype`, + (sum, sum of squares) of the stored rows"""
     M, C = acc.shape

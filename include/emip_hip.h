@@ -183,6 +183,15 @@ int emip_conv2d_splitk(const void* X, const void* W, void* Y, const float* bias,
                        int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act,
                        void* zero_ptr, long zero_bytes, const float* ln_stats, float ln_eps, float* out_stats,
                        float* acc_out, long ldacc, int ksplit, int dtype, void* stream);
+
+/* emip_conv2d / emip_conv2d_ln with split-K reduced INSIDE the launch (no finalize launch): ksplit workgroups share every
+ * 64 x 64 output tile, the last to arrive at the tile's ticket takes the sums back and runs the normal epilogue (bias, act,
+ * storage type, row statistics).  acc: f32 [B*Ho*Wo][Cout], ticket: u32 [ceil(M/64) * ceil(Cout/64)], both ZERO on entry
+ * and left zero.  ln_stats may be NULL (plain conv: the decoder-side reductions, create_backbone.py:199-208) or the row
+ * statistics of the input pixels (the 8 x 8 / 4 x 4 spatial-reduction convs, lib/pvt_v2.py:106-108). */
+int emip_conv2d_ksplit(const void* X, const void* W, void* Y, const float* bias, int B, int H, int Wd, int Cin, long ldx,
+                       int Cout, int KH, int KW, int stride, int pad, long ldy, int act, const float* ln_stats, float ln_eps,
+                       float* out_stats, float* acc, void* ticket, int ksplit, int dtype, void* stream);
 int emip_rows_finalize(const float* A, long lda, void* Y, long ldy, float* out_stats, long M, int C, int dtype,
                        void* stream);
 

@@ -529,3 +529,41 @@ def test_mlp_fc1dw_fused_head(B, H, W, K, N):
     err = (fused.float() - ref).abs().max().item()
     assert err < 0.03 * max(1.0, ref.abs().max().item()), err
     assert not ops.mlp_fc1dw_eligible(B, 11, 11, K, N)         # 121 tokens would pad to 512 MFMA rows: two launches stay
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("B,H,Cin,Cout,k,s,p,ks,ln", [(16, 11, 512, 32, 3, 1, 1, 9, False), (4, 22, 320, 32, 3, 1, 1, 3, False),
+                                                      (4, 88, 64, 64, 8, 8, 0, 5, True), (5, 44, 128, 128, 4, 4, 0, 3, True),
+                                                      (2, 22, 320, 320, 2, 2, 0, 4, True)])
+def test_conv_split_k_reduced_inside_the_launch(dt, tol, B, H, Cin, Cout, k, s, p, ks, ln):
+    """emip_conv2d_ksplit against emip_conv2d / emip_conv2d_ln on the same operands: the decoder-side reductions (3 x 3, pad 1,
+    ReLU) and the spatial-reduction convs behind the folded LayerNorm with their row statistics.  Three launches: each gets a
+    fresh accumulator, and (second check) one explicit accumulator is left zero by every launch."""
+    from emip_amd import _lib, ops
+    g = torch.Generator().manual_seed(B * 100 + Cin + ks)
+    x = (torch.randn(B, H, H, Cin, generator=g) * 1.2 + 0.3).to(dt).cuda()
+    w = (torch.randn(Cout, k * k * Cin, generator=g) / (k * k * Cin) ** 0.5).to(dt).cuda()
+    b = (0.1 * torch.randn(Cout, generator=g)).cuda()
+    xf = x.float().view(-1, Cin)
+    stats = torch.stack([xf.sum(1), (xf ** 2).sum(1)], 1).contiguous() if ln else None
+    act = ops.ACT_NONE if ln else ops.ACT_RELU
+    Ho = (H + 2 * p - k) // s + 1
+    M = B * Ho * Ho
+    st_ref = torch.zeros(M, 2, device="cuda") if ln else None
+    ref = ops.conv2d(x, w, k, k, s, p, bias=b, act=act, ln_stats=stats, ln_eps=1e-6, out_stats=st_ref)
+    scale = max(1.0, ref.float().abs().max().item())
+    for _ in range(3):
+        st = torch.zeros(M, 2, device="cuda") if ln else None
+        y = ops.conv2d_ksplit(x, w, k, k, s, p, ks, bias=b, act=act, ln_stats=stats, ln_eps=1e-6, out_stats=st)
+        assert (y.float() - ref.float()).abs().max().item() < tol * scale
+        if ln:
+            assert ((st - st_ref).abs() / (st_ref.abs() + 1.0)).max().item() < (2e-2 if dt == torch.bfloat16 else 1e-3)
+    ntick = ((M + 63) // 64) * ((Cout + 63) // 64)
+    scratch = torch.zeros(M * Cout + ntick, device="cuda")
+    y = torch.empty_like(ref)
+    for _ in range(2):
+        _lib.call("emip_conv2d_ksplit", x.data_ptr(), w.data_ptr(), y.data_ptr(), b.data_ptr(), B, H, H, Cin, Cin, Cout, k, k, s, p,
+                  Cout, act, stats.data_ptr() if ln else None, 1e-6, None, scratch.data_ptr(), scratch.data_ptr() + 4 * M * Cout,
+                  ks, ops.dt_code(dt), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert (y.float() - ref.float()).abs().max().item() < tol * scale and scratch.abs().max().item() == 0
