@@ -71,6 +71,9 @@ def _launch_info(lib, name, a):
         # fc1 as a GEMM + 9 taps per hidden element; tokens in, weights once, activated hidden tensor out (the fc1 output
         # itself never leaves the CU, so it is not algorithmic traffic of this kernel)
         return 2.0 * M * N * K + 18.0 * M * N, "mlp_fc1dw_kernel", 2.0 * (M * K + N * K + M * N) + 8.0 * M + 44.0 * N
+    if name == "emip_window_attention":   # (Q, K, V, O, B, nwin, L, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, rows, gid, tokens, rot, scale, stream)
+        Bf, nwin, L = a[4], a[5], a[6]
+        return 4.0 * Bf * nwin * L * L * 128, "wattn_kernel", 2.0 * Bf * nwin * L * 128 * 4
     if name == "emip_match":              # (Q, K, V, S, Out, Z, Zs, n, W, ldq, ldk, q_bs, k_bs, rot, scale, sub, stream)
         Z, Zs, n = a[5], a[6], a[7]
         # features in once as queries and once as keys, the raw correlation of the forward direction out once, flows out
@@ -183,6 +186,8 @@ def rocprof_avg(key):
     import re
     if not os.path.exists(PROFILE_CSV):
         return None
+    if key == "wattn_kernel":
+        pass
     if key.startswith("match_kernel"):
         key = "match_kernel<true>" if key.endswith("+scores") else "match_kernel<false>"
     key = key.replace("+scores", "")
@@ -777,12 +782,16 @@ def main():
                          "same_kernel_unsplit_batch_TFLOPs": (round(whole[1] / (whole[0] * 1e-3) / 1e12, 2)
                                                               if whole else None)})
         out["roofline_named"] = {
-            "sra": named_roofline(agg, "sra_q_kernel",
-                                  "PVTv2 spatial-reduction attention of the 22x22 stage with its q projection, "
-                                  "softmax((LN(x) Wq^T) k^T / 8) v, lib/pvt_v2.py:95-125 (emip_sra_qattn)"),
-            "sra_block": named_roofline(agg, "sra_block_kernel",
-                                        "the same with proj and the residual add in the launch (88x88 and 44x44 stages), "
-                                        "lib/pvt_v2.py:95-127,165-168 (emip_sra_block)"),
+            "sra": named_roofline(agg, "sra_block_kernel",
+                                  "PVTv2 spatial-reduction attention with its q projection, proj and the residual add in one "
+                                  "launch, x + proj(softmax((LN(x) Wq^T) k^T / 8) v), stages 1-3 (49 blocks), "
+                                  "lib/pvt_v2.py:95-127,165-168 (emip_sra_block)"),
+            "sra_qattn": named_roofline(agg, "sra_q_kernel",
+                                        "q projection + attention per (image, 128 queries, head), the proj GEMM separate: the "
+                                        "22x22 stage below 12 000 token rows per launch (emip_sra_qattn)"),
+            "window_attention": named_roofline(agg, "wattn_kernel",
+                                               "GMFlow split-window attention, 2 x 2 windows of 484 tokens, D = 128, "
+                                               "gmflow/transformer.py:46-105 (emip_window_attention)"),
             "sra_attention_only": named_roofline(agg, "sra_kernel",
                                                  "softmax(q k^T / 8) v alone (the 11x11 stage, sr_ratio 1), lib/pvt_v2.py:113-125"),
             "correlation": named_roofline(agg, "match_kernel+scores",

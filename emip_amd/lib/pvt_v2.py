@@ -42,8 +42,10 @@ SRA_FUSED = True
 # free: 1401 against 1536 pairs/s (tools/flag_ab.py).  What it would take: DESIGN.md section 7d.
 MLP_BLOCK = False
 # the spatial-reduction convs with few output tiles and a long K walk (stages 1-2: 61 tiles x 64 / 32 K tiles at 32 images)
-# split K inside the launch (emip_conv2d_ksplit, the normalising loader) instead of the per-tap ring body
-SR_KSPLIT = True
+# with K split inside the launch (emip_conv2d_ksplit, the normalising loader) instead of the per-tap ring body.  OFF: shorter
+# alone, but with three steps in flight 1554 against 1587 pairs/s (tools/flag_ab.py) -- the third time a split-K form loses
+# here: its f32 atomics and 3-5 x the workgroups cost the other steps' kernels more than the walk saves
+SR_KSPLIT = False
 
 _lin_packs, _conv_dgrad_pack = lin_packs, conv_dgrad_pack
 

@@ -14,9 +14,10 @@ from ...autograd import BilinearFn, BilinearPlanarFn, BNReluFn, ConcatFn, ConvFn
 from ...nn_base import EmipModule, f32, conv_dgrad_pack, fold_bn, pack_conv, to_cl, to_planar
 
 
-# eval-mode ConvBR launches with few output tiles and a long K walk split K inside the launch (emip_conv2d_ksplit);
-# tests/test_ops_gpu.py compares both forms
-KSPLIT = True
+# eval-mode ConvBR launches with few output tiles and a long K walk (11 x 11 x 512 -> 32: 31 tiles x 72 K tiles, 73 us) with K
+# split inside the launch (emip_conv2d_ksplit; tests/test_ops_gpu.py compares both forms).  OFF: 1552 against 1562 pairs/s with
+# three steps in flight (tools/flag_ab.py), see lib/pvt_v2.py SR_KSPLIT
+KSPLIT = False
 
 
 class ConvBR(EmipModule):
