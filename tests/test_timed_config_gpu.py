@@ -139,8 +139,9 @@ def stage_table(net, g, im1, im2):
 
 
 # 1.5 x the errors observed on MI355X for the bf16 mode (profiles/r03_bf16_stage_errors.json has the table this was taken from)
-BF16_STAGE_BOUNDS = {"pvt_s2": 0.08, "pvt_s3": 0.08, "pvt_s4": 0.08, "gm": 0.08, "inj_a": 0.08, "corr": 0.08,
-                     "conv_corr": 0.08, "inj1": 0.08, "dr2": 0.08, "dr3": 0.08, "mask": 0.08}
+# 1.5 x the larger of two runs on MI355X (profiles/r03_bf16_stage_errors.json); the bf16 mode moves by ~10 % of these run to run
+BF16_STAGE_BOUNDS = {"pvt_s2": 0.019, "pvt_s3": 0.06, "pvt_s4": 0.027, "gm": 0.026, "inj_a": 0.027, "corr": 0.037,
+                     "conv_corr": 0.018, "inj1": 0.028, "dr2": 0.041, "dr3": 0.031, "mask": 0.05}
 
 
 def test_bf16_stage_error_table(model_args, short_sd, golden):
