@@ -202,6 +202,9 @@ class QSrFn(Function):
         return dh, dwq, dbq, dwsr, dbsr, None, None, None, None, None
 
 
+DW_BWD_FUSED = True         # emip_dwconv3x3_bwd_fused instead of gelu_bwd + dwconv3x3(flipped) + dwconv3x3_wgrad
+
+
 class DwConvFn(Function):
     """depthwise 3x3 (+ exact GELU).  wt: [9][C] f32 pack, wt_flip: taps reversed (input gradient)."""
 
@@ -213,6 +216,7 @@ class DwConvFn(Function):
             y = z = ops.dwconv3x3(x, wt, bias)
         ctx.save_for_backward(x, z if gelu else x, weight)
         ctx.cfg = (wt_flip, gelu, bias is not None)
+        ctx.wt = wt
         return y
 
     @staticmethod
@@ -220,6 +224,15 @@ class DwConvFn(Function):
         x, z, weight = ctx.saved_tensors
         wt_flip, gelu, has_bias = ctx.cfg
         dy = dy.contiguous()
+        C = x.shape[-1]
+        if (DW_BWD_FUSED and x.dtype == torch.bfloat16 and C % 8 == 0 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                and x.is_contiguous() and z.is_contiguous()):
+            # one pass over the hidden gradient: GELU backward, input gradient and weight / bias gradient (dw_bwd.hip);
+            # the weight gradient comes out in the parameter's own order, so autograd receives arena views as they are
+            acc = ops.grad_zeros((10 * C,), x.device)
+            dwt, dbt = acc[:9 * C], (acc[9 * C:] if has_bias else None)
+            dx = ops.dwconv3x3_bwd_fused(x, z, dy, ctx.wt, dwt, dbt, gelu)
+            return dx, dwt.view(weight.shape), dbt, None, None, None
         dz = ops.gelu_bwd(z, dy) if gelu else dy
         dx = ops.dwconv3x3(dz, wt_flip) if ctx.needs_input_grad[0] else None
         dw = db = None

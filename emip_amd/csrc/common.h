@@ -80,8 +80,7 @@ __device__ __forceinline__ float gelu_poly(float x) {
 template <>
 __device__ __forceinline__ float gelu_t<bf16_t>(float x) { return gelu_poly(x); }
 
-// d gelu(z) / dz = Phi(z) + z phi(z).  bf16 mode shares ONE exp between the Abramowitz-Stegun erf and the density
-// (both need e^{-z^2/2}); f32 parity mode keeps libm's erff / expf.
+// d gelu(z) / dz = Phi(z) + z phi(z).  f32 parity mode keeps libm's erff / expf.
 template <typename T>
 __device__ __forceinline__ float gelu_grad_t(float z);
 template <>
@@ -90,18 +89,26 @@ __device__ __forceinline__ float gelu_grad_t<float>(float z) {
     const float pdf = 0.3989422804014327f * expf(-0.5f * z * z);
     return cdf + z * pdf;
 }
-template <>
-__device__ __forceinline__ float gelu_grad_t<bf16_t>(float z) {
-    const float az = fabsf(z) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, az, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * z * z);      // e^{-z^2/2}
-    const float cdf = 0.5f * (1.f + copysignf(fmaf(-p * t, e, 1.0f), z));
-    return fmaf(z * 0.3989422804014327f, e, cdf);
+// bf16 storage: Phi(z) - 0.5 and z phi(z) are both odd, so gelu'(z) = 0.5 + t Q(t^2) with t = clamp(z, -4, 4) and Q of degree 8
+// (weighted least squares towards minimax on [0, 4]; |error| <= 1e-4 on a function of range [-0.13, 1.13], 5.6e-4 in the
+// clamped tails), 11 full-rate VALU slots per element that hipcc packs two by two -- the exp + rcp form (one shared exponential
+// between the Abramowitz-Stegun erf and the density) took ~25 slots plus two quarter-rate transcendentals and made the
+// backward of the depthwise + GELU pair VALU-bound.
+__device__ __forceinline__ float gelu_grad_poly(float z) {
+    const float t = __builtin_amdgcn_fmed3f(z, -4.0f, 4.0f);
+    const float u = t * t;
+    float p = fmaf(9.796147385e-10f, u, -8.218867416e-08f);
+    p = fmaf(p, u, 3.028366673e-06f);
+    p = fmaf(p, u, -6.495786215e-05f);
+    p = fmaf(p, u, 9.073290484e-04f);
+    p = fmaf(p, u, -8.716332020e-03f);
+    p = fmaf(p, u, 5.845612905e-02f);
+    p = fmaf(p, u, -2.648265643e-01f);
+    p = fmaf(p, u, 7.976095594e-01f);
+    return fmaf(t, p, 0.5f);
 }
+template <>
+__device__ __forceinline__ float gelu_grad_t<bf16_t>(float z) { return gelu_grad_poly(z); }
 
 // 4 consecutive elements as a vector (16 B for f32, 8 B for bf16)
 template <typename T>

@@ -959,6 +959,20 @@ def dwconv3x3_wgrad(x, dy, dw, db=None):
     return dw
 
 
+def dwconv3x3_bwd_fused(x, z, dy, wt, dw, db=None, gelu=True):
+    """depthwise 3x3 (+ GELU) backward in one pass (bf16): -> dx; dw f32 [C, 9] (the parameter's order) and db f32 [C] are
+    accumulated into.  x: the conv's input, z: its pre-activation output (gelu only), dy: gradient of the block's output"""
+    B, H, W, C = x.shape
+    assert x.dtype == torch.bfloat16 and dy.dtype == torch.bfloat16
+    _, _, ldx = rows(x)
+    _, _, lddy = rows(dy)
+    ldz = rows(z)[2] if gelu else 0
+    dx = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
+    _lib.call("emip_dwconv3x3_bwd_fused", _p(x), ldx, _p(z) if gelu else None, ldz, _p(dy), lddy, _p(dx), C, _p(wt), _p(dw),
+              _p(db), B, H, W, C, 1 if gelu else 0, _stream())
+    return dx
+
+
 def bn_train_bwd(x, dy, out, fsums, gamma, dgamma, dbeta, eps):
     M, C, ldx = rows(x)
     _, _, lddy = rows(dy)

@@ -479,6 +479,13 @@ int emip_gelu_bwd(const void* Z, long ldz, const void* DY, long lddy, void* DZ, 
 int emip_dwconv3x3_wgrad(const void* X, long ldx, const void* DY, long lddy, float* dW, float* db, int B, int H, int Wd,
                          int C, int dtype, void* stream);
 
+/* Backward of depthwise 3x3 (+ exact GELU when gelu != 0) in one pass, bf16 (lib/pvt_v2.py:45-54,316-327: DWConv + nn.GELU of
+ * the Mlp): dPre = DY * gelu'(Z) (Z = the forward's pre-activation; ignored without gelu), DX = input gradient,
+ * dW f32 [C][9] (the parameter's own [C][1][3][3] order) and db f32 [C] (may be NULL) are ACCUMULATED into; wt f32 [9][C] are
+ * the forward's taps.  Replaces emip_gelu_bwd + emip_dwconv3x3 on flipped taps + emip_dwconv3x3_wgrad. */
+int emip_dwconv3x3_bwd_fused(const void* X, long ldx, const void* Z, long ldz, const void* DY, long lddy, void* DX, long lddx,
+                             const float* wt, float* dW, float* db, int B, int H, int Wd, int C, int gelu, void* stream);
+
 /* Train-mode BatchNorm2d (+ReLU when OUT != NULL) backward (ConvBR, create_backbone.py:22-42; conv_corr, model.py:59-62).  X: pre-BN conv output, OUT: the forward output,
  * fsums: the forward's emip_chan_stats (groups = 1); dgamma/dbeta accumulated; ws: f32 [2*C]. */
 int emip_bn_train_bwd(const void* X, long ldx, const void* DY, long lddy, const void* OUT, long ldo, void* DX, long lddx,
