@@ -566,34 +566,53 @@ def dense_attention_bwd(q, k, v, do, L, scale, gq=None, gk=None, nwin=1, dscore=
     return dq, dK, dV
 
 
+WATTN_BWD_FUSED = True      # emip_window_attention (+ log-sum-exp) / emip_window_attention_bwd in the bf16 training step
+
+
 class WindowAttentionFn(Function):
-    """Swin split-window single-head attention (transformer.py:46-105): fused forward through the index tables;
-    backward gathers each window into a dense batch and runs the unfused formulation."""
+    """Swin split-window single-head attention (transformer.py:46-105).  k / v of frame b are those of frame (b + kv_rot) mod 2B
+    (cross attention between the frames of a pair: no swapped copies).  bf16 at 128 channels: the dedicated forward kernel,
+    which also leaves every query's log-sum-exp, and the three-launch fused backward (wattn_bwd.hip).  Otherwise: the generic
+    fused forward through the index tables; backward gathers each window into a dense batch and runs the unfused formulation."""
 
     @staticmethod
-    def forward(ctx, q, k, v, h, w, shift, splits):
+    def forward(ctx, q, k, v, h, w, shift, splits, kv_rot=0):
         from .model.EMIP_short.motion.gmflow.tables import window_tables
         B2, n, C = q.shape
         rows_t, gid = window_tables(h, w, splits, shift, q.device)
         L = (h // splits) * (w // splits)
         out = torch.empty((B2, n, C), dtype=q.dtype, device=q.device)
-        ops.attention(q, k, v, out, batch=B2, heads=1, nwin=splits * splits, Lq=L, Lk=L, D=C, DV=C, q_bs=n * C,
-                      k_bs=n * C, v_bs=n * C, o_bs=n * C, ldq=C, ldk=C, ldv=C, ldo=C, q_rows=rows_t, k_rows=rows_t,
-                      q_gid=gid if shift else None, k_gid=gid if shift else None, scale=C ** -0.5)
-        ctx.save_for_backward(q, k, v)
-        ctx.cfg = (h, w, shift, splits)
+        fused = WATTN_BWD_FUSED and q.dtype == torch.bfloat16 and C == 128 and 64 <= L <= 512
+        if fused:
+            lse = torch.empty((B2, n), dtype=torch.float32, device=q.device)
+            ops.window_attention(q, k, v, out, rows_t, gid if shift else None, n, C ** -0.5, kv_rot, lse=lse)
+            ctx.save_for_backward(q, k, v, out, lse)
+        else:
+            if kv_rot:
+                k, v = torch.roll(k, -kv_rot, 0), torch.roll(v, -kv_rot, 0)
+            ops.attention(q, k, v, out, batch=B2, heads=1, nwin=splits * splits, Lq=L, Lk=L, D=C, DV=C, q_bs=n * C,
+                          k_bs=n * C, v_bs=n * C, o_bs=n * C, ldq=C, ldk=C, ldv=C, ldo=C, q_rows=rows_t, k_rows=rows_t,
+                          q_gid=gid if shift else None, k_gid=gid if shift else None, scale=C ** -0.5)
+            ctx.save_for_backward(q, k, v)
+        ctx.cfg = (h, w, shift, splits, kv_rot, fused)
         return out
 
     @staticmethod
     def backward(ctx, do):
         from .model.EMIP_short.motion.gmflow.tables import window_tables
-        q, k, v = ctx.saved_tensors
-        h, w, shift, splits = ctx.cfg
-        B2, n, C = q.shape
+        h, w, shift, splits, kv_rot, fused = ctx.cfg
         nwin = splits * splits
+        rows_t, gid = window_tables(h, w, splits, shift, do.device)
+        if fused:
+            q, k, v, out, lse = ctx.saved_tensors
+            n, C = q.shape[1], q.shape[2]
+            dq, dk, dv = ops.window_attention_bwd(q, k, v, out, do.contiguous(), lse, rows_t, gid if shift else None, n,
+                                                  C ** -0.5, kv_rot)
+            return dq, dk, dv, None, None, None, None, None
+        q, k, v = ctx.saved_tensors
+        B2, n, C = q.shape
         L = n // nwin
         Lp = _round_up(L, 8)
-        rows_t, gid = window_tables(h, w, splits, shift, q.device)
         gq = None
         if shift:
             gq = torch.zeros((nwin, Lp), dtype=torch.int32, device=q.device)
@@ -601,7 +620,10 @@ class WindowAttentionFn(Function):
         g = lambda t: ops.window_rows(t.contiguous(), rows_t, B2, nwin, L, Lp, n, C)
         dq, dK, dV = dense_attention_bwd(g(q), g(k), g(v), g(do), L, C ** -0.5, gq, gid if shift else None, nwin)
         s = lambda t: ops.window_rows(t, rows_t, B2, nwin, L, Lp, n, C, scatter=True)
-        return s(dq), s(_to_act(dK, q.dtype)), s(_to_act(dV, q.dtype)), None, None, None, None
+        dk, dv = s(_to_act(dK, q.dtype)), s(_to_act(dV, q.dtype))
+        if kv_rot:
+            dk, dv = torch.roll(dk, kv_rot, 0), torch.roll(dv, kv_rot, 0)
+        return s(dq), dk, dv, None, None, None, None, None
 
 
 class GlobalMatchFn(Function):

@@ -43,10 +43,11 @@ struct WaArgs {
     const bf16_t* K;
     const bf16_t* V;
     bf16_t* O;
+    float* lse;            // [B][tokens] log2-sum-exp of the scaled, masked scores (training forward) or null
     const int* rows;       // [nwin][L] token of the frame for every window-local token
     const int* gid;        // [nwin][L] region ids (shifted windows) or null
     long ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs;
-    int B, nwin, L, rot, qblocks;
+    int B, nwin, L, rot, qblocks, tokens;
     float scale;
     unsigned k_bytes, v_bytes;
 #ifdef EMIP_TUNING
@@ -233,8 +234,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
     }
 
     // ---- normalise and store: registers 4 g .. 4 g + 3 of block d = channels 32 d + 8 g + 4 h + (0..3) of this lane's query
-    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32));
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
     if (q_ok) {
+        if (p.lse && h == 0) p.lse[b * p.tokens + qrow] = m_run + __log2f(l_tot);      // what emip_window_attention_bwd rebuilds P from
         bf16_t* Op = p.O + b * p.o_bs + (long)qrow * p.ldo;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
@@ -257,10 +260,11 @@ extern "C" int emip_debug_set_wa(int flags) { g_wa_skip = flags; return 0; }
 
 // Q, K, V, O: bf16 token matrices of B frames (batch strides q_bs ... o_bs, row strides ldq ... ldo, in elements; 128
 // channels at the pointer); rows: int [nwin][L] frame token of every window-local token, gid: int [nwin][L] region ids of the
-// shifted layout or NULL (no mask); keys / values of frame b are read from frame (b + kv_rot) mod B.  L <= 512.
+// shifted layout or NULL (no mask); keys / values of frame b are read from frame (b + kv_rot) mod B.  L <= 512.  lse: NULL or
+// f32 [B][tokens], receives log2(sum_k exp2(score_k log2 e)) of every query (the training forward; emip_window_attention_bwd).
 extern "C" int emip_window_attention(const void* Q, const void* K, const void* V, void* O, int B, int nwin, int L, long ldq,
                                      long ldk, long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs, const int* rows,
-                                     const int* gid, int tokens, int kv_rot, float scale, void* stream) {
+                                     const int* gid, int tokens, int kv_rot, float scale, float* lse, void* stream) {
     EMIP_REQUIRE(Q && K && V && O && rows && B > 0 && nwin > 0 && L >= WA_BK && L <= WA_LMAX && tokens >= L);
     EMIP_REQUIRE(B < 65536 && nwin < 65536 && kv_rot >= 0 && kv_rot < B);
     EMIP_REQUIRE(ldq >= 128 && ldk >= 128 && ldv >= 128 && ldo >= 128 && ((ldq | ldk | ldv) & 7) == 0 && (ldo & 3) == 0);
@@ -268,7 +272,7 @@ extern "C" int emip_window_attention(const void* Q, const void* K, const void* V
     EMIP_REQUIRE(aligned16(Q) && aligned16(K) && aligned16(V) && (reinterpret_cast<uintptr_t>(O) & 7u) == 0);
     EMIP_REQUIRE(((long)(tokens - 1) * ldk + 128) * 2 < 0x7FFF0000L && ((long)(tokens - 1) * ldv + 128) * 2 < 0x7FFF0000L);
     WaArgs a{};
-    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O; a.rows = rows; a.gid = gid;
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O; a.lse = lse; a.tokens = tokens; a.rows = rows; a.gid = gid;
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
     a.B = B; a.nwin = nwin; a.L = L; a.rot = kv_rot; a.scale = scale;
     a.qblocks = (L + 255) / 256;

@@ -123,16 +123,17 @@ class FeatureTransformer(EmipModule):
         """differentiable variant of run(): same op stream, out of place, every step a Function over HIP kernels"""
         B2, n, C = c0.shape
         B = B2 // 2
-        swap = lambda t: torch.cat((t[B:], t[:B]), 0)            # the other frame's tokens (data movement only)
         for blk in self.layers:
             sa, ca = blk.self_attn, blk.cross_attn_ffn
             shift = sa.with_shift
-            kx, vx = swap(ca.lin("k_proj", c0)), swap(ca.lin("v_proj", c0))
+            # keys / values of the cross attention: the OTHER frame's tokens as they are at block start, read in place from the
+            # other half of the batch (kv_rot = B), like the inference path
+            kx, vx = ca.lin("k_proj", c0), ca.lin("v_proj", c0)
             msg = WindowAttentionFn.apply(sa.lin("q_proj", c0), sa.lin("k_proj", c0), sa.lin("v_proj", c0), h, w, shift,
                                           attn_num_splits)
             msg = LayerNormFn.apply(sa.lin("merge", msg), sa.norm1.weight, sa.norm1.bias, sa.norm1.eps)
             c1 = AddFn.apply(c0, msg)
-            msg = WindowAttentionFn.apply(ca.lin("q_proj", c1), kx, vx, h, w, shift, attn_num_splits)
+            msg = WindowAttentionFn.apply(ca.lin("q_proj", c1), kx, vx, h, w, shift, attn_num_splits, B)
             msg = LayerNormFn.apply(ca.lin("merge", msg), ca.norm1.weight, ca.norm1.bias, ca.norm1.eps)
             hid = ActFn.apply(ca.lin("mlp0", ConcatFn.apply(None, c1, msg)), ops.ACT_GELU)
             msg = LayerNormFn.apply(ca.lin("mlp2", hid), ca.norm2.weight, ca.norm2.bias, ca.norm2.eps)

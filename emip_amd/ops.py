@@ -490,8 +490,9 @@ def attention(q, k, v, out, *, batch, heads, nwin, Lq, Lk, D, DV, q_bs, k_bs, v_
     return out
 
 
-def window_attention(q, k, v, out, rows, gid, tokens, scale, kv_rot=0):
-    """emip_window_attention: q / k / v / out [B, tokens, >=128] bf16 views (unit channel stride), rows / gid int32 [nwin, L]"""
+def window_attention(q, k, v, out, rows, gid, tokens, scale, kv_rot=0, lse=None):
+    """emip_window_attention: q / k / v / out [B, tokens, >=128] bf16 views (unit channel stride), rows / gid int32 [nwin, L];
+    lse: f32 [B, tokens] receives the log2-sum-exp of every query (what window_attention_bwd needs)"""
     _dev(q)
     B = q.shape[0]
     nwin, L = rows.shape
@@ -501,8 +502,25 @@ def window_attention(q, k, v, out, rows, gid, tokens, scale, kv_rot=0):
         assert t.dim() == 3 and t.shape[0] == B and t.shape[1] == tokens and t.stride(2) == 1
     _lib.call("emip_window_attention", _p(q), _p(k), _p(v), _p(out), B, nwin, L, q.stride(1), k.stride(1), v.stride(1),
               out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0), _p(rows), _p(gid), int(tokens), int(kv_rot),
-              float(scale), _stream())
+              float(scale), _p(lse), _stream())
     return out
+
+
+def window_attention_bwd(q, k, v, out, dout, lse, rows, gid, tokens, scale, kv_rot=0):
+    """emip_window_attention_bwd -> (dq, dk, dv) bf16 [B, tokens, 128]; out / dout contiguous, q / k / v may be column slices"""
+    _dev(q)
+    B = q.shape[0]
+    nwin, L = rows.shape
+    assert out.is_contiguous() and dout.is_contiguous() and out.shape == (B, tokens, 128) and dout.shape == out.shape
+    assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.numel() == B * tokens
+    for t in (q, k, v):
+        assert t.dtype == torch.bfloat16 and t.dim() == 3 and t.shape[0] == B and t.shape[1] == tokens and t.stride(2) == 1
+    g = torch.empty((3, B, tokens, 128), dtype=torch.bfloat16, device=q.device)
+    delta = torch.empty((B, tokens), dtype=torch.float32, device=q.device)
+    _lib.call("emip_window_attention_bwd", _p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(delta), _p(g[0]), _p(g[1]), _p(g[2]),
+              B, nwin, L, q.stride(1), k.stride(1), v.stride(1), q.stride(0), k.stride(0), v.stride(0), _p(rows), _p(gid),
+              int(tokens), int(kv_rot), float(scale), _stream())
+    return g[0], g[1], g[2]
 
 
 def match(q, k, W, scale, v=None, scores=None, kv_rot=0, sub_grid=True):

@@ -262,7 +262,17 @@ int emip_match(const void* Q, const void* K, const float* V, void* S, float* Out
  * frame (b + kv_rot) mod B (cross attention between the two frames of a pair). */
 int emip_window_attention(const void* Q, const void* K, const void* V, void* O, int B, int nwin, int L, long ldq, long ldk,
                           long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs, const int* rows, const int* gid,
-                          int tokens, int kv_rot, float scale, void* stream);
+                          int tokens, int kv_rot, float scale, float* lse, void* stream);
+
+/* Backward of emip_window_attention in three launches (train.py:52-58 through transformer.py:46-105; GMFlow is frozen,
+ * train.py:340-342, only the token gradients exist): delta = rowsum(dO o O); dQ with the queries stationary; dK, dV with the keys
+ * stationary; P is recomputed from lse (the forward's log2-sum-exp, f32 [B][tokens]).  O, dO and the three gradients are
+ * contiguous [B][tokens][128] bf16; Q, K, V may be column slices (ld*, *_bs in elements); delta: f32 [B][tokens] workspace.
+ * Gradients of the keys / values of frame (b + kv_rot) mod B are written to that frame's rows.  nwin * L == tokens. */
+int emip_window_attention_bwd(const void* Q, const void* K, const void* V, const void* O, const void* dO, const float* lse,
+                              float* delta, void* dQ, void* dK, void* dV, int B, int nwin, int L, long ldq, long ldk, long ldv,
+                              long q_bs, long k_bs, long v_bs, const int* rows, const int* gid, int tokens, int kv_rot,
+                              float scale, void* stream);
 
 /* MDTA channel attention matrix: L2-normalise q,k over pixels, 64x64 Gram per head, * temperature, softmax.
  * PromptInteract.py:423-428.  ws: f32 [B*heads*(4096+128)] scratch; attn out: T [B][heads][64][64]. */

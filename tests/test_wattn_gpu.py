@@ -45,3 +45,40 @@ def test_window_attention(B2, shift, rot):
     d_old = (out.float() - old.float()).abs().max().item()
     print(f"  B2={B2} shift={shift} rot={rot}: max |d| vs PyTorch {err:.4f}, vs the generic kernel {d_old:.4f} (values up to {ref.abs().max().item():.2f})")
     assert err < 2e-2 * max(1.0, ref.abs().max().item()) and d_old < 2e-2 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.parametrize("B2,shift,rot,hw", [(4, False, 0, 44), (4, True, 0, 44), (6, True, 3, 44), (2, True, 1, 24)])
+def test_window_attention_backward(B2, shift, rot, hw):
+    """emip_window_attention_bwd (three launches: delta, dQ with the queries stationary, dK / dV with the keys stationary; P from
+    the forward's log-sum-exp) against torch autograd through the f32 evaluation on the same bf16-rounded operands"""
+    from emip_amd import ops
+    from emip_amd.model.EMIP_short.motion.gmflow.tables import window_tables
+    h = w = hw
+    n, C = h * w, 128
+    g = torch.Generator().manual_seed(7 + B2 + rot)
+    big = (torch.randn(B2, n, 3 * C, generator=g) * 1.2).cuda().to(torch.bfloat16)
+    q, k, v = big[..., :C], big[..., C:2 * C], big[..., 2 * C:]
+    do = torch.randn(B2, n, C, generator=g).cuda().to(torch.bfloat16)
+    rows, gid = window_tables(h, w, 2, shift, big.device)
+    gm = gid if shift else None
+    out = torch.empty((B2, n, C), dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty((B2, n), dtype=torch.float32, device="cuda")
+    ops.window_attention(q, k, v, out, rows, gm, n, C ** -0.5, rot, lse=lse)
+    # log-sum-exp in log2 units against the f32 evaluation
+    qf, kf, vf = (t.float().clone().requires_grad_(True) for t in (q, k, v))
+    ref = _reference(qf, kf, vf, rows, gm, rot, C ** -0.5)
+    kk = torch.roll(k, -rot, 0) if rot else k
+    for wi in range(rows.shape[0]):
+        r = rows[wi].long()
+        s = torch.einsum("bqc,bkc->bqk", q[:, r].float(), kk[:, r].float()) * C ** -0.5
+        if gm is not None:
+            s = s + (gm[wi].view(-1, 1) != gm[wi].view(1, -1)).float() * -100.0
+        l2 = torch.logsumexp(s, -1) * 1.4426950408889634
+        assert (lse[:, r] - l2).abs().max().item() < 2e-2
+    ref.backward(do.float())
+    dq, dk, dv = ops.window_attention_bwd(q, k, v, out, do, lse, rows, gm, n, C ** -0.5, rot)
+    torch.cuda.synchronize()
+    for name, got, want in (("dq", dq, qf.grad), ("dk", dk, kf.grad), ("dv", dv, vf.grad)):
+        e = (got.float() - want).abs().max().item() / (want.abs().max().item() + 1e-9)
+        print(f"  B2={B2} shift={shift} rot={rot} hw={hw} {name}: rel {e:.4f}")
+        assert e < 2.5e-2, (name, e)
