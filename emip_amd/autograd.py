@@ -626,25 +626,48 @@ class WindowAttentionFn(Function):
         return s(dq), dk, dv, None, None, None, None, None
 
 
+MATCH_BWD_FUSED = True      # emip_match (+ log-sum-exp) / emip_match_bwd in the bf16 training step
+
+
+def _match_fused(t):
+    n, C = t.shape[1], t.shape[2]
+    return MATCH_BWD_FUSED and t.dtype == torch.bfloat16 and C == 128 and 128 <= n <= 2048 and n % 8 == 0 and t.stride(2) == 1
+
+
 class GlobalMatchFn(Function):
     """Global correlation softmax in both directions (matching.py:8-41).  tokens [2B, n, C] (frame 0 | frame 1) ->
-    (expected positions f32 [2B, n, 32] with (x, y) in columns 0..1, scaled correlation [B, n(src), n(tgt)])."""
+    (expected positions f32 with (x, y) in columns 0..1: [2B, n, 2] on the fused path, [2B, n, 32] otherwise; scaled correlation
+    [B, n(src), n(tgt)]).  bf16 at 128 channels: emip_match forward (one launch, leaves the log-sum-exp) and emip_match_bwd."""
 
     @staticmethod
-    def forward(ctx, c0, grid):
+    def forward(ctx, c0, grid, W):
         B2, n, C = c0.shape
         B = B2 // 2
         corr = torch.empty((B, n, n), dtype=c0.dtype, device=c0.device)
+        if _match_fused(c0):
+            lse = torch.empty((B2, n), dtype=torch.float32, device=c0.device)
+            o = ops.match(c0, c0, W, C ** -0.5, scores=corr, kv_rot=B, sub_grid=False, lse=lse)
+            ctx.save_for_backward(c0, o, lse)
+            ctx.cfg = (W, True)
+            return o, corr
         o = torch.empty((B2, n, 32), dtype=torch.float32, device=c0.device)
         common = dict(batch=B, heads=1, nwin=1, Lq=n, Lk=n, D=C, DV=32, q_bs=n * C, k_bs=n * C, v_bs=0, o_bs=n * 32,
                       ldq=C, ldk=C, ldv=32, ldo=32, scale=C ** -0.5)
         ops.attention(c0[:B], c0[B:], grid, o[:B], scores=corr, s_bs=n * n, lds=n, **common)
         ops.attention(c0[B:], c0[:B], grid, o[B:], **common)
         ctx.save_for_backward(c0, grid)
+        ctx.cfg = (W, False)
         return o, corr
 
     @staticmethod
     def backward(ctx, do, dcorr):
+        W, fused = ctx.cfg
+        if fused:
+            c0, o, lse = ctx.saved_tensors
+            B2, n, C = c0.shape
+            dtok, _ = ops.match_bwd(c0, c0, W, C ** -0.5, o, do.contiguous(), lse, dscores=dcorr.contiguous(), kv_rot=B2 // 2,
+                                    sub_grid=False, accum=True)
+            return dtok, None, None
         c0, grid = ctx.saved_tensors
         B2, n, C = c0.shape
         B = B2 // 2
@@ -659,26 +682,38 @@ class GlobalMatchFn(Function):
         dc0 = torch.empty_like(c0)
         ops.axpby(dq_f, _to_act(dk_b, dt), 1.0, 1.0, out=dc0[:B])
         ops.axpby(dq_b, _to_act(dk_f, dt), 1.0, 1.0, out=dc0[B:])
-        return dc0, None
+        return dc0, None, None
 
 
 class FlowPropFn(Function):
     """Flow propagation by feature self-similarity (transformer.py:485-533): softmax(q k^T / sqrt(C)) flow; the flow
-    operand is detached in the reference (gmflow.py:139)."""
+    operand is detached in the reference (gmflow.py:139).  Output f32 [N, n, 2] on the fused path, [N, n, 32] otherwise."""
 
     @staticmethod
     def forward(ctx, q, k, flow):
         N, n, C = q.shape
+        if _match_fused(q) and _match_fused(k):
+            v = flow.reshape(N, n, 2).contiguous()
+            lse = torch.empty((N, n), dtype=torch.float32, device=q.device)
+            o = ops.match(q, k, 1, C ** -0.5, v=v, sub_grid=False, lse=lse)
+            ctx.save_for_backward(q, k, v, o, lse)
+            ctx.fused = True
+            return o
         v = torch.empty((N, n, 32), dtype=q.dtype, device=q.device)
         ops.copy_cols(flow.view(N * n, 2), 0, 2, v.view(N * n, 32), 0, 32)
         o = torch.empty((N, n, 32), dtype=torch.float32, device=q.device)
         ops.attention(q, k, v, o, batch=N, heads=1, nwin=1, Lq=n, Lk=n, D=C, DV=32, q_bs=n * C, k_bs=n * C,
                       v_bs=n * 32, o_bs=n * 32, ldq=C, ldk=C, ldv=32, ldo=32, scale=C ** -0.5)
         ctx.save_for_backward(q, k, v)
+        ctx.fused = False
         return o
 
     @staticmethod
     def backward(ctx, do):
+        if ctx.fused:
+            q, k, v, o, lse = ctx.saved_tensors
+            dq, dk = ops.match_bwd(q, k, 1, q.shape[2] ** -0.5, o, do.contiguous(), lse, v=v, sub_grid=False)
+            return dq, dk, None
         q, k, v = ctx.saved_tensors
         N, n, C = q.shape
         dq, dk, _ = dense_attention_bwd(q, k, v, _to_act(do.contiguous(), q.dtype), n, C ** -0.5, need_dv=False)
@@ -690,11 +725,14 @@ class CorrespToFlowFn(Function):
 
     @staticmethod
     def forward(ctx, o, N, h, w, sub_grid):
+        ctx.cols = o.shape[-1]
         return ops.corresp_to_flow(o, N, h, w, sub_grid)
 
     @staticmethod
     def backward(ctx, dflow):
         N, h, w, _ = dflow.shape
+        if ctx.cols == 2:                                   # the fused matching path hands over [N, n, 2]: the gradient as it is
+            return dflow.contiguous().view(N, h * w, 2), None, None, None, None
         do = torch.empty((N, h * w, 32), dtype=torch.float32, device=dflow.device)
         ops.copy_cols(dflow.contiguous().view(-1, 2), 0, 2, do.view(-1, 32), 0, 32)
         return do, None, None, None, None

@@ -57,6 +57,7 @@ struct MatchArgs {
     const float* V;       // [Z][n][2] or null (= the pixel grid)
     bf16_t* S;            // [Zs][n][n] raw scores (scale * q.k) of batches z < Zs, or null
     float* Out;           // [Z][n][2]
+    float* lse;           // [Z][n] log2-sum-exp of the scaled scores (training forward) or null
     long ldq, ldk, q_bs, k_bs;
     int Z, Zs, n, W, rot, sub, xcd_map, qtiles;
     float scale;
@@ -265,7 +266,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void m
         const float4 o2 = part[qw * 32 + lq];
         const float m = fmaxf(m_run, o2.w);                // (o2.w = -inf with an all-zero partial when there was a single tile)
         const float fa = __builtin_amdgcn_exp2f(m_run - m), fb = __builtin_amdgcn_exp2f(o2.w - m);
-        const float inv = 1.0f / (oacc[2] * fa + o2.z * fb);
+        const float l_tot = oacc[2] * fa + o2.z * fb;
+        const float inv = 1.0f / l_tot;
+        if (p.lse) p.lse[(long)z * p.n + q] = m + __log2f(l_tot);
         float ox = (oacc[0] * fa + o2.x * fb) * inv, oy = (oacc[1] * fa + o2.y * fb) * inv;
         if (p.sub) {
             const int qy = q / p.W;
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void m
 // S: bf16 [Zs][n][n] receives scale * q.k for batches z < Zs (may be NULL with Zs = 0).  Out: f32 [Z][n][2] =
 // softmax-weighted mean of V, minus the query's own pixel when sub_grid.
 extern "C" int emip_match(const void* Q, const void* K, const float* V, void* S, float* Out, int Z, int Zs, int n, int W,
-                          long ldq, long ldk, long q_bs, long k_bs, int kv_rot, float scale, int sub_grid, void* stream) {
+                          long ldq, long ldk, long q_bs, long k_bs, int kv_rot, float scale, int sub_grid, float* lse, void* stream) {
     EMIP_REQUIRE(Q && K && Out && Z > 0 && Zs >= 0 && Zs <= Z && (Zs == 0 || S));
     EMIP_REQUIRE(n >= 2 * MT_BK && n <= MT_NPAD && (n & 7) == 0 && W > 0 && kv_rot >= 0 && kv_rot < Z);
     EMIP_REQUIRE(ldq >= 128 && ldk >= 128 && (ldq & 7) == 0 && (ldk & 7) == 0 && (q_bs & 7) == 0 && (k_bs & 7) == 0);
@@ -294,7 +297,7 @@ extern "C" int emip_match(const void* Q, const void* K, const float* V, void* S,
     MatchArgs a{};
     a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = V; a.S = (bf16_t*)S; a.Out = Out;
     a.ldq = ldq; a.ldk = ldk; a.q_bs = q_bs; a.k_bs = k_bs;
-    a.Z = Z; a.Zs = Zs; a.n = n; a.W = W; a.rot = kv_rot; a.sub = sub_grid; a.scale = scale;
+    a.lse = lse; a.Z = Z; a.Zs = Zs; a.n = n; a.W = W; a.rot = kv_rot; a.sub = sub_grid; a.scale = scale;
     a.qtiles = (n + 127) / 128;
     a.xcd_map = (Z % 8) == 0;
     a.k_bytes = (unsigned)(((long)(n - 1) * ldk + 128) * 2);

@@ -49,7 +49,7 @@ class GMFlow(EmipModule):
         pos = position_table(h, w, C, splits, dt, ab.device)
         c0 = BcastAddFn.apply(ab.view(B2, n, C), pos, n)
         c0 = self.transformer.run_train(c0, h, w, splits)
-        o, corr = GlobalMatchFn.apply(c0, grid_values(h, w, dt, ab.device))
+        o, corr = GlobalMatchFn.apply(c0, grid_values(h, w, dt, ab.device), w)
         flow = CorrespToFlowFn.apply(o, B2, h, w, True)
         preds = []
         if self.training:

@@ -523,7 +523,7 @@ def window_attention_bwd(q, k, v, out, dout, lse, rows, gid, tokens, scale, kv_r
     return g[0], g[1], g[2]
 
 
-def match(q, k, W, scale, v=None, scores=None, kv_rot=0, sub_grid=True):
+def match(q, k, W, scale, v=None, scores=None, kv_rot=0, sub_grid=True, lse=None):
     """emip_match: q, k bf16 [Z, n, 128] (unit channel stride), v f32 [Z, n, 2] or None (= the pixel grid of width W),
     scores bf16 [Zs, n, n] or None -> f32 [Z, n, 2]; keys / values of batch z come from batch (z + kv_rot) mod Z"""
     _dev(q)
@@ -538,8 +538,31 @@ def match(q, k, W, scale, v=None, scores=None, kv_rot=0, sub_grid=True):
     if v is not None:
         assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == Z * n * 2
     _lib.call("emip_match", _p(q), _p(k), _p(v), _p(scores), _p(out), Z, Zs, n, int(W), q.stride(1), k.stride(1), q.stride(0),
-              k.stride(0), int(kv_rot), float(scale), int(sub_grid), _stream())
+              k.stride(0), int(kv_rot), float(scale), int(sub_grid), _p(lse), _stream())
     return out
+
+
+def match_bwd(q, k, W, scale, out, dout, lse, v=None, dscores=None, kv_rot=0, sub_grid=True, accum=False):
+    """emip_match_bwd -> (dq, dk) bf16 [Z, n, 128]; accum: dk is added into dq's buffer (q and k are the same tokens) and the one
+    tensor is returned twice"""
+    _dev(q)
+    Z, n, C = q.shape
+    assert C == 128 and k.shape == q.shape and q.dtype == k.dtype == torch.bfloat16 and q.stride(2) == 1 and k.stride(2) == 1
+    assert out.dtype == dout.dtype == lse.dtype == torch.float32 and out.is_contiguous() and dout.is_contiguous()
+    assert out.numel() == Z * n * 2 and dout.numel() == Z * n * 2 and lse.numel() == Z * n
+    Zs = 0
+    if dscores is not None:
+        Zs = dscores.shape[0]
+        assert dscores.shape == (Zs, n, n) and dscores.dtype == torch.bfloat16 and dscores.is_contiguous()
+    if v is not None:
+        assert v.dtype == torch.float32 and v.is_contiguous() and v.numel() == Z * n * 2
+    dq = torch.empty((Z, n, 128), dtype=torch.bfloat16, device=q.device)
+    dk = dq if accum else torch.empty_like(dq)
+    stat = torch.empty((Z, n, 4), dtype=torch.float32, device=q.device)
+    _lib.call("emip_match_bwd", _p(q), _p(k), _p(v), _p(out), _p(dout), _p(lse), _p(dscores), _p(stat), _p(dq), _p(dk), Z, Zs, n,
+              int(W), q.stride(1), k.stride(1), q.stride(0), k.stride(0), int(kv_rot), float(scale), int(sub_grid), int(accum),
+              _stream())
+    return dq, dk
 
 
 def sra_attention(q, kv, out, batch, heads, Lq, Lk, scale):

@@ -253,7 +253,16 @@ int emip_attention_rot(const void* Q, const void* K, const void* V, void* O, voi
  * volume matching.py:18-20 returns (permuted) and model.py:96 hands to conv_corr; Out: f32 [Z][n][2].  Both matching
  * directions are ONE launch (Z = 2B, kv_rot = B, Zs = B).  128 <= n <= 2048, n % 8 == 0. */
 int emip_match(const void* Q, const void* K, const float* V, void* S, float* Out, int Z, int Zs, int n, int W, long ldq,
-               long ldk, long q_bs, long k_bs, int kv_rot, float scale, int sub_grid, void* stream);
+               long ldk, long q_bs, long k_bs, int kv_rot, float scale, int sub_grid, float* lse, void* stream);
+
+/* Backward of emip_match (train.py:52-58 through matching.py:8-41 / transformer.py:485-533; no parameters: token gradients
+ * only).  Out / dOut: f32 [Z][n][2] the forward's output and its gradient; lse: f32 [Z][n] the log2-sum-exp emip_match wrote;
+ * dS: bf16 [Zs][n][n] gradient w.r.t. the scaled scores S of batches z < Zs (the correlation volume conv_corr consumed) or NULL;
+ * stat: f32 [Z][n][4] workspace; dQ, dK: bf16 [Z][n][128]; the gradient of the keys batch z read is written to batch
+ * (z + kv_rot) mod Z; accum_dk != 0 ADDS it to those rows (dK == dQ when Q == K: the token gradient of matching.py:13-14). */
+int emip_match_bwd(const void* Q, const void* K, const float* V, const float* Out, const float* dOut, const float* lse,
+                   const void* dS, float* stat, void* dQ, void* dK, int Z, int Zs, int n, int W, long ldq, long ldk, long q_bs,
+                   long k_bs, int kv_rot, float scale, int sub_grid, int accum_dk, void* stream);
 
 /* GMFlow split-window attention (gmflow/transformer.py:46-105, masks :19-43) on a kernel built for the shape (bf16, one head,
  * D = DV = 128, windows of L <= 512 tokens): O[rows[win][q]] = softmax_k(scale <Q[rows[win][q]], K[rows[win][k]]> - 100

@@ -91,3 +91,51 @@ def test_against_the_generic_attention_path():
     flow_b = ops.corresp_to_flow(o, 2 * B, h, w, True)
     assert torch.equal(corr_a, corr_b)
     assert (flow_a - flow_b).abs().max().item() < 0.2
+
+
+@pytest.mark.parametrize("Z,n,W,rot,same,use_v,up", [(4, 1936, 44, 2, True, False, True), (2, 136, 34, 1, True, False, True),
+                                                     (4, 1936, 44, 0, False, True, False), (3, 256, 16, 1, False, False, False),
+                                                     (2, 2048, 64, 1, True, False, True)])
+def test_matching_backward(Z, n, W, rot, same, use_v, up):
+    """emip_match_bwd (statistics, dQ with the queries stationary, dK with the keys stationary; P from the forward's log-sum-exp;
+    the upstream gradient of the returned score volume added to d score) against torch autograd through the f32 evaluation"""
+    from emip_amd import ops
+    scale = 128 ** -0.5
+    q = _feat(Z, n, 11, 0.9)
+    k = q if same else _feat(Z, n, 12, 0.9)
+    g = torch.Generator().manual_seed(5)
+    v = (torch.randn(Z, n, 2, generator=g) * 10).cuda() if use_v else None
+    do = torch.randn(Z, n, 2, generator=g).cuda()
+    Zs = max(1, Z // 2) if up else 0
+    ds = (torch.randn(Zs, n, n, generator=g) * 0.05).cuda().to(torch.bfloat16) if up else None
+    lse = torch.empty((Z, n), dtype=torch.float32, device="cuda")
+    scores = torch.empty((Zs, n, n), dtype=torch.bfloat16, device="cuda") if up else None
+    out = ops.match(q, k, W, scale, v=v, scores=scores, kv_rot=rot, sub_grid=not use_v, lse=lse)
+    qf = q.float().clone().requires_grad_(True)
+    kf = qf if same else k.float().clone().requires_grad_(True)
+    kk = torch.roll(kf, -rot, 0) if rot else kf
+    s = torch.einsum("zqc,zkc->zqk", qf, kk) * scale
+    l2 = torch.logsumexp(s, -1) * 1.4426950408889634
+    assert (lse - l2).abs().max().item() < 2e-2
+    p = torch.softmax(s, -1)
+    if use_v:
+        vv = torch.roll(v, -rot, 0) if rot else v
+        o = torch.einsum("zqk,zkc->zqc", p, vv)
+    else:
+        idx = torch.arange(n, device=q.device)
+        o = p @ torch.stack((idx % W, idx // W), -1).float()
+    loss = (o * do).sum()
+    if up:
+        loss = loss + (s[:Zs] * ds.float()).sum()
+    loss.backward()
+    dq, dk = ops.match_bwd(q, k, W, scale, out, do, lse, v=v, dscores=ds, kv_rot=rot, sub_grid=not use_v, accum=same)
+    torch.cuda.synchronize()
+    if same:
+        e = (dq.float() - qf.grad).abs().max().item() / qf.grad.abs().max().item()
+        print(f"  Z={Z} n={n} rot={rot} token gradient: rel {e:.4f}")
+        assert e < 2.5e-2, e
+    else:
+        eq = (dq.float() - qf.grad).abs().max().item() / qf.grad.abs().max().item()
+        ek = (dk.float() - kf.grad).abs().max().item() / kf.grad.abs().max().item()
+        print(f"  Z={Z} n={n} rot={rot}: dq rel {eq:.4f}, dk rel {ek:.4f}")
+        assert eq < 2.5e-2 and ek < 2.5e-2, (eq, ek)
