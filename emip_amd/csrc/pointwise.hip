@@ -1312,6 +1312,7 @@ extern "C" int emip_rows_finalize(const float* A, long lda, void* Y, long ldy, f
 }
 
 static int g_lnb_wide = 1, g_lnb_rows = 1;
+static long g_lnb_blocks = 256;
 #ifdef EMIP_TUNING
 extern "C" int emip_debug_set_lnb(int wide) {          // 0: the 4-channel form, 1: two 8-channel vectors per lane, 2 (default): + rows
     g_lnb_wide = wide != 0;
@@ -1457,11 +1458,12 @@ extern "C" int emip_layernorm_bwd_res(const void* X, long ldx, const void* DY, l
         aligned16(DX) && (!DR || ((lddr & 7) == 0 && aligned16(DR)))) {
         const int nv8 = C >> 3;
         if (dtype == EMIP_BF16 && g_lnb_rows && nv8 <= 64) {
-            // eight lanes per row: 256-thread workgroups of 32 rows per sweep, two sweeps per workgroup up to 512 workgroups
-            // (every workgroup ends in one global atomic per channel and statistic: ~25 ns each on the same address)
+            // eight lanes per row: 256-thread workgroups of 32 rows per sweep, at most 256 workgroups = one per CU (the kernel
+            // holds ~350 registers at C = 320: one wave per SIMD, so 512 workgroups were two rounds anyway).  Every workgroup
+            // ends in one global atomic per channel and statistic, ~25 ns each on the same address: 6.4 us instead of 12.8
             const int vpl = (nv8 + 7) / 8;
             long blocks = (M + 63) / 64;
-            if (blocks > 512) blocks = 512;
+            if (blocks > g_lnb_blocks) blocks = g_lnb_blocks;
             if (blocks < 1) blocks = 1;
 #define EMIP_LNB_ROWS(V)                                                                                                       \
     hipLaunchKernelGGL((layernorm_bwd_rows_kernel<V>), dim3((unsigned)blocks), dim3(256), 2 * C * sizeof(float),               \
