@@ -445,7 +445,7 @@ def main_train(args):
         dist.destroy_process_group()
 
 
-def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=False, streams=2):
+def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=False, streams=2, inflight=4):
     """BASELINE.json configs[3]: EMIP-long historical-prompt inference, S independent video streams per GPU, steady state
     (5-frame memory window full, memory fed back from the previous step), bf16."""
     from emip_amd import _lib, dist as edist, nn_base
@@ -474,8 +474,12 @@ def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=Fal
     if no_graph:
         step = eager_step
     else:
-        from emip_amd.graph import GraphedLong
-        runner = GraphedLong(net, S, device=dev, splits=min(streams, 2))    # 8 streams: 2 graphs x 4 measured best
+        from emip_amd.graph import GraphedLong, PipelinedLong
+        if inflight > 1:
+            # consecutive TIME STEPS in flight: the memory-independent part of a step runs ahead of the memory reads
+            runner = PipelinedLong(net, S, inflight=inflight, device=dev)
+        else:
+            runner = GraphedLong(net, S, device=dev, splits=min(streams, 2))    # round 2: 2 graphs x 4 streams
         nsplit = runner.splits
         runner.seed_memory(state["k"], state["v"])
         runner.load(f0, f1)
@@ -498,7 +502,11 @@ def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=Fal
         "config": {"workload": "EMIP-long inference step (short-term forward + LTM memorize/segment over a 5-frame "
                                "window + long decoder), %d video streams per GPU, bf16" % S,
                    "streams_per_gpu": S, "memory_frames": int(state["k"].shape[3]), "hipgraph": not no_graph,
-                   "concurrent_streams": nsplit,
+                   "concurrent_streams": nsplit if (no_graph or inflight <= 1) else inflight,
+                   "steps_in_flight": 1 if (no_graph or inflight <= 1) else inflight,
+                   "note": "steps in flight: every step is one graph pair over all streams; the part of a step that does not read "
+                           "the memory (short-term encoders, LTM.memorize) runs ahead, the memory read + long decoder of step t "
+                           "waits for the key / value pairs of frames t-4 .. t",
                    "parallelism": "dp%d (independent replicas, no collective)" % world},
         "achieved_TFLOPs_per_gpu": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3, 1),
         "frac_of_bf16_mfma_peak": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
@@ -515,7 +523,7 @@ def main_long(args):
     """--workload long: reported beside, never instead of, the inference headline."""
     world, rank, dev, dist, red_dev = _dist_setup()
     rec = measure_long(args.pairs or 8, args.steps, args.warmup, world, rank, dev, dist, red_dev, args.no_graph,
-                       args.streams)
+                       args.streams, args.inflight)
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if dist is not None:
@@ -599,7 +607,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--streams", type=int, default=2, help="--inflight 1: sub-batches of the step replayed concurrently on separate HIP streams")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=4,
                     help="consecutive 16-pair steps in flight, each ONE whole-batch graph on its own stream (1 = one step at "
                          "a time, its batch split into --streams sub-batch graphs)")
     ap.add_argument("--no-sub", action="store_true", help="skip the train / long / f32 sub-records of the default run")

@@ -215,3 +215,116 @@ class GraphedLong:
         self.load(frames0, frames1)
         self.replay()
         return self.masks()
+
+
+class _LongSlot:
+    """one in-flight step of PipelinedLong: graph A (memory-independent part) and graph B (memory read + long decoder) over
+    static buffers; `keys` / `values` are B's window, gathered from the ring right before B is replayed"""
+
+    def __init__(self, net, streams, size, device, warmup):
+        T, n, C = net.WINDOW, (size // 8) ** 2, 128
+        self.f0 = torch.zeros(streams, 3, size, size, device=device)
+        self.f1 = torch.zeros(streams, 3, size, size, device=device)
+        self.keys = torch.zeros(streams, T, n, C, dtype=net.cdtype, device=device)
+        self.values = torch.zeros(streams, T, n, C, dtype=net.cdtype, device=device)
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(warmup):
+                a = net.step_a(self.f0, self.f1)
+                net.step_b(a[0], a[1], a[2], self.keys, self.values)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph_a):
+            self.f0s, self.f2_2, self.f2_3, self.pk, self.pv = net.step_a(self.f0, self.f1)
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
+            self.mask = net.step_b(self.f0s, self.f2_2, self.f2_3, self.keys, self.values)
+
+
+class PipelinedLong:
+    """EMIP-long at steady state with consecutive TIME STEPS in flight.  The memory of model_long.py:97-107 is a sliding window
+    of the (key, value) pairs the last five frames contributed, and a frame's pair depends only on that frame's short-term
+    features -- nothing the memory read produces is fed back.  So a step splits into A (short-term encoders, side reductions,
+    LTM.memorize: ~90 % of the work, independent of every other step) and B (LTM.segment over the window + long decoder), and the
+    A parts of successive steps overlap like the independent requests of PipelinedShort; B(t) waits for A(t-4) ... A(t).
+    Every step is ONE graph pair over all `streams` video streams (kernels at the full batch shapes), `inflight` of them on as
+    many HIP streams; the pairs live in a ring of inflight + 5 entries, B's window is gathered from it (2 launches), the entry
+    of step t is written behind A(t) (2 launches)."""
+
+    def __init__(self, net, streams, inflight=3, size=352, device="cuda:0", warmup=2):
+        self.net, self.nstreams, self.inflight = net, streams, inflight
+        self.T = net.WINDOW
+        self.R = inflight + self.T
+        n, C = (size // 8) ** 2, 128
+        self.ring_k = torch.zeros(streams, self.R, n, C, dtype=net.cdtype, device=device)
+        self.ring_v = torch.zeros_like(self.ring_k)
+        self.slots = [_LongSlot(net, streams, size, device, warmup) for _ in range(inflight)]
+        self.streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]
+        self.splits = 1
+        # window of step t = ring entries (t - 4 .. t) mod R, one index vector per residue of t
+        self.idx = [torch.tensor([(r - self.T + 1 + j) % self.R for j in range(self.T)], device=device) for r in range(self.R)]
+        self.t = 0
+        self.ev_a = {}                 # step -> event "ring entry of the step is written"
+        self.ev_b = {}                 # step -> event "B of the step has read its window"
+        self.last = None
+
+    def seed_memory(self, memory_k, memory_v):
+        """memory_k / memory_v: [S,1,128,5,44,44] (the reference layout): the pairs of steps -5 .. -1"""
+        mk, mv = self.net._mem_from_ref(memory_k), self.net._mem_from_ref(memory_v)
+        torch.cuda.synchronize()
+        self.t, self.ev_a, self.ev_b = 0, {}, {}
+        for j in range(self.T):
+            e = (j - self.T) % self.R
+            self.ring_k[:, e].copy_(mk[:, j])
+            self.ring_v[:, e].copy_(mv[:, j])
+        torch.cuda.synchronize()
+
+    def load(self, frames0, frames1, slot=None):
+        for p in (self.slots if slot is None else [self.slots[slot]]):
+            p.f0.copy_(frames0)
+            p.f1.copy_(frames1)
+
+    def replay_free(self):
+        """enqueue step t on stream t mod inflight; returns the slot whose `mask` will hold its result"""
+        t = self.t
+        i = t % self.inflight
+        p, s = self.slots[i], self.streams[i]
+        e = t % self.R
+        with torch.cuda.stream(s):
+            old = self.ev_b.pop(t - self.R + self.T - 1, None)         # last reader of the ring entry about to be overwritten
+            if old is not None:
+                s.wait_event(old)
+            p.graph_a.replay()
+            self.ring_k[:, e].copy_(p.pk[:, 0])
+            self.ring_v[:, e].copy_(p.pv[:, 0])
+            ea = torch.cuda.Event()
+            ea.record(s)
+            self.ev_a[t] = ea
+            for u in range(t - self.T + 1, t):
+                if u in self.ev_a:
+                    s.wait_event(self.ev_a[u])
+            torch.index_select(self.ring_k, 1, self.idx[e], out=p.keys)
+            torch.index_select(self.ring_v, 1, self.idx[e], out=p.values)
+            p.graph_b.replay()
+            eb = torch.cuda.Event()
+            eb.record(s)
+            self.ev_b[t] = eb
+        self.ev_a.pop(t - self.T, None)
+        self.t = t + 1
+        self.last = i
+        return i
+
+    def masks(self, slot=None):
+        return self.slots[self.last if slot is None else slot].mask
+
+    def memory(self):
+        """the window after the last enqueued step, reference layout [S,1,128,5,44,44] (f32), oldest frame first"""
+        torch.cuda.synchronize()
+        e = (self.t - 1) % self.R
+        k = torch.index_select(self.ring_k, 1, self.idx[e])
+        v = torch.index_select(self.ring_v, 1, self.idx[e])
+        h = w = int(round(k.shape[2] ** 0.5))
+        return self.net._mem_to_ref(k, h, w), self.net._mem_to_ref(v, h, w)
+

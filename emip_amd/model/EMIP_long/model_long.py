@@ -78,10 +78,10 @@ class Model_long(EmipModule):
                                                 values.detach()))
         return mask_long, ref_k, ref_v
 
-    def step_cl(self, frames0, frames1, mem_k, mem_v):
-        """One step on channels-last memory (no layout conversion, no host logic beyond shapes): frames [S,3,H,W],
-        mem_k / mem_v [S,T,h*w,128] or None -> (mask [S,1,H,W], keys, values [S,min(T+1,5),h*w,128]).
-        With a full window the shapes are static, which is what emip_amd.graph.GraphedLong captures."""
+    def step_a(self, frames0, frames1):
+        """The part of a step that does not see the memory: short-term encoders (model_long.py:70-79), the two side reductions and
+        the key / value pair this frame contributes to the memory (LTM.memorize, :97-103).  Returns
+        (f0 features of the second frame [S,h,w,128], f2_2, f2_3, pk, pv [S,1,h*w,128])."""
         st = self.short_term
         S = frames0.shape[0]
         with torch.no_grad():                  # model_long.py:70: the short-term part never carries gradient
@@ -92,17 +92,28 @@ class Model_long(EmipModule):
             f2_2 = st.dr2.run(fea[1][S:])
             f2_3 = st.dr3.run(fea[2][S:])
         pk, pv = self.LTM.memorize_cl(fea[0][:S], cc)                  # [S,h,w,128] each
-        pk, pv = pk.view(S, 1, h * w, -1), pv.view(S, 1, h * w, -1)
+        return fea[0][S:], f2_2, f2_3, pk.view(S, 1, h * w, -1), pv.view(S, 1, h * w, -1)
+
+    def step_b(self, f0s, f2_2, f2_3, keys, values):
+        """The part that reads the memory window (model_long.py:105-117): LTM.segment over the window's keys / values (their order
+        does not matter: one softmax over all of them), long_dr, injector1, dr1, decoder -> mask [S,1,H,W]"""
+        mem = self.LTM.segment_cl(f0s, keys, values)                    # [S,h,w,256]
+        mem = self.long_dr.run(mem)
+        fl = self.injector1.run(f0s, mem)
+        fl = self.dr1.run(fl)
+        return self.decoder.run(f2_3, f2_2, fl)
+
+    def step_cl(self, frames0, frames1, mem_k, mem_v):
+        """One step on channels-last memory (no layout conversion, no host logic beyond shapes): frames [S,3,H,W],
+        mem_k / mem_v [S,T,h*w,128] or None -> (mask [S,1,H,W], keys, values [S,min(T+1,5),h*w,128]).
+        With a full window the shapes are static, which is what emip_amd.graph.GraphedLong captures."""
+        f0s, f2_2, f2_3, pk, pv = self.step_a(frames0, frames1)
         if mem_k is None:
             keys, values = pk, pv
         else:
             keys = torch.cat([mem_k, pk], 1)[:, -self.WINDOW:].contiguous()
             values = torch.cat([mem_v, pv], 1)[:, -self.WINDOW:].contiguous()
-        mem = self.LTM.segment_cl(fea[0][S:], keys, values)             # [S,h,w,256]
-        mem = self.long_dr.run(mem)
-        fl = self.injector1.run(fea[0][S:], mem)
-        fl = self.dr1.run(fl)
-        return self.decoder.run(f2_3, f2_2, fl), keys, values
+        return self.step_b(f0s, f2_2, f2_3, keys, values), keys, values
 
     def forward(self, frame0, frame1, index, memory_k, memory_v):
         return self.forward_streams(frame0.unsqueeze(0), frame1.unsqueeze(0), index, memory_k, memory_v)
