@@ -11,11 +11,11 @@
 // Here, as in wattn_bwd.hip, P is recomputed from the forward's log-sum-exp and stays in registers; two kernels, each with its
 // side stationary on the lanes:
 //   match_bwd_dq_kernel  8 waves x 32 queries, K streams (row-read image for S^T = K Q^T, transposed-read image for
-//                        dQ^T += K^T dS^T); V of the key batch sits in LDS (16 KB); the upstream gradient of 4 consecutive keys
-//                        is one 8-byte load per lane (a query's 64-key segment is one 128-byte line over the tile);
+//                        dQ^T += K^T dS^T); V of the key batch sits in LDS (16 KB); the upstream gradient's [256 queries][64 keys]
+//                        tile rides the ring too (8-byte loads per lane from the volume ran the kernel 2.8x slower);
 //   match_bwd_dk_kernel  4 waves x 32 keys, Q streams (row-read + transposed-read images) with one 1-KB piece of per-query
 //                        statistics (lse, delta, dO) per tile; the upstream gradient is read key-contiguous.
-//   match_stat_kernel    packs (lse, delta, dO_x, dO_y) per query.
+//   match_stat_kernel    packs (lse - log2 scale, delta, dO_x, dO_y) per query.
 #include "common.h"
 
 namespace {
@@ -41,7 +41,7 @@ struct MbArgs {
     const bf16_t* Q;      // [Z][n][ldq]
     const bf16_t* K;      // [Z][n][ldk]
     const float* V;       // [Z][n][2] (indexed like the keys) or null (= the pixel grid)
-    const float4* stat;   // [Z][n] (lse, delta, dO_x, dO_y)
+    const float4* stat;   // [Z][n] (lse - log2 scale, delta, dO_x, dO_y)
     const bf16_t* dS;     // [Zs][n][n] upstream gradient w.r.t. the scaled scores of batches z < Zs, or null
     bf16_t* dQ;           // [Z][n][128]
     bf16_t* dK;           // [Z][n][128]; rows of batch (z + rot) mod Z; may be dQ's buffer with accum = 1
@@ -53,7 +53,11 @@ struct MbArgs {
 
 constexpr unsigned MB_OOB = 0x80000000u;
 constexpr int MB_BK = 64, MB_IMG = MB_BK * 256, MB_NPAD = 2048;
-constexpr int MQ_NST = 3, MQ_STAGE = 2 * MB_IMG, MQ_RING = MQ_NST * MQ_STAGE, MQ_LDS = MQ_RING + MB_NPAD * 8;      // 114 688 B
+// dq kernel: 3 ring slots of (K rows | K transposed-read); with an upstream gradient 2 slots of (K rows | K transposed-read | the
+// [256 queries][64 keys] tile of the upstream gradient) -- plus V of every key
+constexpr int MQ_IMGS = 2 * MB_IMG, MQ_UPT = 256 * 128;
+constexpr int MQ_LDS_PLAIN = 3 * MQ_IMGS + MB_NPAD * 8;                 // 114 688 B
+constexpr int MQ_LDS_UP = 2 * (MQ_IMGS + MQ_UPT) + MB_NPAD * 8;         // 147 456 B
 constexpr int MK_NST = 3, MK_STAGE = 2 * MB_IMG + 1024, MK_RING = MK_NST * MK_STAGE, MK_LDS = MK_RING;              // 101 376 B
 
 __device__ __forceinline__ int mb_voff(int row, int c) { return row * 256 + ((c ^ ((row & 3) << 2)) * 16); }
@@ -85,9 +89,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void m
     const long z = blockIdx.y;
     long zk = z + p.rot;
     if (zk >= p.Z) zk -= p.Z;
+    constexpr int NST = UP ? 2 : 3, STAGE = UP ? MQ_IMGS + MQ_UPT : MQ_IMGS, RING = NST * STAGE;
     const i32x4 rsK = mb_rsrc(p.K + zk * p.k_bs, p.k_bytes);
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
-    float2* tv = reinterpret_cast<float2*>(smem + MQ_RING);                   // V of every key of batch zk
+    float2* tv = reinterpret_cast<float2*>(smem + RING);                   // V of every key of batch zk
     for (int i = tid; i < MB_NPAD; i += 512) {
         float2 v = make_float2(0.f, 0.f);
         if (i < p.n) {
@@ -107,11 +112,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void m
     for (int i = 0; i < 8; ++i) qf[i] = *reinterpret_cast<const uint4*>(p.Q + z * p.q_bs + (long)qc * p.ldq + (2 * i + h) * 8);
     const float4 st = p.stat[z * p.n + qc];                                   // (lse, delta, dO_x, dO_y)
     const bool up = UP && z < p.Zs;
-    const bf16_t* ups = UP ? p.dS + ((long)(up ? z : 0) * p.n + qc) * p.n : nullptr;
+    // upstream gradient d score[z][q][k]: the tile [this workgroup's 256 queries][64 keys] rides the ring as 32 1-KB pieces (8
+    // query rows of 128 B each), 4 per wave = the wave's own 32 queries; chunk ^ (row & 7) on the source side
+    const i32x4 rsU = mb_rsrc(UP ? p.dS + (long)(up ? z : 0) * p.n * p.n : nullptr, (unsigned)((long)p.n * p.n * 2));
     __syncthreads();
 
     auto issue = [&](int t) {
-        const unsigned base = lds0 + (t % MQ_NST) * MQ_STAGE;
+        const unsigned base = lds0 + (t % NST) * STAGE;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int r = 4 * (2 * wave + j) + (lane >> 4);
@@ -123,10 +130,20 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void m
             mb_dma16(base + (2 * wave + j) * 1024, kr, rsK);
             mb_dma16(base + MB_IMG + (2 * wave + j) * 1024, kt, rsK);
         }
+        if (UP) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int rl = 8 * j + (lane >> 3);                            // query row inside the wave's 32
+                const int qr = qb * 256 + wave * 32 + rl;
+                const int key = t * MB_BK + 8 * ((lane & 7) ^ (rl & 7));
+                const unsigned uo = (up && qr < p.n && key < p.n) ? (unsigned)(((long)qr * p.n + key) * 2) : MB_OOB;
+                mb_dma16(base + MQ_IMGS + wave * 4096 + j * 1024, uo, rsU);
+            }
+        }
     };
     const int ntile = (p.n + MB_BK - 1) / MB_BK;
     issue(0);
-    if (ntile > 1) issue(1);
+    if (!UP && ntile > 1) issue(1);
 
     f32x16 dq[4];
 #pragma unroll
@@ -137,31 +154,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void m
     const int i16 = lane & 15;
 
     for (int t = 0; t < ntile; ++t) {
-        // upstream gradient of this lane's query for the tile's keys: registers 4 g .. 4 g + 3 of block kt = 4 consecutive keys
-        uint2 ug[2][4];
-        if (UP) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    // unconditional (clamped) loads: the counted wait below relies on exactly 8 of them being in flight
-                    const int kb = min(t * MB_BK + 32 * kt + 8 * g + 4 * h, p.n - 4);
-                    ug[kt][g] = *reinterpret_cast<const uint2*>(ups + kb);
-                }
-        }
-        if (UP) {
-            // the 8 loads above are younger than tile t's DMA pieces and older than nothing: count them in
-            if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (UP) {                                            // 2 slots: tile t is the only one in flight
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             if (t + 1 < ntile) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if (t + 2 < ntile) issue(t + 2);
+        if (UP) {
+            if (t + 1 < ntile) issue(t + 1);
+        } else if (t + 2 < ntile) {
+            issue(t + 2);
+        }
 
-        const char* kr_ = smem + (t % MQ_NST) * MQ_STAGE;
+        const char* kr_ = smem + (t % NST) * STAGE;
+        const char* up_ = kr_ + MQ_IMGS + wave * 4096 + lq * 128 + h * 8;
         const char* kt_ = kr_ + MB_IMG;
         f32x16 s[2];
 #pragma unroll
@@ -184,16 +192,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void m
                 const float4 va = *reinterpret_cast<const float4*>(tv + kb), vb = *reinterpret_cast<const float4*>(tv + kb + 2);
                 const float vx[4] = {va.x, va.z, vb.x, vb.z}, vy[4] = {va.y, va.w, vb.y, vb.w};
                 float u[4] = {0.f, 0.f, 0.f, 0.f};
-                if (UP && up) {
-                    u[0] = __uint_as_float(ug[kt][g].x << 16); u[1] = __uint_as_float(ug[kt][g].x & 0xffff0000u);
-                    u[2] = __uint_as_float(ug[kt][g].y << 16); u[3] = __uint_as_float(ug[kt][g].y & 0xffff0000u);
+                if (UP) {                                    // zeros where there is no upstream gradient (out-of-range DMA)
+                    const uint2 ug = *reinterpret_cast<const uint2*>(up_ + (((4 * kt + g) ^ (lq & 7)) * 16));
+                    u[0] = __uint_as_float(ug.x << 16); u[1] = __uint_as_float(ug.x & 0xffff0000u);
+                    u[2] = __uint_as_float(ug.y << 16); u[3] = __uint_as_float(ug.y & 0xffff0000u);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][4 * g + j], sc2, -st.x));
-                    if (kb + j >= p.n) pr = 0.f;
-                    const float dpv = fmaf(st.z, vx[j], st.w * vy[j]);
-                    s[kt][4 * g + j] = (fmaf(pr, dpv - st.y, u[j])) * p.scale;
+                    // st.x carries -log2(scale): pr = scale P.  Keys beyond n: their K rows read as zeros, so whatever d score
+                    // comes out for them adds nothing to dQ
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[kt][4 * g + j], sc2, -st.x));
+                    const float w = fmaf(st.z, vx[j], fmaf(st.w, vy[j], -st.y));
+                    s[kt][4 * g + j] = UP ? fmaf(u[j], p.scale, pr * w) : pr * w;
                 }
             }
 #pragma unroll
@@ -341,12 +351,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     const int ql = 32 * qt + 8 * g + 4 * h + j;              // query inside the tile
                     const float4 st = stq[ql];
                     const int qi = t * MB_BK + ql;
-                    float pr = __builtin_amdgcn_exp2f(fmaf(s[qt][4 * g + j], sc2, -st.x));
-                    if (qi >= p.n) pr = 0.f;
+                    // pr = scale P (st.x carries -log2(scale)); queries beyond n: zero statistics, so w = 0
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(s[qt][4 * g + j], sc2, -st.x));
                     float u = 0.f;
                     if (UP && up && qi < p.n) u = __uint_as_float((unsigned)ur[qt][4 * g + j] << 16);
-                    const float dpv = fmaf(st.z, vx, st.w * vy);
-                    s[qt][4 * g + j] = fmaf(pr, dpv - st.y, u) * p.scale;
+                    const float w = fmaf(st.z, vx, fmaf(st.w, vy, -st.y));
+                    s[qt][4 * g + j] = UP ? fmaf(u, p.scale, pr * w) : pr * w;
                 }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -385,7 +395,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // stat[z][q] = (lse, <dO, O>, dO_x, dO_y); O = Out (+ the query's own pixel when the forward subtracted it)
 __global__ __launch_bounds__(256) void match_stat_kernel(const float* __restrict__ lse, const float* __restrict__ Out,
                                                          const float* __restrict__ dOut, float4* __restrict__ stat, long total,
-                                                         int n, int W, int sub) {
+                                                         int n, int W, int sub, float lscale) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const float2 o = *reinterpret_cast<const float2*>(Out + 2 * i), d = *reinterpret_cast<const float2*>(dOut + 2 * i);
         float ox = o.x, oy = o.y;
@@ -394,7 +404,7 @@ __global__ __launch_bounds__(256) void match_stat_kernel(const float* __restrict
             ox += (float)(q - qy * W);
             oy += (float)qy;
         }
-        stat[i] = make_float4(lse[i], d.x * ox + d.y * oy, d.x, d.y);
+        stat[i] = make_float4(lse[i] - lscale, d.x * ox + d.y * oy, d.x, d.y);      // exp2(s - stat.x) = scale P
     }
 }
 
@@ -424,8 +434,8 @@ extern "C" int emip_match_bwd(const void* Q, const void* K, const float* V, cons
     static bool attr = false;
     if (!attr) {
         attr = true;
-        if (hipFuncSetAttribute((const void*)match_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_LDS) != hipSuccess ||
-            hipFuncSetAttribute((const void*)match_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_LDS) != hipSuccess ||
+        if (hipFuncSetAttribute((const void*)match_bwd_dq_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_LDS_UP) != hipSuccess ||
+            hipFuncSetAttribute((const void*)match_bwd_dq_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MQ_LDS_PLAIN) != hipSuccess ||
             hipFuncSetAttribute((const void*)match_bwd_dk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MK_LDS) != hipSuccess ||
             hipFuncSetAttribute((const void*)match_bwd_dk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MK_LDS) != hipSuccess)
             return EMIP_E_LAUNCH;
@@ -435,13 +445,13 @@ extern "C" int emip_match_bwd(const void* Q, const void* K, const float* V, cons
     long nb = (total + 255) / 256;
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(match_stat_kernel, dim3((unsigned)nb), dim3(256), 0, st, lse, Out, dOut, (float4*)stat, total, n, W,
-                       sub_grid ? 1 : 0);
+                       sub_grid ? 1 : 0, log2f(scale));
     const dim3 gq((unsigned)((n + 255) / 256), (unsigned)Z), gk((unsigned)((n + 127) / 128), (unsigned)Z);
     if (a.Zs > 0) {
-        hipLaunchKernelGGL(match_bwd_dq_kernel<true>, gq, dim3(512), MQ_LDS, st, a);
+        hipLaunchKernelGGL(match_bwd_dq_kernel<true>, gq, dim3(512), MQ_LDS_UP, st, a);
         hipLaunchKernelGGL(match_bwd_dk_kernel<true>, gk, dim3(256), MK_LDS, st, a);
     } else {
-        hipLaunchKernelGGL(match_bwd_dq_kernel<false>, gq, dim3(512), MQ_LDS, st, a);
+        hipLaunchKernelGGL(match_bwd_dq_kernel<false>, gq, dim3(512), MQ_LDS_PLAIN, st, a);
         hipLaunchKernelGGL(match_bwd_dk_kernel<false>, gk, dim3(256), MK_LDS, st, a);
     }
     return emip_launch_status();

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
         qf[i] = *reinterpret_cast<const uint4*>(p.Q + b * p.q_bs + (long)qrow * p.ldq + (2 * i + h) * 8);
         dof[i] = *reinterpret_cast<const uint4*>(p.dO + b * p.do_bs + (long)qrow * p.lddo + (2 * i + h) * 8);
     }
-    const float lse = p.lse[b * p.tokens + qrow];
+    const float lse = p.lse[b * p.tokens + qrow] - __log2f(p.scale);          // exp2(s - lse) = scale P
     const float del = p.delta[b * p.tokens + qrow];
     __syncthreads();                                        // the tables are in LDS
 
@@ -198,8 +198,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
                     float x = fmaf(s[kt][4 * g + j], sc2, -lse);
                     if (MASK) x += (kgv[j] != q_g) ? mask2 : 0.f;
                     float pr = __builtin_amdgcn_exp2f(x);
-                    if (kb + j >= p.L) pr = 0.f;
-                    s[kt][4 * g + j] = pr * (dp[kt][4 * g + j] - del) * p.scale;
+                    s[kt][4 * g + j] = pr * (dp[kt][4 * g + j] - del);      // pr = scale P; keys beyond L: zero K rows, no effect
                 }
             }
         // ---- dQ^T += K^T dS^T
@@ -256,7 +255,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         trow[i] = r;
         tgid[i] = (MASK && ok) ? p.gid[(long)win * p.L + i] : 0;
         tlse[i] = ok ? p.lse[b * p.tokens + r] : 1e30f;      // P of a padding query = exp2(-1e30) = 0
-        tdel[i] = ok ? p.delta[b * p.tokens + r] : 0.f;
+        tdel[i] = ok ? p.delta[b * p.tokens + r] * p.scale : 0.f;
     }
 
     // ---- this lane's key: fragments of its K and V rows
@@ -358,7 +357,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                     if (MASK) x += (gv[j] != k_g) ? mask2 : 0.f;
                     const float pr = __builtin_amdgcn_exp2f(x);
                     s[qt][4 * g + j] = pr;
-                    dp[qt][4 * g + j] = pr * (dp[qt][4 * g + j] - dl[j]) * p.scale;
+                    dp[qt][4 * g + j] = pr * fmaf(dp[qt][4 * g + j], p.scale, -dl[j]);      // the table holds scale delta
                 }
             }
         // ---- dV^T += dO^T P, dK^T += Q^T dS
