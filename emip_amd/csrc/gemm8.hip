@@ -592,6 +592,10 @@ int pick_cfg(int M, int N, long K) {
     if ((double)K * N >= 4.0e6 && M >= 8192) return 7;
     const long tiles3 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (tiles3 < 192) return N <= 64 ? 8 : 9;   // round 2c: was 384 (8-pair sub-batches: the 242-tile GEMMs prefer 128 x 128)
+    // the training step's 64-image shapes (tools/gemm8_train_sweep.py; the inference shapes end at M = 15 488 for N = 320):
+    // 30 976 x 320 x 1280 (fc2 forward, fc1 input gradient): N = 320 in one 128 x 320 tile 36.5 us, 256 x 64 42.0;
+    // 30 976 x 320 x 320 (q / proj forward and input gradient): 128 x 128 16.3 us, 256 x 64 17.6
+    if (N == 320 && M >= 24576) return K >= 1024 ? 4 : 3;
     if (N % 128 == 64 || N <= 64) return 6;
     return 3;
 }
