@@ -596,6 +596,7 @@ int pick_cfg(int M, int N, long K) {
     // 30 976 x 320 x 1280 (fc2 forward, fc1 input gradient): N = 320 in one 128 x 320 tile 36.5 us, 256 x 64 42.0;
     // 30 976 x 320 x 320 (q / proj forward and input gradient): 128 x 128 16.3 us, 256 x 64 17.6
     if (N == 320 && M >= 24576) return K >= 1024 ? 4 : 3;
+    if (N == 320 && K >= 1024) return 3;      // 15 488 x 320 x 1280 (fc2 at 32 images): 128 x 128 27.1 us, 256 x 64 30.6
     if (N % 128 == 64 || N <= 64) return 6;
     return 3;
 }
