@@ -590,7 +590,7 @@ def sra_attention_bwd(q, kv, out, dout, L, batch, heads, Lq, Lk, scale):
     C = heads * 64
     assert q.is_contiguous() and kv.is_contiguous() and out.is_contiguous() and dout.is_contiguous()
     dq = torch.empty_like(q)
-    dkv = torch.zeros((batch, Lk, 2 * C), dtype=torch.float32, device=q.device)
+    dkv = grad_zeros((batch, Lk, 2 * C), q.device)          # arena slice inside a training step: no fill launch of its own
     _lib.call("emip_sra_attention_bwd", _p(q), _p(kv), _p(out), _p(dout), _p(L), _p(dq), _p(dkv), batch, heads, Lq, Lk, C,
               float(scale), _stream())
     return dq, dkv

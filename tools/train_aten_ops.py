@@ -47,6 +47,7 @@ im1, im2, gt = im1.cuda(), im2.cuda(), gt.cuda()
 for _ in range(2):
     train_step(net, opt, None, im1, im2, gt)
 torch.cuda.synchronize()
+torch.autograd.set_multithreading_enabled(False)      # backward on this thread: a dispatch mode is thread-local
 m = Count()
 with m:
     train_step(net, opt, None, im1, im2, gt)
