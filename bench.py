@@ -338,15 +338,52 @@ def parity_figures(net_bf16, margs, sd, ref_mask, dev):
         try:
             net32 = CoUpdater(margs)
             net32.load_state_dict(sd)
-            m32 = net32.to(dev).eval()(im1, im2)[0].cpu()
+            o32 = net32.to(dev).eval()(im1, im2)
+            m32, fl32 = o32[0].cpu(), o32[2][-1]              # flow_bw: the last (full-resolution) prediction
         finally:
             nn_base.set_default_dtype(torch.bfloat16)
 
     iou = _iou
-    return {"mask_iou_bf16_vs_cpu_ref": round(iou(m16, ref_mask), 5), "mask_iou_f32_vs_cpu_ref": round(iou(m32, ref_mask), 5),
+    # warp-corner indices (loss/warp_utils.py:26-70) of the f32 mode's backward flow at 352 x 352: device kernel against the CPU
+    # oracle on the SAME flow tensor, index for index
+    from emip_amd import ops
+    from oracle import emip_oracle as O
+    flow = fl32.float().contiguous()
+    idx_dev, _ = ops.occ_corners(flow)
+    idx_ref, _ = O.corresponding_indices(O.mesh_grid(flow.shape[0], flow.shape[2], flow.shape[3]).type_as(flow.cpu()) + flow.cpu())
+    bad = int((idx_dev.cpu() != idx_ref).sum().item())
+    warp = {"indices": int(idx_ref.numel()), "mismatches": bad, "status": "bit-exact" if bad == 0 else "MISMATCH"}
+    return {"warp_indices": warp,
+            "mask_iou_bf16_vs_cpu_ref": round(iou(m16, ref_mask), 5), "mask_iou_f32_vs_cpu_ref": round(iou(m32, ref_mask), 5),
             "mask_logit_max_abs_err_f32_vs_cpu_ref": float("%.3g" % (m32 - ref_mask).abs().max().item()),
             "mask_logit_max_abs_err_bf16_vs_cpu_ref": float("%.3g" % (m16 - ref_mask).abs().max().item()),
             "pair": "synthetic seed 1234, batch 1"}
+
+
+def report_rows(out, world):
+    """one row per configuration this run measured, from the figures of the same JSON line"""
+    par = out.get("parity", {})
+    rows = [{"config": "short inference B=16 bf16 (configs[1])", "gpus": world,
+             "rate_median": out.get("per_step", {}).get("pairs_per_s_median"), "rate": out.get("value"), "unit": "pairs/s",
+             "achieved_TFLOPs": out.get("end_to_end", {}).get("achieved_TFLOPs"),
+             "frac_of_bf16_mfma_peak": out.get("end_to_end", {}).get("frac_of_bf16_mfma_peak"),
+             "mask_max_abs_err_f32_mode": par.get("mask_logit_max_abs_err_f32_vs_cpu_ref"),
+             "mask_iou_vs_ref": par.get("mask_iou_bf16_vs_cpu_ref"), "warp_indices": None}]
+    t = out.get("train")
+    if isinstance(t, dict) and "value" in t:
+        rows.append({"config": "short train step B=32 bf16 (configs[2]%s)" % (" / DP configs[4]" if world > 1 else ""),
+                     "gpus": world, "rate": t["value"], "unit": "pairs/s", "ms_per_step": t["ms_per_step"],
+                     "achieved_TFLOPs": t.get("achieved_TFLOPs_per_gpu"), "frac_of_bf16_mfma_peak": t.get("frac_of_bf16_mfma_peak"),
+                     "mask_max_abs_err_f32_mode": None, "mask_iou_vs_ref": None,
+                     "warp_indices": (par.get("warp_indices") or {}).get("status")})
+    lg = out.get("long")
+    if isinstance(lg, dict) and "value" in lg:
+        rows.append({"config": "long inference 8 streams, T=5 (configs[3])", "gpus": world, "rate": lg["value"],
+                     "unit": "stream-frames/s", "achieved_TFLOPs": lg.get("achieved_TFLOPs_per_gpu"),
+                     "frac_of_bf16_mfma_peak": lg.get("frac_of_bf16_mfma_peak"),
+                     "mask_max_abs_err_f32_mode": "tests/test_long_gpu.py (<= 1e-3 against the reference's 7-step golden)",
+                     "mask_iou_vs_ref": None, "warp_indices": None})
+    return rows
 
 
 def _dist_setup():
@@ -834,6 +871,7 @@ def main():
                 sub["f32_parity_mode"] = {"error": repr(e)[:300]}
     if rank == 0:
         out.update(sub)
+        out["report"] = report_rows(out, world)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
