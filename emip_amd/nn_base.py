@@ -10,6 +10,8 @@ emip_amd.ops on channels-last activations.  This file provides
     parameters' version counters (optimizer steps and load_state_dict bump them),
   * packing helpers (conv weights to [Cout][KH][KW][Cin], BatchNorm folding, ...).
 """
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -38,7 +40,8 @@ def get_default_dtype():
 # norms, permuted channel orders, other optimizers) keeps the rebuild-on-version-change path.
 
 _REC = None            # list while a builder runs under packed(): (src, dst, dims4, strides4, base, valid3)
-_REFRESHABLE = []      # (cache dict, key, _Entry)
+_REFRESHABLE = {}      # (id(module), cache key) -> weakref(module): the packs die with their module (a strong reference
+                       # here kept every discarded model's bf16 / f32 packs in GPU memory for the life of the process)
 _TABLE = {}            # device -> (key, recs tensor, blockmap tensor, nblocks)
 
 
@@ -82,10 +85,15 @@ def refresh_packs():
     import struct
 
     from . import _lib
-    global _REFRESHABLE
-    live = [(c, k, e) for (c, k, e) in _REFRESHABLE if c.get(k) is e]
-    _REFRESHABLE = live
-    todo = [e for (_, _, e) in live if any(t.requires_grad for t in e.tensors)]
+    live = []
+    for rk, ref in list(_REFRESHABLE.items()):
+        m = ref()
+        e = m._pack_cache.get(rk[1]) if m is not None else None
+        if e is None or e.recs is None:
+            del _REFRESHABLE[rk]                  # module gone, cache cleared (.to()), or the entry was rebuilt as not refreshable
+        else:
+            live.append(e)
+    todo = [e for e in live if any(t.requires_grad for t in e.tensors)]
     by_dev = {}
     for e in todo:
         by_dev.setdefault(e.tensors[0].device, []).append(e)
@@ -153,7 +161,7 @@ class EmipModule(nn.Module):
         ent = _Entry(sig, val, recs if ok else None, tuple(tensors), mode)
         self._pack_cache[key] = ent
         if ok:
-            _REFRESHABLE.append((self._pack_cache, key, ent))
+            _REFRESHABLE[(id(self), key)] = weakref.ref(self)
         return val
 
     def _apply(self, fn, *a, **k):  # .to()/.cuda(): drop packed copies living on the old device

@@ -36,7 +36,12 @@ def test_refreshed_packs_equal_the_permuted_masters_after_optimizer_steps(model_
         for _ in range(2):
             train_step(net, opt, None, im1, im2, gt)
         torch.cuda.synchronize()
-        live = [e for (c, k, e) in nn_base._REFRESHABLE if c.get(k) is e and any(t.requires_grad for t in e.tensors)]
+        live = []
+        for (_, k), ref in nn_base._REFRESHABLE.items():
+            m = ref()
+            e = m._pack_cache.get(k) if m is not None else None
+            if e is not None and e.recs is not None and any(t.requires_grad for t in e.tensors):
+                live.append(e)
         nrec = sum(len(e.recs) for e in live)
         assert len(live) > 150 and nrec > 700, (len(live), nrec)      # PVT blocks, patch embeds, decoder, injectors
         bad = 0
@@ -225,3 +230,35 @@ def test_deferred_result_of_a_weight_used_twice_is_fixed_up():
     assert ((w.grad - ref_w).abs().max() / ref_w.abs().max()).item() < 1e-2
     assert ((b.grad - 3.0 * 4096).abs().max() / (3.0 * 4096)).item() < 1e-2
     del wf
+
+
+def test_packs_die_with_their_module(model_args, short_sd):
+    """the registry of refreshable packs holds modules weakly: a discarded model's packed weights leave GPU memory"""
+    import gc
+    from emip_amd import nn_base
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    try:
+        nn_base.set_default_dtype(torch.bfloat16)
+        nn_base.refresh_packs()
+        gc.collect(); torch.cuda.empty_cache()
+        base_entries, base_mem = len(nn_base._REFRESHABLE), torch.cuda.memory_allocated()
+        net = CoUpdater(model_args)
+        net.load_state_dict(short_sd)
+        net = net.to("cuda:0").train()
+        for p in net.parameters():
+            p.requires_grad_(True)
+        im1, im2 = synthetic_pair(1, seed=3)
+        with torch.enable_grad():
+            net(im1.cuda(), im2.cuda())
+        torch.cuda.synchronize()
+        assert len(nn_base._REFRESHABLE) > base_entries + 100
+        held = torch.cuda.memory_allocated()
+        del net
+        gc.collect()
+        nn_base.refresh_packs()                    # prunes the dead entries
+        gc.collect(); torch.cuda.empty_cache()
+        assert len(nn_base._REFRESHABLE) == base_entries
+        assert torch.cuda.memory_allocated() < base_mem + 0.1 * (held - base_mem), (base_mem, held, torch.cuda.memory_allocated())
+    finally:
+        nn_base.set_default_dtype(torch.float32)
+
