@@ -277,6 +277,8 @@ class SraAttentionFn(Function):
             B, N, C = q.shape
             Lk = kv.shape[1]
             dq, dkv32 = ops.sra_attention_bwd(q, kv, out, do.contiguous(), L, B, heads, N, Lk, scale)
+            if dkv32.dtype == q.dtype:
+                return dq, dkv32, None, None
             dkv = torch.empty((B, Lk, 2 * C), dtype=q.dtype, device=q.device)
             ops.copy_cols(dkv32.view(B * Lk, 2 * C), 0, 2 * C, dkv.view(B * Lk, 2 * C), 0)
             return dq, dkv, None, None

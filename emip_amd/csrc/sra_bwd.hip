@@ -26,6 +26,7 @@ struct SraBwdArgs {
     const float* L;      // [B, heads, Lq]  log2-sum-exp of the scaled scores
     bf16_t* dQ;          // [B, Lq, C]
     float* dKV;          // [B, Lk, 2C]  accumulated into
+    bf16_t* dKVb;        // or: [B, Lk, 2C] bf16, STORED (one workgroup per (image, head): splits == 1)
     int Lq, Lk, C, heads, splits;
     float scale;
 };
@@ -259,6 +260,21 @@ __global__ __launch_bounds__(256) void sra_bwd_kernel(const SraBwdArgs p) {
     }
 
     // ---- dK_w, dV_w: lane = head channel 32 dt + lq, register = key 32 w + 8 (r >> 2) + 4 h + (r & 3) ----------------------
+    if (p.dKVb) {                                            // this workgroup saw every query of its (image, head): final values
+        bf16_t* __restrict__ dkb = p.dKVb + batch * p.Lk * 2 * p.C + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * wave + 8 * (r >> 2) + 4 * h + (r & 3);
+                if (key < p.Lk) {
+                    bf16_t* row = dkb + (long)key * 2 * p.C + 32 * dt + lq;
+                    row[0] = (bf16_t)dk[dt][r];
+                    row[p.C] = (bf16_t)dv[dt][r];
+                }
+            }
+        return;
+    }
     float* __restrict__ dkp = p.dKV + batch * p.Lk * 2 * p.C + head * 64;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
@@ -275,19 +291,36 @@ __global__ __launch_bounds__(256) void sra_bwd_kernel(const SraBwdArgs p) {
 
 }  // namespace
 
+static int sra_bwd_launch(const void* Q, const void* KV, const void* O, const void* dO, const float* L, void* dQ, float* dKV,
+                          void* dKVb, int batch, int heads, int Lq, int Lk, int C, float scale, void* stream);
+
 extern "C" int emip_sra_attention_bwd(const void* Q, const void* KV, const void* O, const void* dO, const float* L, void* dQ,
                                       float* dKV, int batch, int heads, int Lq, int Lk, int C, float scale, void* stream) {
-    EMIP_REQUIRE(Q && KV && O && dO && L && dQ && dKV && batch > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lk <= 128 && C == heads * 64);
+    EMIP_REQUIRE(dKV);
+    return sra_bwd_launch(Q, KV, O, dO, L, dQ, dKV, nullptr, batch, heads, Lq, Lk, C, scale, stream);
+}
+
+// the same with dK | dV STORED as bf16 [B, Lk, 2C] (no pre-cleared f32 accumulator, no conversion pass): one workgroup per
+// (image, head) walks all queries -- the form for batch * heads >= 256 (the 22 x 22 and 11 x 11 stages at batch 32)
+extern "C" int emip_sra_attention_bwd_bf16(const void* Q, const void* KV, const void* O, const void* dO, const float* L, void* dQ,
+                                           void* dKV, int batch, int heads, int Lq, int Lk, int C, float scale, void* stream) {
+    EMIP_REQUIRE(dKV && aligned16(dKV));
+    return sra_bwd_launch(Q, KV, O, dO, L, dQ, nullptr, dKV, batch, heads, Lq, Lk, C, scale, stream);
+}
+
+static int sra_bwd_launch(const void* Q, const void* KV, const void* O, const void* dO, const float* L, void* dQ, float* dKV,
+                          void* dKVb, int batch, int heads, int Lq, int Lk, int C, float scale, void* stream) {
+    EMIP_REQUIRE(Q && KV && O && dO && L && dQ && batch > 0 && heads > 0 && Lq > 0 && Lk > 0 && Lk <= 128 && C == heads * 64);
     EMIP_REQUIRE(batch < 65536 && heads < 65536 && aligned16(Q) && aligned16(KV) && aligned16(O) && aligned16(dO) && aligned16(dQ));
     SraBwdArgs a{};
     a.Q = (const bf16_t*)Q; a.KV = (const bf16_t*)KV; a.O = (const bf16_t*)O; a.dO = (const bf16_t*)dO; a.L = L;
-    a.dQ = (bf16_t*)dQ; a.dKV = dKV; a.Lq = Lq; a.Lk = Lk; a.C = C; a.heads = heads; a.scale = scale;
+    a.dQ = (bf16_t*)dQ; a.dKV = dKV; a.dKVb = (bf16_t*)dKVb; a.Lq = Lq; a.Lk = Lk; a.C = C; a.heads = heads; a.scale = scale;
     // two workgroups per CU (72 KB each); the query blocks of an (image, head) pair are split when there are fewer pairs than
     // that, but every workgroup keeps >= 8 blocks: its prologue (K, V, K^T into registers) and its 64 KB of atomics are fixed
     const int nblk = (Lq + 31) / 32, pairs = batch * heads;
     int splits = (512 + pairs - 1) / pairs;
     if (splits > nblk / 8) splits = nblk / 8;
-    if (splits < 1) splits = 1;
+    if (splits < 1 || dKVb) splits = 1;
     a.splits = splits;
     static bool attr = false;
     if (!attr) {

@@ -586,10 +586,15 @@ def sra_attention_lse(q, kv, out, batch, heads, Lq, Lk, scale):
 
 
 def sra_attention_bwd(q, kv, out, dout, L, batch, heads, Lq, Lk, scale):
-    """-> (dq bf16 [B,Lq,C], dkv f32 [B,Lk,2C]: dK at columns 64 h, dV at C + 64 h)"""
+    """-> (dq bf16 [B,Lq,C], dkv [B,Lk,2C]: dK at columns 64 h, dV at C + 64 h; bf16 when batch * heads >= 256, else f32)"""
     C = heads * 64
     assert q.is_contiguous() and kv.is_contiguous() and out.is_contiguous() and dout.is_contiguous()
     dq = torch.empty_like(q)
+    if batch * heads >= 256:          # one workgroup per (image, head) fills the chip: final bf16 values, stored
+        dkv = torch.empty((batch, Lk, 2 * C), dtype=torch.bfloat16, device=q.device)
+        _lib.call("emip_sra_attention_bwd_bf16", _p(q), _p(kv), _p(out), _p(dout), _p(L), _p(dq), _p(dkv), batch, heads, Lq, Lk,
+                  C, float(scale), _stream())
+        return dq, dkv
     dkv = grad_zeros((batch, Lk, 2 * C), q.device)          # arena slice inside a training step: no fill launch of its own
     _lib.call("emip_sra_attention_bwd", _p(q), _p(kv), _p(out), _p(dout), _p(L), _p(dq), _p(dkv), batch, heads, Lq, Lk, C,
               float(scale), _stream())

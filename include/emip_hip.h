@@ -126,6 +126,9 @@ int emip_sra_attention_lse(const void* Q, const void* KV, void* O, float* L, int
  * per block), which materialised the [B, heads, Lq, 128] score matrices four times. */
 int emip_sra_attention_bwd(const void* Q, const void* KV, const void* O, const void* dO, const float* L, void* dQ, float* dKV,
                            int batch, int heads, int Lq, int Lk, int C, float scale, void* stream);
+/* The same with dK | dV stored as bf16 [B][Lk][2C] (nothing pre-cleared, no conversion): one workgroup per (image, head). */
+int emip_sra_attention_bwd_bf16(const void* Q, const void* KV, const void* O, const void* dO, const float* L, void* dQ, void* dKV,
+                           int batch, int heads, int Lq, int Lk, int C, float scale, void* stream);
 
 /* The attention half of a PVTv2 block in one launch (bf16 inference; lib/pvt_v2.py:95-127 Attention.forward with sr_ratio > 1
  * and the residual add of Block.forward, :165-168):  Out = X + proj(softmax((LN(X) Wq^T) k^T scale) v).

@@ -51,7 +51,8 @@ def test_sra_writes_nothing_beyond_its_rows():
     assert (buf[B * N * C:] == 9.0).all()
 
 
-@pytest.mark.parametrize("B,heads,Lq,Lk", [(3, 5, 484, 121), (2, 1, 7744, 121), (4, 2, 1936, 121), (2, 8, 121, 121), (2, 2, 300, 77)])
+@pytest.mark.parametrize("B,heads,Lq,Lk", [(3, 5, 484, 121), (2, 1, 7744, 121), (4, 2, 1936, 121), (2, 8, 121, 121), (2, 2, 300, 77),
+                                           (52, 5, 484, 121), (32, 8, 121, 121)])
 def test_sra_attention_backward_fused(B, heads, Lq, Lk):
     """emip_sra_attention_lse + emip_sra_attention_bwd (one launch each) against torch autograd on the rounded operands:
     the forward's output and log-sum-exp, dQ, dK, dV.  Shapes: the four PVT stages (stage 1 splits its 242 query blocks over
@@ -81,3 +82,5 @@ def test_sra_attention_backward_fused(B, heads, Lq, Lk):
     dv = dkv[:, :Lk, C:].reshape(B, Lk, heads, 64).permute(0, 2, 1, 3)
     assert rel(dk, kf.grad) < 2e-2 and rel(dv, vf.grad) < 2e-2
     assert dkv.shape == (B, Lk, 2 * C)
+    # batch * heads >= 256: one workgroup per (image, head) stores final bf16 values (emip_sra_attention_bwd_bf16)
+    assert dkv.dtype == (torch.bfloat16 if B * heads >= 256 else torch.float32)
