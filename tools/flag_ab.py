@@ -23,7 +23,7 @@ im1, im2 = im1.cuda(), im2.cuda()
 runners = []
 for v in vals:
     setattr(mod, attr, v)
-    r = PipelinedShort(net, 16, inflight=3); r.load(im1, im2)
+    r = PipelinedShort(net, 16, inflight=int(os.environ.get("INFLIGHT", "4"))); r.load(im1, im2)
     runners.append(r)
 torch.cuda.synchronize()
 
