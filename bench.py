@@ -821,9 +821,11 @@ def main():
                          "traffic_bytes_per_step": step_traffic,
                          "compulsory_bytes_per_step": int(COMPULSORY_STEP_BYTES),
                          "traffic_over_compulsory": (round(step_traffic / COMPULSORY_STEP_BYTES, 1) if step_traffic else None),
-                         "note": "launch durations are per kernel in ISOLATION on the sub-batch shapes the graphs "
-                                 "replay; in the timed region %d such streams overlap (sum of isolated kernel time "
-                                 "%.1f ms vs %.1f ms wall per step)" % (nsplit, total_ms, dt / args.steps * 1e3),
+                         "note": "launch durations are per kernel in ISOLATION on the shapes the graphs replay; in the "
+                                 "timed region %d %s overlap (sum of isolated kernel time %.1f ms vs %.1f ms wall per step)" % (
+                                     args.inflight if pipelined else nsplit,
+                                     "whole-batch steps in flight" if pipelined else "sub-batch streams", total_ms,
+                                     dt / args.steps * 1e3),
                          "same_kernel_unsplit_batch_TFLOPs": (round(whole[1] / (whole[0] * 1e-3) / 1e12, 2)
                                                               if whole else None)})
         out["roofline_named"] = {
