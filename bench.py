@@ -482,7 +482,7 @@ def main_train(args):
         dist.destroy_process_group()
 
 
-def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=False, streams=2, inflight=4):
+def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=False, streams=2, inflight=4, group=2):
     """BASELINE.json configs[3]: EMIP-long historical-prompt inference, S independent video streams per GPU, steady state
     (5-frame memory window full, memory fed back from the previous step), bf16."""
     from emip_amd import _lib, dist as edist, nn_base
@@ -514,7 +514,7 @@ def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=Fal
         from emip_amd.graph import GraphedLong, PipelinedLong
         if inflight > 1:
             # consecutive TIME STEPS in flight: the memory-independent part of a step runs ahead of the memory reads
-            runner = PipelinedLong(net, S, inflight=inflight, device=dev)
+            runner = PipelinedLong(net, S, inflight=inflight, device=dev, group=group)
         else:
             runner = GraphedLong(net, S, device=dev, splits=min(streams, 2))    # round 2: 2 graphs x 4 streams
         nsplit = runner.splits
@@ -541,9 +541,11 @@ def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=Fal
                    "streams_per_gpu": S, "memory_frames": int(state["k"].shape[3]), "hipgraph": not no_graph,
                    "concurrent_streams": nsplit if (no_graph or inflight <= 1) else inflight,
                    "steps_in_flight": 1 if (no_graph or inflight <= 1) else inflight,
-                   "note": "steps in flight: every step is one graph pair over all streams; the part of a step that does not read "
-                           "the memory (short-term encoders, LTM.memorize) runs ahead, the memory read + long decoder of step t "
-                           "waits for the key / value pairs of frames t-4 .. t",
+                   "time_steps_per_encoder_graph": 1 if (no_graph or inflight <= 1) else group,
+                   "note": "time steps in flight: the part of a step that does not read the memory (short-term encoders, "
+                           "LTM.memorize) runs ahead as ONE graph per group of consecutive time steps (a batch of group x streams "
+                           "pairs), several groups in flight; the memory read + long decoder of step t waits for the key / value "
+                           "pairs of frames t-4 .. t",
                    "parallelism": "dp%d (independent replicas, no collective)" % world},
         "achieved_TFLOPs_per_gpu": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3, 1),
         "frac_of_bf16_mfma_peak": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
@@ -560,7 +562,7 @@ def main_long(args):
     """--workload long: reported beside, never instead of, the inference headline."""
     world, rank, dev, dist, red_dev = _dist_setup()
     rec = measure_long(args.pairs or 8, args.steps, args.warmup, world, rank, dev, dist, red_dev, args.no_graph,
-                       args.streams, args.inflight)
+                       args.streams, args.inflight, args.long_group)
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if dist is not None:
@@ -647,6 +649,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=4,
                     help="consecutive 16-pair steps in flight, each ONE whole-batch graph on its own stream (1 = one step at "
                          "a time, its batch split into --streams sub-batch graphs)")
+    ap.add_argument("--long-group", type=int, default=2, help="EMIP-long: consecutive time steps per graph of the memory-independent part")
     ap.add_argument("--no-sub", action="store_true", help="skip the train / long / f32 sub-records of the default run")
     ap.add_argument("--dp-algo", choices=("allreduce", "direct"), default="allreduce",
                     help="train workload, N > 1: gradient exchange of emip_amd.dp.GradReducer")

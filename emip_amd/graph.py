@@ -218,29 +218,36 @@ class GraphedLong:
 
 
 class _LongSlot:
-    """one in-flight step of PipelinedLong: graph A (memory-independent part) and graph B (memory read + long decoder) over
-    static buffers; `keys` / `values` are B's window, gathered from the ring right before B is replayed"""
+    """one in-flight GROUP of `group` consecutive time steps of PipelinedLong: graph A (the memory-independent part of all of them
+    as one batch of group x streams pairs) and one graph B per time step (memory read + long decoder) over static buffers;
+    `keys[g]` / `values[g]` are B's window of step g, gathered from the ring right before that B is replayed"""
 
-    def __init__(self, net, streams, size, device, warmup):
+    def __init__(self, net, streams, size, device, warmup, group=1):
         T, n, C = net.WINDOW, (size // 8) ** 2, 128
-        self.f0 = torch.zeros(streams, 3, size, size, device=device)
-        self.f1 = torch.zeros(streams, 3, size, size, device=device)
-        self.keys = torch.zeros(streams, T, n, C, dtype=net.cdtype, device=device)
-        self.values = torch.zeros(streams, T, n, C, dtype=net.cdtype, device=device)
+        S, G = streams, group
+        self.f0 = torch.zeros(G * S, 3, size, size, device=device)
+        self.f1 = torch.zeros(G * S, 3, size, size, device=device)
+        self.keys = [torch.zeros(S, T, n, C, dtype=net.cdtype, device=device) for _ in range(G)]
+        self.values = [torch.zeros(S, T, n, C, dtype=net.cdtype, device=device) for _ in range(G)]
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():
             for _ in range(warmup):
                 a = net.step_a(self.f0, self.f1)
-                net.step_b(a[0], a[1], a[2], self.keys, self.values)
+                net.step_b(a[0][:S], a[1][:S], a[2][:S], self.keys[0], self.values[0])
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph_a = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph_a):
             self.f0s, self.f2_2, self.f2_3, self.pk, self.pv = net.step_a(self.f0, self.f1)
-        self.graph_b = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph_b, pool=self.graph_a.pool()):
-            self.mask = net.step_b(self.f0s, self.f2_2, self.f2_3, self.keys, self.values)
+        self.graph_b, self.mask = [], []
+        for g in range(G):
+            gb = torch.cuda.CUDAGraph()
+            sl = slice(g * S, (g + 1) * S)
+            with torch.no_grad(), torch.cuda.graph(gb, pool=self.graph_a.pool()):
+                m = net.step_b(self.f0s[sl], self.f2_2[sl], self.f2_3[sl], self.keys[g], self.values[g])
+            self.graph_b.append(gb)
+            self.mask.append(m)
 
 
 class PipelinedLong:
@@ -249,18 +256,18 @@ class PipelinedLong:
     features -- nothing the memory read produces is fed back.  So a step splits into A (short-term encoders, side reductions,
     LTM.memorize: ~90 % of the work, independent of every other step) and B (LTM.segment over the window + long decoder), and the
     A parts of successive steps overlap like the independent requests of PipelinedShort; B(t) waits for A(t-4) ... A(t).
-    Every step is ONE graph pair over all `streams` video streams (kernels at the full batch shapes), `inflight` of them on as
-    many HIP streams; the pairs live in a ring of inflight + 5 entries, B's window is gathered from it (2 launches), the entry
-    of step t is written behind A(t) (2 launches)."""
+    `group` consecutive time steps share ONE A graph (a batch of group x streams pairs: the kernels run at the shapes of the
+    EMIP-short benchmark), `inflight` groups are in flight on as many HIP streams; the pairs live in a ring of
+    inflight * group + 5 entries, B's window is gathered from it (2 launches), the entries of a group are written behind its A."""
 
-    def __init__(self, net, streams, inflight=3, size=352, device="cuda:0", warmup=2):
-        self.net, self.nstreams, self.inflight = net, streams, inflight
+    def __init__(self, net, streams, inflight=3, size=352, device="cuda:0", warmup=2, group=1):
+        self.net, self.nstreams, self.inflight, self.group = net, streams, inflight, group
         self.T = net.WINDOW
-        self.R = inflight + self.T
+        self.R = inflight * group + self.T
         n, C = (size // 8) ** 2, 128
         self.ring_k = torch.zeros(streams, self.R, n, C, dtype=net.cdtype, device=device)
         self.ring_v = torch.zeros_like(self.ring_k)
-        self.slots = [_LongSlot(net, streams, size, device, warmup) for _ in range(inflight)]
+        self.slots = [_LongSlot(net, streams, size, device, warmup, group) for _ in range(inflight)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]
         self.splits = 1
         # window of step t = ring entries (t - 4 .. t) mod R, one index vector per residue of t
@@ -281,43 +288,61 @@ class PipelinedLong:
             self.ring_v[:, e].copy_(mv[:, j])
         torch.cuda.synchronize()
 
-    def load(self, frames0, frames1, slot=None):
-        for p in (self.slots if slot is None else [self.slots[slot]]):
-            p.f0.copy_(frames0)
-            p.f1.copy_(frames1)
+    def load(self, frames0, frames1, slot=None, sub=None):
+        """frames of one time step ([S,3,H,W] each) into every (slot, sub-step) -- the benchmark -- or into one"""
+        S = self.nstreams
+        for i, p in enumerate(self.slots):
+            if slot is not None and slot != i:
+                continue
+            for g in range(self.group):
+                if sub is None or sub == g:
+                    p.f0[g * S:(g + 1) * S].copy_(frames0)
+                    p.f1[g * S:(g + 1) * S].copy_(frames1)
 
     def replay_free(self):
-        """enqueue step t on stream t mod inflight; returns the slot whose `mask` will hold its result"""
+        """enqueue time step t; returns (slot, sub-step) whose `mask` will hold its result.  The first step of a group replays
+        the group's A graph (its frames must all be loaded by then: a look-ahead of group - 1 frames)."""
         t = self.t
-        i = t % self.inflight
+        S, G = self.nstreams, self.group
+        grp, g = divmod(t, G)
+        i = grp % self.inflight
         p, s = self.slots[i], self.streams[i]
-        e = t % self.R
         with torch.cuda.stream(s):
-            old = self.ev_b.pop(t - self.R + self.T - 1, None)         # last reader of the ring entry about to be overwritten
-            if old is not None:
-                s.wait_event(old)
-            p.graph_a.replay()
-            self.ring_k[:, e].copy_(p.pk[:, 0])
-            self.ring_v[:, e].copy_(p.pv[:, 0])
-            ea = torch.cuda.Event()
-            ea.record(s)
-            self.ev_a[t] = ea
+            if g == 0:
+                for u in range(t, t + G):                    # last readers of the ring entries about to be overwritten
+                    old = self.ev_b.pop(u - self.R + self.T - 1, None)
+                    if old is not None:
+                        s.wait_event(old)
+                p.graph_a.replay()
+                for u in range(G):
+                    e = (t + u) % self.R
+                    self.ring_k[:, e].copy_(p.pk[u * S:(u + 1) * S, 0])
+                    self.ring_v[:, e].copy_(p.pv[u * S:(u + 1) * S, 0])
+                ea = torch.cuda.Event()
+                ea.record(s)
+                for u in range(G):
+                    self.ev_a[t + u] = ea
             for u in range(t - self.T + 1, t):
-                if u in self.ev_a:
+                if u in self.ev_a and u // G != grp:         # (the group's own entries are ordered by the stream)
                     s.wait_event(self.ev_a[u])
-            torch.index_select(self.ring_k, 1, self.idx[e], out=p.keys)
-            torch.index_select(self.ring_v, 1, self.idx[e], out=p.values)
-            p.graph_b.replay()
+            e = t % self.R
+            torch.index_select(self.ring_k, 1, self.idx[e], out=p.keys[g])
+            torch.index_select(self.ring_v, 1, self.idx[e], out=p.values[g])
+            p.graph_b[g].replay()
             eb = torch.cuda.Event()
             eb.record(s)
             self.ev_b[t] = eb
-        self.ev_a.pop(t - self.T, None)
+        self.ev_a.pop(t - self.T - G, None)
         self.t = t + 1
-        self.last = i
-        return i
+        self.last = (i, g)
+        return i if G == 1 else (i, g)
 
-    def masks(self, slot=None):
-        return self.slots[self.last if slot is None else slot].mask
+    def masks(self, slot=None, sub=0):
+        if slot is None:
+            slot, sub = self.last
+        elif isinstance(slot, tuple):
+            slot, sub = slot
+        return self.slots[slot].mask[sub]
 
     def memory(self):
         """the window after the last enqueued step, reference layout [S,1,128,5,44,44] (f32), oldest frame first"""
@@ -327,4 +352,3 @@ class PipelinedLong:
         v = torch.index_select(self.ring_v, 1, self.idx[e])
         h = w = int(round(k.shape[2] ** 0.5))
         return self.net._mem_to_ref(k, h, w), self.net._mem_to_ref(v, h, w)
-

@@ -258,8 +258,21 @@ class Block(EmipModule):
                 s = ops.conv2d_ksplit(x, w["sr"], sr, sr, sr, 0, ks, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps,
                                       out_stats=st_sr)
             elif bf:   # raw patches on the LDS-DMA ring, LayerNorm per tap on the output side (the statistics ride the ring)
-                s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"], ln_eps=self.norm1.eps,
-                              out_stats=st_sr)
+                # that launch form keeps a tile's tap sums in LDS: one tile per workgroup, at most 256 tiles -- beyond (more than
+                # ~44 images at C = 320) the batch goes in image chunks
+                rows_img = (H // sr) * (W // sr)
+                per_tile, ntile_n = (128, 1) if C <= 64 else (64, (C + 127) // 128)
+                per = max(1, ((256 // ntile_n) * per_tile) // rows_img)
+                if B <= per:
+                    s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"],
+                                  ln_eps=self.norm1.eps, out_stats=st_sr)
+                else:
+                    s = torch.empty((B, H // sr, W // sr, C), dtype=dt, device=x.device)
+                    for b0 in range(0, B, per):
+                        b1 = min(B, b0 + per)
+                        ops.conv8(x[b0:b1], w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats[2 * b0 * N:2 * b1 * N],
+                                  tapsum=w["tsr"], ln_eps=self.norm1.eps, out=s[b0:b1],
+                                  out_stats=st_sr[2 * b0 * rows_img:2 * b1 * rows_img])
             else:
                 s = ops.conv2d(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps, out_stats=st_sr)
             kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=cs("kv"))

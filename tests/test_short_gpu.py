@@ -212,3 +212,26 @@ def test_flow_outputs_under_the_well_conditioned_filler(model_args, short_sd, go
     # Measured on MI355X: median 0.75 / 0.19 px, 90th percentile 14 / 7 px, max 64 / 99 px.  The bf16 bound is therefore
     # a bound on the MEDIAN displacement error; the f32 mode above is the one that pins the flow arithmetic.
     assert res[torch.bfloat16][3] < 2.0 and res[torch.bfloat16][4] < 2.0
+
+
+def test_bf16_inference_beyond_the_single_launch_batch(model_args, short_sd):
+    """24 pairs = 48 images: the spatial-reduction conv of the 22 x 22 stage would need 273 tiles, more than the one-tile-per-
+    workgroup launch form takes -- the batch goes in image chunks.  Same masks as two 12-pair forwards (bf16 repeatability band)."""
+    from emip_amd import nn_base
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    try:
+        nn_base.set_default_dtype(torch.bfloat16)
+        net = CoUpdater(model_args)
+        net.load_state_dict(short_sd)
+        net = net.to("cuda:0").eval()
+        im1, im2 = synthetic_pair(24, seed=77)
+        im1, im2 = im1.cuda(), im2.cuda()
+        with torch.no_grad():
+            whole = net(im1, im2)[0].float()
+            halves = torch.cat([net(im1[:12], im2[:12])[0], net(im1[12:], im2[12:])[0]], 0).float()
+            again = torch.cat([net(im1[:12], im2[:12])[0], net(im1[12:], im2[12:])[0]], 0).float()
+        d, jit = (whole - halves).abs().max().item(), (again - halves).abs().max().item()
+        print(f"  24 pairs at once vs 2 x 12: max |dlogit| {d:.4f} (two runs of the halves: {jit:.4f})")
+        assert torch.isfinite(whole).all() and d <= 2.0 * jit + 0.1
+    finally:
+        nn_base.set_default_dtype(torch.float32)

@@ -212,11 +212,13 @@ def test_timed_long_graph_replay_outputs(model_args, long_sd):
         nn_base.set_default_dtype(torch.float32)
 
 
-def test_timed_long_pipelined_steps_in_flight(model_args, long_sd):
-    """bench.py's EMIP-long arrangement: every step one graph pair over all 8 streams, three consecutive TIME STEPS in flight
-    (graph.PipelinedLong: the memory-independent part of a step runs ahead, the memory read waits for the four previous frames'
-    key / value pairs).  Eight different frames are pushed through without a host synchronisation in between; every mask and the
-    final memory window must be what the eager step-by-step evaluation gives (inside the bf16 mode's own repeatability band)."""
+@pytest.mark.parametrize("group", [1, 2])
+def test_timed_long_pipelined_steps_in_flight(model_args, long_sd, group):
+    """bench.py's EMIP-long arrangement: `group` consecutive time steps share one graph of the memory-independent part (a batch of
+    group x 8 pairs), three such groups in flight (graph.PipelinedLong); the memory read of step t waits for the key / value pairs
+    of frames t-4 .. t.  Eight different frames are pushed through without a host synchronisation in between (beyond reading a
+    slot's masks before its buffers are reused); every mask and the final memory window must be what the eager step-by-step
+    evaluation gives (inside the bf16 mode's own repeatability band)."""
     from emip_amd import nn_base
     from emip_amd.graph import PipelinedLong
     from emip_amd.model.EMIP_long.model_long import Model_long
@@ -225,38 +227,46 @@ def test_timed_long_pipelined_steps_in_flight(model_args, long_sd):
         net = Model_long(model_args)
         net.load_state_dict(long_sd)
         net = net.to("cuda:0").eval()
-        S, N = 8, 8
+        S, N, G, NF = 8, 8, group, 3
         frames = [torch.cat([synthetic_pair(1, seed=700 + s, shift=(t % 9 - 4, 4 - t % 7))[1] for s in range(S)], 0).cuda()
                   for t in range(7 + N)]
         k = v = None
         with torch.no_grad():
             for i in range(6):
                 _, k, v = net.forward_streams(frames[i], frames[i + 1], i, k, v)
-            runner = PipelinedLong(net, S, inflight=3)
+            runner = PipelinedLong(net, S, inflight=NF, group=G)
             runner.seed_memory(k, v)
             refs, again = [], []
-            k2, v2 = k, v
             for i in range(6, 6 + N):
                 again.append(net.forward_streams(frames[i], frames[i + 1], i, k, v)[0].float())
                 m, k, v = net.forward_streams(frames[i], frames[i + 1], i, k, v)
                 refs.append(m.float())
             torch.cuda.synchronize()
-            outs = []
-            for j, i in enumerate(range(6, 6 + N)):
-                slot = j % 3
-                if j >= 3:                                   # the slot's previous mask must be read before its buffers are reused
-                    runner.streams[slot].synchronize()
-                    outs.append(runner.masks(slot).float().clone())
-                runner.load(frames[i], frames[i + 1], slot)
-                torch.cuda.current_stream().synchronize()    # the input copies ran on the current stream
-                assert runner.replay_free() == slot
+            outs = [None] * N
+            where = {}
+            for j in range(N):
+                grp, sub = divmod(j, G)
+                slot = grp % NF
+                if sub == 0:
+                    if grp >= NF:                            # the slot's previous masks must be read before its buffers are reused
+                        runner.streams[slot].synchronize()
+                        for jj, (sl, sb) in list(where.items()):
+                            if sl == slot:
+                                outs[jj] = runner.masks(sl, sb).float().clone()
+                                del where[jj]
+                    for u in range(G):                       # the whole group's frames: a look-ahead of G - 1 frames
+                        runner.load(frames[6 + j + u], frames[7 + j + u], slot, u)
+                    torch.cuda.current_stream().synchronize()
+                got = runner.replay_free()
+                assert got == (slot if G == 1 else (slot, sub))
+                where[j] = (slot, sub)
             torch.cuda.synchronize()
-            for j in range(N - 3, N):
-                outs.append(runner.masks(j % 3).float().clone())
+            for jj, (sl, sb) in where.items():
+                outs[jj] = runner.masks(sl, sb).float().clone()
             for j in range(N):
                 d, jit = (outs[j] - refs[j]).abs().max().item(), (again[j] - refs[j]).abs().max().item()
                 iou, iou_jit = _iou(outs[j], refs[j]), _iou(again[j], refs[j])
-                print(f"  long step {6 + j}: pipelined vs eager bf16 max |dlogit| {d:.4f}, IoU {iou:.5f} (two eager runs: {jit:.4f}, IoU {iou_jit:.5f})")
+                print(f"  group {G} long step {6 + j}: pipelined vs eager bf16 max |dlogit| {d:.4f}, IoU {iou:.5f} (two eager runs: {jit:.4f}, IoU {iou_jit:.5f})")
                 assert torch.isfinite(outs[j]).all()
                 assert d <= 2.0 * jit + 0.15 and iou >= iou_jit - 0.03
             mk, mv = runner.memory()
