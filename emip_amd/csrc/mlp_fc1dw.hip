@@ -46,6 +46,7 @@ struct MhArgs {
     bf16_t* G;              // [B * H * W, ldg]
     long ldx, ldg;
     int B, H, Wd_, K, N;
+    int bands, band_rows;   // row bands per image (1: the whole image) and output rows per band
     float eps;
     unsigned x_bytes, w_bytes;
     int xcd_map;
@@ -64,17 +65,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void m
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int slabs = p.N / MH_BN;
-    int img, slab;
+    int unit, slab;                                    // unit = (image, row band)
     if (p.xcd_map) {
         const int j = blockIdx.x >> 3;
         slab = j % slabs;
-        img = (blockIdx.x & 7) + 8 * (j / slabs);
+        unit = (blockIdx.x & 7) + 8 * (j / slabs);
     } else {
         slab = blockIdx.x % slabs;
-        img = blockIdx.x / slabs;
+        unit = blockIdx.x / slabs;
     }
-    const int T = p.H * p.Wd_;                        // tokens of the image
-    const long row0 = (long)img * T;
+    const int img = unit / p.bands, band = unit - img * p.bands;
+    // the band's output rows y0 .. y1 - 1 need the fc1 result of rows ylo .. yhi - 1 (one halo row on each side inside the image:
+    // recomputed by the neighbouring band too -- the price of keeping the fc1 output out of memory on maps of > 512 tokens)
+    const int y0 = band * p.band_rows, y1 = min(p.H, y0 + p.band_rows);
+    const int ylo = max(0, y0 - 1), yhi = min(p.H, y1 + 1);
+    const int T = (yhi - ylo) * p.Wd_;                // tokens staged by this workgroup
+    const long img0 = (long)img * p.H * p.Wd_;
+    const long row0 = img0 + (long)ylo * p.Wd_;
     const int n0 = slab * MH_BN;
 
     const i32x4 rsX = mh_rsrc(p.X, p.x_bytes);
@@ -187,7 +194,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void m
     {
         const int cg = tid & 7, c0 = n0 + 8 * cg;
         const int W2 = (p.Wd_ + 1) >> 1;                  // pixel pairs per image row
-        const int npair = p.H * W2;
+        const int npair = (y1 - y0) * W2;
         float bdv[8];
 #pragma unroll
         for (int j = 0; j < 8; j += 4) {
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void m
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int pr = (tid >> 3) + 64 * i;
-            py[i] = pr < npair ? pr / W2 : -4;            // -4: no row of the window is inside the image
+            py[i] = pr < npair ? y0 + pr / W2 : -4;       // image row; -4: no row of the window is inside the image
             px[i] = 2 * (pr - (pr / W2) * W2);
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void m
                 for (int dx = 0; dx < 4; ++dx) {
                     const int xx = px[i] - 1 + dx;
                     if ((unsigned)xx >= (unsigned)p.Wd_) continue;
-                    const int t = yy * p.Wd_ + xx;
+                    const int t = (yy - ylo) * p.Wd_ + xx;  // token inside the staged rows
                     const uint4 raw = *reinterpret_cast<const uint4*>(smem + t * 128 + ((cg ^ (t & 7)) * 16));
                     const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w};
                     float v[8];
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void m
                     bf16x8 ov;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)gelu_poly(o[i][q][j]);
-                    *reinterpret_cast<bf16x8*>(p.G + (row0 + py[i] * p.Wd_ + x) * p.ldg + c0) = ov;
+                    *reinterpret_cast<bf16x8*>(p.G + (img0 + py[i] * p.Wd_ + x) * p.ldg + c0) = ov;
                 }
             }
         }
@@ -265,9 +272,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4))) void m
 
 }  // namespace
 
+// output rows per band: the whole image when it fits the 512-row tile, else the most rows whose halo-extended band does
+static int mh_band_rows(int H, int Wd) {
+    if (H * Wd <= MH_ROWS) return H;
+    const int r = MH_ROWS / Wd - 2;
+    return r >= 1 ? r : 0;
+}
+
 extern "C" int emip_mlp_fc1dw_eligible(int B, int H, int Wd, int K, int N) {
     // at least half of the 512-row tile must be tokens (the 11 x 11 stage pads 121 to 512 and loses: 46 vs 34 us)
     return B > 0 && H * Wd <= MH_ROWS && 2 * H * Wd > MH_ROWS && Wd >= 2 && K % MH_BK == 0 && K >= MH_BK && N % MH_BN == 0;
+}
+
+// maps of more than 512 tokens: row bands with a halo row on each side (the 44 x 44 stage: bands of 9 rows, 11 staged = 1.22x the
+// fc1 work; the 88 x 88 stage: 3 rows, 5 staged = 1.67x).  Returns the output rows per band, 0 = not eligible.
+extern "C" int emip_mlp_fc1dw_band_rows(int B, int H, int Wd, int K, int N) {
+    if (!(B > 0 && Wd >= 2 && K % MH_BK == 0 && K >= MH_BK && N % MH_BN == 0) || H * Wd <= MH_ROWS) return 0;
+    const int r = mh_band_rows(H, Wd);
+    return (r >= 1 && 2 * (r + 2) * Wd > MH_ROWS) ? r : 0;
 }
 
 // G = GELU(dwconv3x3(LN(X) W1^T + b1) + bd) per image; see the head of this file.  bf16 activations / weights, f32 vectors.
@@ -275,7 +297,8 @@ extern "C" int emip_mlp_fc1dw(const void* X, long ldx, const void* W1, const flo
                               const float* ln_stats, float eps, const float* Wd, const float* bd, void* G, long ldg, int B,
                               int H, int Wdt, int K, int N, void* stream) {
     EMIP_REQUIRE(X && W1 && b1 && colsum && ln_stats && Wd && bd && G);
-    EMIP_REQUIRE(emip_mlp_fc1dw_eligible(B, H, Wdt, K, N) && ldx >= K && (ldx & 7) == 0 && ldg >= N && (ldg & 7) == 0);
+    EMIP_REQUIRE((emip_mlp_fc1dw_eligible(B, H, Wdt, K, N) || emip_mlp_fc1dw_band_rows(B, H, Wdt, K, N) > 0) && ldx >= K &&
+                 (ldx & 7) == 0 && ldg >= N && (ldg & 7) == 0);
     EMIP_REQUIRE(aligned16(X) && aligned16(W1) && aligned16(G) && aligned16(Wd) && aligned16(bd));
     const long rows = (long)B * H * Wdt;
     EMIP_REQUIRE(rows * ldx * 2 < 0x7FFF0000L && (long)N * K * 2 < 0x7FFF0000L);
@@ -285,13 +308,16 @@ extern "C" int emip_mlp_fc1dw(const void* X, long ldx, const void* W1, const flo
     a.B = B; a.H = H; a.Wd_ = Wdt; a.K = K; a.N = N; a.eps = eps;
     a.x_bytes = (unsigned)(((rows - 1) * ldx + K) * 2);
     a.w_bytes = (unsigned)((long)N * K * 2);
-    a.xcd_map = (B % 8) == 0;
+    a.band_rows = mh_band_rows(H, Wdt);
+    a.bands = (H + a.band_rows - 1) / a.band_rows;
+    a.xcd_map = ((B * a.bands) % 8) == 0;
+    EMIP_REQUIRE((long)B * a.bands * (N / MH_BN) < 2147483647L);
     static bool attr = false;
     if (!attr) {
         attr = true;
         if (hipFuncSetAttribute((const void*)mlp_fc1dw_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS) != hipSuccess)
             return EMIP_E_LAUNCH;
     }
-    hipLaunchKernelGGL(mlp_fc1dw_kernel, dim3((unsigned)(B * (N / MH_BN))), dim3(512), MH_LDS, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(mlp_fc1dw_kernel, dim3((unsigned)(B * a.bands * (N / MH_BN))), dim3(512), MH_LDS, (hipStream_t)stream, a);
     return emip_launch_status();
 }

@@ -40,6 +40,8 @@ SRA_FUSED = True
 # other on 10 waves per CU (phase ablation: depthwise + GELU 43 us, fc2 26, fc1 18, H stores 8, 60 barriers + prologue 24) --
 # and with three steps in flight the throughput follows the SUM of the kernels' isolated times, not the CUs a launch leaves
 # free: 1401 against 1536 pairs/s (tools/flag_ab.py).  What it would take: DESIGN.md section 7d.
+FC1DW_BAND_MIN_ROWS = 3     # banded fc1 + depthwise launch for maps of > 512 tokens when a band has at least this many output rows (0: off;
+                            # in-call at 16 pairs: off 1592, the 44 x 44 stage only 1618, the 88 x 88 stage too 1628 pairs/s)
 MLP_BLOCK = False
 # the spatial-reduction convs with few output tiles and a long K walk (stages 1-2: 61 tiles x 64 / 32 K tiles at 32 images)
 # with K split inside the launch (emip_conv2d_ksplit, the normalising loader) instead of the per-tap ring body.  OFF: shorter
@@ -305,7 +307,7 @@ class Block(EmipModule):
             # the whole Mlp half in one launch: the hidden tensor never leaves the CU (out of place: bands read halo rows)
             ops.mlp_block(x, w["w1"], w["w2"], w["mcst"], w["b2"], st1, self.norm2.eps, alt, out_stats=st2)
             return alt, st2, x
-        if bf and ops.mlp_fc1dw_eligible(B, H, W, C, hid):
+        if bf and (ops.mlp_fc1dw_eligible(B, H, W, C, hid) or (0 < FC1DW_BAND_MIN_ROWS <= ops.mlp_fc1dw_band_rows(B, H, W, C, hid))):
             # fc1 + depthwise 3x3 + GELU in one launch, one whole image per workgroup: the fc1 output never leaves the CU
             t = ops.mlp_fc1dw(x, w["w1"], w["b1"], w["sw1"], st1, self.norm2.eps, w["wd"], w["bd"])
         else:

@@ -665,6 +665,11 @@ def mlp_fc1dw_eligible(B, H, W, K, N):
     return bool(_lib.load().emip_mlp_fc1dw_eligible(B, H, W, K, N))
 
 
+def mlp_fc1dw_band_rows(B, H, W, K, N):
+    """output rows per band of the banded form (maps of more than 512 tokens); 0 = not eligible"""
+    return int(_lib.load().emip_mlp_fc1dw_band_rows(B, H, W, K, N))
+
+
 def mlp_fc1dw(x, w1, b1, colsum, ln_stats, eps, wd, bd):
     """GELU(dwconv3x3(LN(x) w1^T + b1) + bd) for images of <= 512 tokens (bf16): x [B,H,W,K] raw tokens with their row
     statistics ln_stats [B*H*W, 2], w1 [N,K] with the LayerNorm scale folded in, colsum [N] its row sums -> [B,H,W,N]"""

@@ -431,6 +431,9 @@ int emip_mlp_block(const void* X, long ldx, const void* W1, const void* W2, cons
                    const float* ln_stats, float eps, void* Out, long ldo, float* out_stats, int B, int H, int W, int C,
                    int N, void* stream);
 int emip_mlp_fc1dw_eligible(int B, int H, int Wd, int K, int N);
+/* Maps of more than 512 tokens go in row bands with one halo row on each side (the fc1 result of the halo rows is recomputed):
+ * output rows per band, 0 = not eligible.  emip_mlp_fc1dw accepts both forms. */
+int emip_mlp_fc1dw_band_rows(int B, int H, int Wd, int K, int N);
 
 /* The large-launch body of the weight gradients (bf16, dense operands, M >= 2048): the same contraction as emip_gemm_tn on a
  * ring of LDS-DMA stages (gemm_tn8.hip).  emip_gemm_tn / _bias / _into hand it every eligible launch; this is the explicit

@@ -501,13 +501,16 @@ def test_conv_pair_with_fused_split_k(dt, tol, B, H, C, k, ksplit):
         assert acc.abs().max().item() == 0 and ticket.abs().max().item() == 0
 
 
-@pytest.mark.parametrize("B,H,W,K,N", [(8, 22, 22, 320, 1280), (3, 22, 22, 320, 1280), (5, 20, 24, 64, 128), (2, 17, 23, 96, 192)])
+@pytest.mark.parametrize("B,H,W,K,N", [(8, 22, 22, 320, 1280), (3, 22, 22, 320, 1280), (5, 20, 24, 64, 128), (2, 17, 23, 96, 192),
+                                       (4, 44, 44, 128, 512), (3, 88, 88, 64, 256), (2, 30, 37, 64, 128), (8, 24, 24, 64, 64)])
 def test_mlp_fc1dw_fused_head(B, H, W, K, N):
     """emip_mlp_fc1dw (lib/pvt_v2.py:45-54 with norm2 folded, 165-169): fc1 + depthwise 3x3 + GELU in one launch == the two
     launches it replaces (bit for bit where both run the same K order, else to one bf16 step) == torch on the rounded operands.
     B = 8: the XCD-aware id decode; odd widths and a non-square image: the window logic at the borders."""
     from emip_amd import ops
-    assert ops.mlp_fc1dw_eligible(B, H, W, K, N)
+    # maps of more than 512 tokens: row bands with a recomputed halo row on each side (44 x 44: 9-row bands, 88 x 88: 3-row bands,
+    # 30 x 37: 11-row bands with a ragged last one, 24 x 24: 19 + 5 rows)
+    assert ops.mlp_fc1dw_eligible(B, H, W, K, N) or ops.mlp_fc1dw_band_rows(B, H, W, K, N) > 0
     g = torch.Generator().manual_seed(B * 1000 + H)
     x = (torch.randn(B, H, W, K, generator=g) * 1.3 + 0.2).to(torch.bfloat16).cuda()
     w1 = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).cuda()
