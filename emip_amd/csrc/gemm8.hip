@@ -550,7 +550,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
 }
 
 struct Cfg {
-    int bm, bn, nst;
+    int bm, bn, nst, nst_lnt;
     void (*dense)(const G8Args);
     void (*conv)(const G8Args);
     void (*lnt)(const G8Args);      // conv with the per-tap LayerNorm (small tiles only)
@@ -559,17 +559,22 @@ struct Cfg {
 };
 
 #define G8_CFG(BM, BN, WGM, WGN, NST)                                                                            \
-    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr, \
+    {BM, BN, NST, 0, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr, \
      gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>, nullptr}
 #define G8_CFG_LNO(BM, BN, WGM, WGN, NST)                                                                        \
-    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr, \
+    {BM, BN, NST, 0, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, nullptr, \
      gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>, gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, false, true>}
 // the per-tap LayerNorm instances serve 31..183 workgroups walking 20..64 K tiles each: a 5-deep ring (4 tiles in flight)
 constexpr int NST_LNT = 5;
 #define G8_CFG_LNT(BM, BN, WGM, WGN, NST)                                                             \
-    {BM, BN, NST, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, \
+    {BM, BN, NST, NST_LNT, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, \
      gemm8_kernel<BM, BN, WGM, WGN, NST_LNT, true, true>, gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>, \
      gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, false, true>}
+// N = 320 in ONE tile for the per-tap LayerNorm conv of the 22 x 22 stage: the token panel is read once instead of once per
+// 128-column tile, 61 workgroups instead of 183 at 32 images; 3 ring slots of 50 KB
+#define G8_CFG_LNTW(BM, BN, WGM, WGN, NST, NSTL)                                                          \
+    {BM, BN, NST, NSTL, gemm8_kernel<BM, BN, WGM, WGN, NST, false>, gemm8_kernel<BM, BN, WGM, WGN, NST, true>, \
+     gemm8_kernel<BM, BN, WGM, WGN, NSTL, true, true>, gemm8_kernel<BM, BN, WGM, WGN, NST, false, false, true>, nullptr}
 
 const Cfg g_cfg[] = {
     G8_CFG(256, 128, 4, 2, 3),       // 1: wave 64 x 64, 144 KB
@@ -581,6 +586,7 @@ const Cfg g_cfg[] = {
     G8_CFG(256, 256, 2, 4, 2),       // 7: wave 128 x 64, 128 KB
     G8_CFG_LNT(128, 64, 4, 2, 3),    // 8: wave 32 x 32, 72 KB (2 per CU)
     G8_CFG_LNT(64, 128, 2, 4, 3),    // 9: wave 32 x 32, 72 KB (2 per CU)
+    G8_CFG_LNTW(64, 320, 2, 4, 3, 3),  // 10: wave 32 x 80, 144 KB; per-tap LayerNorm 155 KB
 };
 constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
 
@@ -613,7 +619,7 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     a.tiles_m = (a.M + g.bm - 1) / g.bm;
     a.tiles_n = (a.N + g.bn - 1) / g.bn;
     size_t lds = (size_t)g.nst * (g.bm + g.bn) * 128;
-    if (lnt) lds = (size_t)NST_LNT * ((g.bm + g.bn) * 128 + 2048) + (size_t)a.KH * a.KW * g.bn * 4;
+    if (lnt) lds = (size_t)g.nst_lnt * ((g.bm + g.bn) * 128 + 2048) + (size_t)a.KH * a.KW * g.bn * 4;
     if (lds > 160 * 1024) return EMIP_E_INVALID;
     const bool rs = a.rowscale != nullptr;
     if (rs && (lnt || conv)) return EMIP_E_INVALID;
@@ -647,7 +653,7 @@ extern "C" int emip_tuning_gemm8_dbg(int v) { g8_dbg = v; return 0; }
 // introspection for bench.py: the tile (BM * 1000 + BN) and ring depth of a configuration, 0 for an unknown one
 extern "C" int emip_gemm8_cfg_tile(int cfg) { return cfg >= 1 && cfg <= NCFG ? g_cfg[cfg - 1].bm * 1000 + g_cfg[cfg - 1].bn : 0; }
 extern "C" int emip_gemm8_cfg_stages(int cfg, int lnt) {
-    return cfg >= 1 && cfg <= NCFG ? (lnt ? NST_LNT : g_cfg[cfg - 1].nst) : 0;
+    return cfg >= 1 && cfg <= NCFG ? (lnt ? g_cfg[cfg - 1].nst_lnt : g_cfg[cfg - 1].nst) : 0;
 }
 
 // ---- dispatch hooks of emip_gemm_ln / emip_conv2d_splitk (gemm.hip): > 0 = not eligible, the 4-wave body runs -----------

@@ -40,6 +40,7 @@ SRA_FUSED = True
 # other on 10 waves per CU (phase ablation: depthwise + GELU 43 us, fc2 26, fc1 18, H stores 8, 60 barriers + prologue 24) --
 # and with three steps in flight the throughput follows the SUM of the kernels' isolated times, not the CUs a launch leaves
 # free: 1401 against 1536 pairs/s (tools/flag_ab.py).  What it would take: DESIGN.md section 7d.
+SR_WIDE_TILE = True         # the spatial-reduction conv of the 22 x 22 stage on ONE 64 x 320 tile per 64 rows (gemm8 configuration 10)
 FC1DW_BAND_MIN_ROWS = 3     # banded fc1 + depthwise launch for maps of > 512 tokens when a band has at least this many output rows (0: off;
                             # in-call at 16 pairs: off 1592, the 44 x 44 stage only 1618, the 88 x 88 stage too 1628 pairs/s)
 MLP_BLOCK = False
@@ -263,18 +264,20 @@ class Block(EmipModule):
                 # that launch form keeps a tile's tap sums in LDS: one tile per workgroup, at most 256 tiles -- beyond (more than
                 # ~44 images at C = 320) the batch goes in image chunks
                 rows_img = (H // sr) * (W // sr)
-                per_tile, ntile_n = (128, 1) if C <= 64 else (64, (C + 127) // 128)
+                wide = SR_WIDE_TILE and C == 320           # N = 320 in one 64 x 320 tile: the token panel is read once
+                scfg = 10 if wide else 0
+                per_tile, ntile_n = (128, 1) if C <= 64 else (64, 1 if wide else (C + 127) // 128)
                 per = max(1, ((256 // ntile_n) * per_tile) // rows_img)
                 if B <= per:
                     s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"],
-                                  ln_eps=self.norm1.eps, out_stats=st_sr)
+                                  ln_eps=self.norm1.eps, out_stats=st_sr, cfg=scfg)
                 else:
                     s = torch.empty((B, H // sr, W // sr, C), dtype=dt, device=x.device)
                     for b0 in range(0, B, per):
                         b1 = min(B, b0 + per)
                         ops.conv8(x[b0:b1], w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats[2 * b0 * N:2 * b1 * N],
                                   tapsum=w["tsr"], ln_eps=self.norm1.eps, out=s[b0:b1],
-                                  out_stats=st_sr[2 * b0 * rows_img:2 * b1 * rows_img])
+                                  out_stats=st_sr[2 * b0 * rows_img:2 * b1 * rows_img], cfg=scfg)
             else:
                 s = ops.conv2d(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, ln_eps=self.norm1.eps, out_stats=st_sr)
             kv = ops.gemm(s, w["kv"], bias=w["bkv"], ln_stats=st_sr, ln_eps=a.norm.eps, colsum=cs("kv"))

@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-NCFG = 9
+NCFG = 10
 
 
 def dev():
@@ -94,8 +94,9 @@ def test_conv_implicit_gemm(cfg, B, H, W, Cin, Cout, k, stride, pad):
     assert (out.float() - ref).abs().max().item() < 2e-2 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("B,H,C,sr", [(4, 22, 320, 2), (3, 44, 128, 4), (2, 88, 64, 8), (1, 22, 320, 2)])
-def test_spatial_reduction_conv_with_per_tap_layernorm(B, H, C, sr):
+@pytest.mark.parametrize("B,H,C,sr,cfg", [(4, 22, 320, 2, 0), (3, 44, 128, 4, 0), (2, 88, 64, 8, 0), (1, 22, 320, 2, 0),
+                                          (32, 22, 320, 2, 10), (5, 22, 320, 2, 10)])
+def test_spatial_reduction_conv_with_per_tap_layernorm(B, H, C, sr, cfg):
     """x_ = sr(norm1(x)) with gamma / beta folded into the weights: raw patches in, LayerNorm applied per tap on the output"""
     from emip_amd import ops
     x = (_rand(B, H, H, C, seed=14) * 1.5 + _rand(B, H, H, 1, seed=15) * 4).to(torch.bfloat16)
@@ -108,7 +109,8 @@ def test_spatial_reduction_conv_with_per_tap_layernorm(B, H, C, sr):
     ln = (xf - xf.mean(-1, keepdim=True)) * torch.rsqrt(xf.var(-1, unbiased=False, keepdim=True) + eps)
     ref = _conv_ref(ln, wp, bias, sr, sr, 0)
     ost = torch.zeros(ref.numel() // C, 2, device=dev())
-    out = ops.conv8(x, wp, sr, sr, sr, 0, bias=bias, ln_stats=stats, tapsum=tapsum, ln_eps=eps, out_stats=ost)
+    # cfg 10: N = 320 in one 64 x 320 tile (the token panel read once)
+    out = ops.conv8(x, wp, sr, sr, sr, 0, bias=bias, ln_stats=stats, tapsum=tapsum, ln_eps=eps, out_stats=ost, cfg=cfg)
     assert (out.float() - ref).abs().max().item() < 3e-2 * max(1.0, ref.abs().max().item())
     of = out.float().reshape(-1, C)
     assert (ost[:, 0] - of.sum(1)).abs().max().item() < 2e-2 * max(1.0, of.sum(1).abs().max().item())
