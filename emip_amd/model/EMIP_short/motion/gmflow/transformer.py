@@ -52,8 +52,9 @@ class TransformerLayer(EmipModule):
                                  self.norm1.weight, self.norm1.bias), build)
         if not self.no_ffn:
             f = self.packed("ffn", (self.mlp[0].weight, self.mlp[2].weight, self.norm2.weight, self.norm2.bias),
-                            lambda a, b, g, be: dict(m0=pack_linear(a, dt), m2=pack_linear(b, dt),
-                                                     n2=(f32(g), f32(be))))
+                            lambda a, b, g, be: dict(m0=pack_linear(a, dt), m2=pack_linear(b, dt), n2=(f32(g), f32(be)),
+                                                     ffn=(ops.ffn_block_packs(a, b, dt) if (dt == torch.bfloat16 and
+                                                          tuple(a.shape) == (1024, 256)) else None)))
             w = dict(w, **f)
         return w
 
@@ -102,6 +103,9 @@ def _window_attention(q, k, v, B2, h, w, C, ldq, ldk, ldv, shift, splits, kv_rot
                   k_bs=n * ldk, v_bs=n * ldv, o_bs=n * C, ldq=ldq, ldk=ldk, ldv=ldv, ldo=C, q_rows=rows, k_rows=rows,
                   q_gid=gid if shift else None, k_gid=gid if shift else None, scale=C ** -0.5, kv_rot=kv_rot)
     return out
+
+
+FFN_BLOCK = True        # emip_ffn_block: mlp[0] + GELU + mlp[2] + norm2 + residual in one launch (bf16 inference)
 
 
 class FeatureTransformer(EmipModule):
@@ -164,8 +168,12 @@ class FeatureTransformer(EmipModule):
             q = ops.gemm(c0, wc["q"])
             msg = _window_attention(q, ck, cv, B2, h, w, C, C, ldc5, ldc5, shift, attn_num_splits, kv_rot=rot)
             msg = ops.gemm_ln_out(msg, wc["merge"], wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps)
-            hid = ops.gemm(c0, wc["m0"], a2=msg, act=ops.ACT_GELU)
-            ops.gemm_ln_out(hid, wc["m2"], wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps, res=c0, out=c0)  # c0 += LN(mlp)
+            if FFN_BLOCK and wc.get("ffn") is not None:      # the whole FFN in one launch: the 1024-wide hidden tensor stays on the CU
+                ops.ffn_block(c0, msg, wc["ffn"][0], wc["ffn"][1], wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps,
+                              res=c0, out=c0)
+            else:
+                hid = ops.gemm(c0, wc["m0"], a2=msg, act=ops.ACT_GELU)
+                ops.gemm_ln_out(hid, wc["m2"], wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps, res=c0, out=c0)  # c0 += LN(mlp)
         return c0
 
 

@@ -454,6 +454,36 @@ def gemm_ln_out(a, w, gamma, beta, eps, bias=None, res=None, out=None):
     return layernorm(msg, gamma, beta, eps, out=out, res=res)
 
 
+def ffn_block_packs(w0, w2, dtype=torch.bfloat16):
+    """mlp[0].weight [1024, 256] and mlp[2].weight [128, 1024] in the fragment order emip_ffn_block streams: one 1-KB piece = the
+    MFMA A operand of all 64 lanes (lane = row r + 32 h holds 8 values).  W0: [chunk c][k-step i][h][r][j] = W0[32 c + r][16 i + 8 h
+    + j]; W2: [chunk c][row tile d][k-step sp][h][r][j] = W2[32 d + r][32 c + 16 sp + 8 (j >> 2) + 4 h + (j & 3)] -- the hidden
+    channel the accumulator register 8 sp + j of lane half h holds after H^T = W0 X^T."""
+    assert tuple(w0.shape) == (1024, 256) and tuple(w2.shape) == (128, 1024)
+    p0 = w0.detach().to(dtype).view(32, 32, 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    sp, h, j = torch.meshgrid(torch.arange(2), torch.arange(2), torch.arange(8), indexing="ij")
+    hid = (16 * sp + 8 * (j >> 2) + 4 * h + (j & 3)).to(w2.device)                     # [sp][h][j]
+    w2v = w2.detach().to(dtype).view(4, 32, 32, 32)                                    # [d][r][c][hidden in chunk]
+    p2 = w2v[:, :, :, hid]                                                             # [d][r][c][sp][h][j]
+    p2 = p2.permute(2, 0, 3, 4, 1, 5).contiguous()                                     # [c][d][sp][h][r][j]
+    return p0.view(-1), p2.view(-1)
+
+
+def ffn_block(x1, x2, w0p, w2p, gamma, beta, eps, res=None, out=None):
+    """emip_ffn_block: out = res + LayerNorm(GELU([x1 | x2] W0^T) W2^T) * gamma + beta on [.., 128] bf16 tokens"""
+    _dev(x1)
+    M, C, ld1 = rows(x1)
+    _, _, ld2 = rows(x2)
+    assert C == 128 and x2.shape[-1] == 128 and x1.dtype == x2.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty(x1.shape, dtype=x1.dtype, device=x1.device)
+    ldo = rows(out)[2]
+    ldr = rows(res)[2] if res is not None else 0
+    _lib.call("emip_ffn_block", _p(x1), ld1, _p(x2), ld2, _p(w0p), _p(w2p), _p(gamma), _p(beta), float(eps), _p(res), ldr,
+              _p(out), ldo, M, _stream())
+    return out
+
+
 # emip_attention_splitkv for >= KV_SPLIT_MIN_KEYS keys on grids of < KV_SPLIT_TARGET workgroups (two per CU)
 KV_SPLIT_MIN_KEYS = 1024
 KV_SPLIT_TARGET = 512

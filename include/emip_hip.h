@@ -286,6 +286,13 @@ int emip_window_attention_bwd(const void* Q, const void* K, const void* V, const
                               long q_bs, long k_bs, long v_bs, const int* rows, const int* gid, int tokens, int kv_rot,
                               float scale, void* stream);
 
+/* GMFlow transformer FFN in one launch (gmflow/transformer.py:316-345: mlp = Linear(2C, 8C) -> GELU -> Linear(8C, C), both without
+ * bias, norm2, `source + message`; C = 128): Out = Res + LayerNorm(GELU([X1 | X2] W0^T) W2^T) * gamma + beta, the [M][1024] hidden
+ * tensor never leaves the CU.  W0p / W2p: mlp[0].weight [1024][256] and mlp[2].weight [128][1024] packed in MFMA-fragment order
+ * (emip_amd.ops.ffn_block_packs).  Res may be NULL or alias Out; X1 may alias Out (a token's row is read and written by one lane). */
+int emip_ffn_block(const void* X1, long ld1, const void* X2, long ld2, const void* W0p, const void* W2p, const float* gamma,
+                   const float* beta, float eps, const void* Res, long ldr, void* Out, long ldo, long M, void* stream);
+
 /* MDTA channel attention matrix: L2-normalise q,k over pixels, 64x64 Gram per head, * temperature, softmax.
  * PromptInteract.py:423-428.  ws: f32 [B*heads*(4096+128)] scratch; attn out: T [B][heads][64][64]. */
 int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K, long ldk, long k_bs, const float* temperature,
