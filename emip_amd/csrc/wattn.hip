@@ -44,6 +44,12 @@ struct WaArgs {
     const bf16_t* V;
     bf16_t* O;
     float* lse;            // [B][tokens] log2-sum-exp of the scaled, masked scores (training forward) or null
+    const bf16_t* Wm;      // MERGE: merge.weight [128][128] in fragment order (ops.wattn_merge_pack)
+    const float* gamma;    // MERGE: norm1 weight / bias, f32 [128]
+    const float* beta;
+    const bf16_t* Res;     // MERGE: residual tokens (may alias O) or null
+    long ldr, r_bs;
+    float eps;
     const int* rows;       // [nwin][L] token of the frame for every window-local token
     const int* gid;        // [nwin][L] region ids (shifted windows) or null
     long ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs;
@@ -64,10 +70,11 @@ constexpr unsigned WA_OOB = 0x80000000u;
 constexpr int WA_BK = 64, WA_NST = 3, WA_KT = WA_BK * 256, WA_STAGE = 2 * WA_KT, WA_LMAX = 512;
 constexpr int WA_RING = WA_NST * WA_STAGE;                 // 98 304 B
 constexpr int WA_LDS = WA_RING + 2 * WA_LMAX * 4;          // + the window's row and region tables: 102 400 B
+constexpr int WA_WM = 32 * 1024, WA_LDS_MERGE = WA_LDS + WA_WM + 2 * 128 * 4;      // + the merge weight (32 fragment pieces), gamma, beta
 
 __device__ __forceinline__ int wa_voff(int row, int c) { return row * 256 + ((c ^ ((row & 3) << 2)) * 16); }
 
-template <bool MASK>
+template <bool MASK, bool MERGE = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void wattn_kernel(const WaArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -87,6 +94,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
         tgid[i] = (MASK && i < p.L) ? p.gid[(long)win * p.L + i] : 0;
     }
 
+    if (MERGE) {
+        // the merge weight (32 KB, fragment order) and the norm vectors wait behind the tables for the epilogue; issued first, so
+        // every later counted wait covers these pieces too
+        const i32x4 rsM = wa_rsrc(p.Wm, 32768u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wa_dma16(lds0 + WA_LDS + (4 * wave + j) * 1024, (unsigned)((4 * wave + j) * 1024 + lane * 16), rsM);
+        float* tg = reinterpret_cast<float*>(smem + WA_LDS + WA_WM);
+        if (tid < 256) tg[tid] = tid < 128 ? p.gamma[tid] : p.beta[tid - 128];
+    }
     // ---- this lane's query: its row of the frame, its region, its fragments (k-step i: channels 16 i + 8 h .. + 7)
     const int q = qb * 256 + wave * 32 + lq;
     const bool q_ok = q < p.L;
@@ -236,6 +252,65 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
     // ---- normalise and store: registers 4 g .. 4 g + 3 of block d = channels 32 d + 8 g + 4 h + (0..3) of this lane's query
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
+    if (MERGE) {
+        // ---- out = res + LayerNorm(merge(attention)) * gamma + beta (transformer.py:330-338) without the attention output in
+        // memory: the normalised O accumulators, rounded to bf16, are the B operand of M^T = Wm O^T (registers 8 sp .. 8 sp + 7 of
+        // tile d = channels 32 d + 16 sp + 8 (j >> 2) + 4 h + (j & 3): the order the weight pack follows)
+        bf16x8 of[8];
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) of[2 * d + sp][j] = (bf16_t)(oacc[d][8 * sp + j] * inv);
+        const char* wm = smem + WA_LDS;
+        f32x16 macc[4];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) macc[dd][r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint4 wf = *reinterpret_cast<const uint4*>(wm + (dd * 8 + ks) * 1024 + lane * 16);
+                macc[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), of[ks], macc[dd], 0, 0, 0);
+            }
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s1 += macc[dd][r];
+                s2 = fmaf(macc[dd][r], macc[dd][r], s2);
+            }
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        const float mean = s1 * (1.0f / 128), rstd = rsqrtf(fmaxf(s2 * (1.0f / 128) - mean * mean, 0.f) + p.eps);
+        if (q_ok) {
+            const float* tg = reinterpret_cast<const float*>(smem + WA_LDS + WA_WM);
+            const bf16_t* rp = p.Res ? p.Res + b * p.r_bs + (long)qrow * p.ldr : nullptr;
+            bf16_t* Op = p.O + b * p.o_bs + (long)qrow * p.ldo;
+#pragma unroll
+            for (int dd = 0; dd < 4; ++dd)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = 32 * dd + 8 * g + 4 * h;
+                    const float4 gm = *reinterpret_cast<const float4*>(tg + ch), bt = *reinterpret_cast<const float4*>(tg + 128 + ch);
+                    const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (rp) {
+                        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp + ch);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rv[j] = (float)r4[j];
+                    }
+                    bf16x4 ov;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) ov[j] = (bf16_t)(fmaf((macc[dd][4 * g + j] - mean) * rstd, gv[j], bv[j]) + rv[j]);
+                    *reinterpret_cast<bf16x4*>(Op + ch) = ov;
+                }
+        }
+        return;
+    }
     if (q_ok) {
         if (p.lse && h == 0) p.lse[b * p.tokens + qrow] = m_run + __log2f(l_tot);      // what emip_window_attention_bwd rebuilds P from
         bf16_t* Op = p.O + b * p.o_bs + (long)qrow * p.ldo;
@@ -293,5 +368,48 @@ extern "C" int emip_window_attention(const void* Q, const void* K, const void* V
         hipLaunchKernelGGL(wattn_kernel<true>, grid, dim3(512), WA_LDS, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(wattn_kernel<false>, grid, dim3(512), WA_LDS, (hipStream_t)stream, a);
+    return emip_launch_status();
+}
+
+// The same followed, in the launch, by the layer's merge Linear, norm1 and the residual (gmflow/transformer.py:330-338: message =
+// norm1(merge(attention)), then `source + message` for the layer without FFN): O = Res + LayerNorm(attention Wm^T) * gamma + beta.
+// Wm: merge.weight [128][128] in fragment order (emip_amd.ops.wattn_merge_pack); Res: NULL or the residual tokens (row stride ldr,
+// batch stride r_bs; may alias O when Q is not a view of O's rows).
+extern "C" int emip_window_attention_merge(const void* Q, const void* K, const void* V, void* O, int B, int nwin, int L, long ldq,
+                                           long ldk, long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs,
+                                           const int* rows, const int* gid, int tokens, int kv_rot, float scale, const void* Wm,
+                                           const float* gamma, const float* beta, float eps, const void* Res, long ldr, long r_bs,
+                                           void* stream) {
+    EMIP_REQUIRE(Q && K && V && O && rows && Wm && gamma && beta && eps > 0.f && B > 0 && nwin > 0 && L >= WA_BK && L <= WA_LMAX && tokens >= L);
+    EMIP_REQUIRE(B < 65536 && nwin < 65536 && kv_rot >= 0 && kv_rot < B);
+    EMIP_REQUIRE(ldq >= 128 && ldk >= 128 && ldv >= 128 && ldo >= 128 && ((ldq | ldk | ldv) & 7) == 0 && (ldo & 3) == 0);
+    EMIP_REQUIRE(((q_bs | k_bs | v_bs) & 7) == 0 && (o_bs & 3) == 0 && (!Res || (ldr >= 128 && ((ldr | r_bs) & 3) == 0)));
+    EMIP_REQUIRE(aligned16(Q) && aligned16(K) && aligned16(V) && aligned16(Wm) && (reinterpret_cast<uintptr_t>(O) & 7u) == 0 &&
+                 (!Res || (reinterpret_cast<uintptr_t>(Res) & 7u) == 0));
+    EMIP_REQUIRE(((long)(tokens - 1) * ldk + 128) * 2 < 0x7FFF0000L && ((long)(tokens - 1) * ldv + 128) * 2 < 0x7FFF0000L);
+    WaArgs a{};
+    a.Q = (const bf16_t*)Q; a.K = (const bf16_t*)K; a.V = (const bf16_t*)V; a.O = (bf16_t*)O; a.lse = nullptr; a.tokens = tokens;
+    a.rows = rows; a.gid = gid;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.q_bs = q_bs; a.k_bs = k_bs; a.v_bs = v_bs; a.o_bs = o_bs;
+    a.B = B; a.nwin = nwin; a.L = L; a.rot = kv_rot; a.scale = scale;
+    a.qblocks = (L + 255) / 256;
+    a.k_bytes = (unsigned)(((long)(tokens - 1) * ldk + 128) * 2);
+    a.v_bytes = (unsigned)(((long)(tokens - 1) * ldv + 128) * 2);
+    a.Wm = (const bf16_t*)Wm; a.gamma = gamma; a.beta = beta; a.eps = eps; a.Res = (const bf16_t*)Res; a.ldr = ldr; a.r_bs = r_bs;
+#ifdef EMIP_TUNING
+    a.skip = 0;
+#endif
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
+        if (hipFuncSetAttribute((const void*)wattn_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS_MERGE) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wattn_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS_MERGE) != hipSuccess)
+            return EMIP_E_LAUNCH;
+    }
+    const dim3 grid((unsigned)a.qblocks, (unsigned)nwin, (unsigned)B);
+    if (gid)
+        hipLaunchKernelGGL((wattn_kernel<true, true>), grid, dim3(512), WA_LDS_MERGE, (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL((wattn_kernel<false, true>), grid, dim3(512), WA_LDS_MERGE, (hipStream_t)stream, a);
     return emip_launch_status();
 }

@@ -47,7 +47,8 @@ class TransformerLayer(EmipModule):
         def build(q, k, v, m, g, b):
             return dict(qkv=torch.cat([q, k, v], 0).detach().to(dt).contiguous(), q=pack_linear(q, dt),
                         kv=torch.cat([k, v], 0).detach().to(dt).contiguous(), merge=pack_linear(m, dt),
-                        n1=(f32(g), f32(b)))
+                        n1=(f32(g), f32(b)),
+                        mfrag=(ops.wattn_merge_pack(m, dt) if (dt == torch.bfloat16 and tuple(m.shape) == (128, 128)) else None))
         w = self.packed("attn", (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.merge.weight,
                                  self.norm1.weight, self.norm1.bias), build)
         if not self.no_ffn:
@@ -105,6 +106,7 @@ def _window_attention(q, k, v, B2, h, w, C, ldq, ldk, ldv, shift, splits, kv_rot
     return out
 
 
+WATTN_MERGE = True      # emip_window_attention_merge: attention + merge + norm1 (+ residual) in one launch (bf16 inference)
 FFN_BLOCK = True        # emip_ffn_block: mlp[0] + GELU + mlp[2] + norm2 + residual in one launch (bf16 inference)
 
 
@@ -161,13 +163,25 @@ class FeatureTransformer(EmipModule):
             ck, cv, ldc5, rot = big[..., 3 * C:], big[..., 4 * C:], 5 * C, B
             ldb = big.shape[-1]
             # ---- self attention (no FFN): c0 += LN(merge(attn))
-            msg = _window_attention(big, big[..., C:], big[..., 2 * C:], B2, h, w, C, ldb, ldb, ldb, shift,
-                                    attn_num_splits)
-            ops.gemm_ln_out(msg, ws["merge"], ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, res=c0, out=c0)  # c0 += LN(merge)
+            fused = WATTN_MERGE and ws.get("mfrag") is not None and 64 <= (h // attn_num_splits) * (w // attn_num_splits) <= 512
+            if fused:      # attention + merge + norm1 + residual in one launch: c0 += LN(merge(attn))
+                rows_t, gid_t = window_tables(h, w, attn_num_splits, shift, c0.device)
+                ops.window_attention_merge(big[..., :C], big[..., C:2 * C], big[..., 2 * C:3 * C], c0, rows_t,
+                                           gid_t if shift else None, n, C ** -0.5, ws["mfrag"], ws["n1"][0], ws["n1"][1],
+                                           blk.self_attn.norm1.eps, res=c0)
+            else:
+                msg = _window_attention(big, big[..., C:], big[..., 2 * C:], B2, h, w, C, ldb, ldb, ldb, shift,
+                                        attn_num_splits)
+                ops.gemm_ln_out(msg, ws["merge"], ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, res=c0, out=c0)  # c0 += LN(merge)
             # ---- cross attention + FFN
             q = ops.gemm(c0, wc["q"])
-            msg = _window_attention(q, ck, cv, B2, h, w, C, C, ldc5, ldc5, shift, attn_num_splits, kv_rot=rot)
-            msg = ops.gemm_ln_out(msg, wc["merge"], wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps)
+            if fused and wc.get("mfrag") is not None:      # msg = LN(merge(cross attention)), one launch
+                msg = torch.empty((B2, n, C), dtype=dt, device=c0.device)
+                ops.window_attention_merge(q, ck[..., :C], cv[..., :C], msg, rows_t, gid_t if shift else None, n, C ** -0.5,
+                                           wc["mfrag"], wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps, kv_rot=rot)
+            else:
+                msg = _window_attention(q, ck, cv, B2, h, w, C, C, ldc5, ldc5, shift, attn_num_splits, kv_rot=rot)
+                msg = ops.gemm_ln_out(msg, wc["merge"], wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps)
             if FFN_BLOCK and wc.get("ffn") is not None:      # the whole FFN in one launch: the 1024-wide hidden tensor stays on the CU
                 ops.ffn_block(c0, msg, wc["ffn"][0], wc["ffn"][1], wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps,
                               res=c0, out=c0)

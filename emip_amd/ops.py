@@ -536,6 +536,31 @@ def window_attention(q, k, v, out, rows, gid, tokens, scale, kv_rot=0, lse=None)
     return out
 
 
+def wattn_merge_pack(wm, dtype=torch.bfloat16):
+    """merge.weight [128, 128] in the fragment order of emip_window_attention_merge: [row tile dd][k-step ks = 2 d + sp][h][r][j] =
+    Wm[32 dd + r][32 d + 16 sp + 8 (j >> 2) + 4 h + (j & 3)] (the channel the attention accumulator register 8 sp + j of tile d holds)"""
+    assert tuple(wm.shape) == (128, 128)
+    d, sp, h, j = torch.meshgrid(torch.arange(4), torch.arange(2), torch.arange(2), torch.arange(8), indexing="ij")
+    ch = (32 * d + 16 * sp + 8 * (j >> 2) + 4 * h + (j & 3)).to(wm.device)               # [d][sp][h][j]
+    w = wm.detach().to(dtype).view(4, 32, 128)[:, :, ch]                                  # [dd][r][d][sp][h][j]
+    return w.permute(0, 2, 3, 4, 1, 5).contiguous().view(-1)                              # [dd][d][sp][h][r][j]
+
+
+def window_attention_merge(q, k, v, out, rows, gid, tokens, scale, wm_pack, gamma, beta, eps, res=None, kv_rot=0):
+    """emip_window_attention_merge: out = res + LayerNorm(merge(window attention)) * gamma + beta, one launch"""
+    _dev(q)
+    B = q.shape[0]
+    nwin, L = rows.shape
+    assert q.dtype == k.dtype == v.dtype == out.dtype == torch.bfloat16 and rows.dtype == torch.int32 and rows.is_contiguous()
+    for t in (q, k, v, out) + ((res,) if res is not None else ()):
+        assert t.dim() == 3 and t.shape[0] == B and t.shape[1] == tokens and t.stride(2) == 1
+    _lib.call("emip_window_attention_merge", _p(q), _p(k), _p(v), _p(out), B, nwin, L, q.stride(1), k.stride(1), v.stride(1),
+              out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0), _p(rows), _p(gid), int(tokens), int(kv_rot),
+              float(scale), _p(wm_pack), _p(gamma), _p(beta), float(eps), _p(res), res.stride(1) if res is not None else 0,
+              res.stride(0) if res is not None else 0, _stream())
+    return out
+
+
 def window_attention_bwd(q, k, v, out, dout, lse, rows, gid, tokens, scale, kv_rot=0):
     """emip_window_attention_bwd -> (dq, dk, dv) bf16 [B, tokens, 128]; out / dout contiguous, q / k / v may be column slices"""
     _dev(q)

@@ -82,3 +82,38 @@ def test_window_attention_backward(B2, shift, rot, hw):
         e = (got.float() - want).abs().max().item() / (want.abs().max().item() + 1e-9)
         print(f"  B2={B2} shift={shift} rot={rot} hw={hw} {name}: rel {e:.4f}")
         assert e < 2.5e-2, (name, e)
+
+
+@pytest.mark.parametrize("B2,shift,rot,residual", [(4, False, 0, True), (4, True, 2, False), (32, True, 0, True)])
+def test_window_attention_with_merge_norm_residual(B2, shift, rot, residual):
+    """emip_window_attention_merge: attention + merge Linear + norm1 (+ residual) in one launch (transformer.py:330-338) against
+    the two launches it replaces and the f32 evaluation"""
+    import torch.nn.functional as F
+    from emip_amd import ops
+    from emip_amd.model.EMIP_short.motion.gmflow.tables import window_tables
+    h = w = 44
+    n, C = h * w, 128
+    g = torch.Generator().manual_seed(100 + B2 + rot)
+    big = (torch.randn(B2, n, 5 * C, generator=g) * 1.5).cuda().to(torch.bfloat16)
+    q, k, v = big[..., :C], big[..., 3 * C:4 * C], big[..., 4 * C:]
+    c0 = (torch.randn(B2, n, C, generator=g)).cuda().to(torch.bfloat16)
+    wm = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    gamma = (1 + 0.1 * torch.randn(C, generator=g)).cuda()
+    beta = (0.1 * torch.randn(C, generator=g)).cuda()
+    rows, gid = window_tables(h, w, 2, shift, big.device)
+    gm = gid if shift else None
+    att = torch.empty((B2, n, C), dtype=torch.bfloat16, device="cuda")
+    ops.window_attention(q, k, v, att, rows, gm, n, C ** -0.5, rot)
+    two = ops.gemm_ln_out(att, wm.to(torch.bfloat16).contiguous(), gamma, beta, 1e-5, res=c0 if residual else None)
+    ref = F.layer_norm(_reference(q, k, v, rows, gm, rot, C ** -0.5).to(torch.bfloat16).float() @ wm.to(torch.bfloat16).float().t(),
+                       (C,), gamma, beta, 1e-5)
+    if residual:
+        ref = ref + c0.float()
+    out = c0.clone() if residual else torch.empty_like(c0)
+    ops.window_attention_merge(q, k, v, out, rows, gm, n, C ** -0.5, ops.wattn_merge_pack(wm), gamma, beta, 1e-5,
+                               res=out if residual else None, kv_rot=rot)
+    torch.cuda.synchronize()
+    scale = max(1.0, ref.abs().max().item())
+    e_ref, e_two = (out.float() - ref).abs().max().item(), (out.float() - two.float()).abs().max().item()
+    print(f"  B2={B2} shift={shift} rot={rot}: vs PyTorch {e_ref:.4f}, vs the two launches {e_two:.4f} (values up to {scale:.1f})")
+    assert e_ref < 4e-2 * scale and e_two < 4e-2 * scale
