@@ -74,6 +74,15 @@ def _launch_info(lib, name, a):
     if name == "emip_window_attention":   # (Q, K, V, O, B, nwin, L, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, rows, gid, tokens, rot, scale, stream)
         Bf, nwin, L = a[4], a[5], a[6]
         return 4.0 * Bf * nwin * L * L * 128, "wattn_kernel", 2.0 * Bf * nwin * L * 128 * 4
+    if name == "emip_window_attention_merge":   # the same arguments, then (Wm, gamma, beta, eps, Res, ldr, r_bs, stream)
+        Bf, nwin, L = a[4], a[5], a[6]
+        rows_ = Bf * nwin * L
+        return (4.0 * Bf * nwin * L * L * 128 + 2.0 * rows_ * 128 * 128, "wattn_kernel",
+                2.0 * rows_ * 128 * (4 + (1 if a[24] else 0)) + 2.0 * 128 * 128)
+    if name == "emip_ffn_block":          # (X1, ld1, X2, ld2, W0p, W2p, gamma, beta, eps, Res, ldr, Out, ldo, M, stream)
+        M = a[13]
+        return (2.0 * M * (1024 * 256 + 128 * 1024), "ffn_block_kernel",
+                2.0 * M * 128 * (3 + (1 if a[9] else 0)) + 2.0 * (1024 * 256 + 128 * 1024))
     if name == "emip_match":              # (Q, K, V, S, Out, Z, Zs, n, W, ldq, ldk, q_bs, k_bs, rot, scale, sub, stream)
         Z, Zs, n = a[5], a[6], a[7]
         # features in once as queries and once as keys, the raw correlation of the forward direction out once, flows out
@@ -840,8 +849,12 @@ def main():
                                         "q projection + attention per (image, 128 queries, head), the proj GEMM separate: the "
                                         "22x22 stage below 12 000 token rows per launch (emip_sra_qattn)"),
             "window_attention": named_roofline(agg, "wattn_kernel",
-                                               "GMFlow split-window attention, 2 x 2 windows of 484 tokens, D = 128, "
-                                               "gmflow/transformer.py:46-105 (emip_window_attention)"),
+                                               "GMFlow split-window attention, 2 x 2 windows of 484 tokens, D = 128, with the "
+                                               "layer's merge Linear + norm1 + residual in the epilogue, "
+                                               "gmflow/transformer.py:46-105,330-338 (emip_window_attention_merge)"),
+            "ffn": named_roofline(agg, "ffn_block_kernel",
+                                  "GMFlow FFN: mlp[0] + GELU + mlp[2] + norm2 + residual in one launch, hidden tensor on the CU "
+                                  "only, gmflow/transformer.py:316-345 (emip_ffn_block)"),
             "sra_attention_only": named_roofline(agg, "sra_kernel",
                                                  "softmax(q k^T / 8) v alone (the 11x11 stage, sr_ratio 1), lib/pvt_v2.py:113-125"),
             "correlation": named_roofline(agg, "match_kernel+scores",
