@@ -45,6 +45,7 @@ struct WaArgs {
     bf16_t* O;
     float* lse;            // [B][tokens] log2-sum-exp of the scaled, masked scores (training forward) or null
     const bf16_t* Wm;      // MERGE: merge.weight [128][128] in fragment order (ops.wattn_merge_pack)
+    const bf16_t* Wq;      // QP: q_proj.weight [128][128] in fragment order, rows bit-swapped (ops.wattn_q_pack); Q = the token rows
     const float* gamma;    // MERGE: norm1 weight / bias, f32 [128]
     const float* beta;
     const bf16_t* Res;     // MERGE: residual tokens (may alias O) or null
@@ -74,7 +75,7 @@ constexpr int WA_WM = 32 * 1024, WA_LDS_MERGE = WA_LDS + WA_WM + 2 * 128 * 4;   
 
 __device__ __forceinline__ int wa_voff(int row, int c) { return row * 256 + ((c ^ ((row & 3) << 2)) * 16); }
 
-template <bool MASK, bool MERGE = false>
+template <bool MASK, bool MERGE = false, bool QP = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void wattn_kernel(const WaArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -130,8 +131,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void w
         }
     };
     const int ntile = (p.L + WA_BK - 1) / WA_BK;
+    if (QP) {
+        // the q projection weight rides in ring slot 2 (free until the first loop barrier has passed, i.e. until every wave has
+        // left this prologue): 32 fragment pieces, 4 per wave, issued ahead of tiles 0 and 1
+        const i32x4 rsQ = wa_rsrc(p.Wq, 32768u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            wa_dma16(lds0 + 2 * WA_STAGE + (4 * wave + j) * 1024, (unsigned)((4 * wave + j) * 1024 + lane * 16), rsQ);
+    }
     issue(0);
     if (ntile > 1) issue(1);
+    if (QP) {
+        // Q^T = Wq X^T with the query on the lane; the weight rows are stored with bits 2 and 3 of their index swapped inside every
+        // 16, so registers 8 sp .. 8 sp + 7 of tile dd hold channels 32 dd + 16 sp + 8 h .. + 7: the B fragment 2 dd + sp of S^T
+        if (ntile > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // all but the pieces of tiles 0 and 1
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const char* wq = smem + 2 * WA_STAGE;
+        uint4 xq[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) xq[i] = qf[i];
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            f32x16 qa;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) qa[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                const uint4 wf = *reinterpret_cast<const uint4*>(wq + (dd * 8 + ks) * 1024 + lane * 16);
+                qa = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xq[ks]), qa, 0, 0, 0);
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                bf16x8 t;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = (bf16_t)qa[8 * sp + j];
+                qf[2 * dd + sp] = __builtin_bit_cast(uint4, t);
+            }
+        }
+    }
 
     f32x16 oacc[4];
 #pragma unroll
@@ -374,12 +413,14 @@ extern "C" int emip_window_attention(const void* Q, const void* K, const void* V
 // The same followed, in the launch, by the layer's merge Linear, norm1 and the residual (gmflow/transformer.py:330-338: message =
 // norm1(merge(attention)), then `source + message` for the layer without FFN): O = Res + LayerNorm(attention Wm^T) * gamma + beta.
 // Wm: merge.weight [128][128] in fragment order (emip_amd.ops.wattn_merge_pack); Res: NULL or the residual tokens (row stride ldr,
-// batch stride r_bs; may alias O when Q is not a view of O's rows).
+// batch stride r_bs; may alias O when Q is not a view of O's rows).  Wq: NULL, or q_proj.weight [128][128] in fragment order with
+// bit-swapped rows (emip_amd.ops.wattn_q_pack): Q then points at the TOKEN rows and the q projection runs in the launch's prologue
+// (a wave reads the rows of its own 32 queries only, so Q may be O's buffer).
 extern "C" int emip_window_attention_merge(const void* Q, const void* K, const void* V, void* O, int B, int nwin, int L, long ldq,
                                            long ldk, long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs,
                                            const int* rows, const int* gid, int tokens, int kv_rot, float scale, const void* Wm,
                                            const float* gamma, const float* beta, float eps, const void* Res, long ldr, long r_bs,
-                                           void* stream) {
+                                           const void* Wq, void* stream) {
     EMIP_REQUIRE(Q && K && V && O && rows && Wm && gamma && beta && eps > 0.f && B > 0 && nwin > 0 && L >= WA_BK && L <= WA_LMAX && tokens >= L);
     EMIP_REQUIRE(B < 65536 && nwin < 65536 && kv_rot >= 0 && kv_rot < B);
     EMIP_REQUIRE(ldq >= 128 && ldk >= 128 && ldv >= 128 && ldo >= 128 && ((ldq | ldk | ldv) & 7) == 0 && (ldo & 3) == 0);
@@ -395,7 +436,7 @@ extern "C" int emip_window_attention_merge(const void* Q, const void* K, const v
     a.qblocks = (L + 255) / 256;
     a.k_bytes = (unsigned)(((long)(tokens - 1) * ldk + 128) * 2);
     a.v_bytes = (unsigned)(((long)(tokens - 1) * ldv + 128) * 2);
-    a.Wm = (const bf16_t*)Wm; a.gamma = gamma; a.beta = beta; a.eps = eps; a.Res = (const bf16_t*)Res; a.ldr = ldr; a.r_bs = r_bs;
+    a.Wq = (const bf16_t*)Wq; a.Wm = (const bf16_t*)Wm; a.gamma = gamma; a.beta = beta; a.eps = eps; a.Res = (const bf16_t*)Res; a.ldr = ldr; a.r_bs = r_bs;
 #ifdef EMIP_TUNING
     a.skip = 0;
 #endif
@@ -403,13 +444,19 @@ extern "C" int emip_window_attention_merge(const void* Q, const void* K, const v
     if (!attr) {
         attr = true;
         if (hipFuncSetAttribute((const void*)wattn_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS_MERGE) != hipSuccess ||
-            hipFuncSetAttribute((const void*)wattn_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS_MERGE) != hipSuccess)
+            hipFuncSetAttribute((const void*)wattn_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS_MERGE) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wattn_kernel<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS_MERGE) != hipSuccess ||
+            hipFuncSetAttribute((const void*)wattn_kernel<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WA_LDS_MERGE) != hipSuccess)
             return EMIP_E_LAUNCH;
     }
+    EMIP_REQUIRE(!Wq || (aligned16(Wq) && L > 2 * WA_BK));      // (the weight rides in ring slot 2: at least three key tiles)
     const dim3 grid((unsigned)a.qblocks, (unsigned)nwin, (unsigned)B);
-    if (gid)
-        hipLaunchKernelGGL((wattn_kernel<true, true>), grid, dim3(512), WA_LDS_MERGE, (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((wattn_kernel<false, true>), grid, dim3(512), WA_LDS_MERGE, (hipStream_t)stream, a);
+    if (Wq) {
+        if (gid) hipLaunchKernelGGL((wattn_kernel<true, true, true>), grid, dim3(512), WA_LDS_MERGE, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((wattn_kernel<false, true, true>), grid, dim3(512), WA_LDS_MERGE, (hipStream_t)stream, a);
+    } else {
+        if (gid) hipLaunchKernelGGL((wattn_kernel<true, true>), grid, dim3(512), WA_LDS_MERGE, (hipStream_t)stream, a);
+        else hipLaunchKernelGGL((wattn_kernel<false, true>), grid, dim3(512), WA_LDS_MERGE, (hipStream_t)stream, a);
+    }
     return emip_launch_status();
 }

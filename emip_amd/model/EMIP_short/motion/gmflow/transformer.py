@@ -48,7 +48,8 @@ class TransformerLayer(EmipModule):
             return dict(qkv=torch.cat([q, k, v], 0).detach().to(dt).contiguous(), q=pack_linear(q, dt),
                         kv=torch.cat([k, v], 0).detach().to(dt).contiguous(), merge=pack_linear(m, dt),
                         n1=(f32(g), f32(b)),
-                        mfrag=(ops.wattn_merge_pack(m, dt) if (dt == torch.bfloat16 and tuple(m.shape) == (128, 128)) else None))
+                        mfrag=(ops.wattn_merge_pack(m, dt) if (dt == torch.bfloat16 and tuple(m.shape) == (128, 128)) else None),
+                        qfrag=(ops.wattn_q_pack(q, dt) if (dt == torch.bfloat16 and tuple(q.shape) == (128, 128)) else None))
         w = self.packed("attn", (self.q_proj.weight, self.k_proj.weight, self.v_proj.weight, self.merge.weight,
                                  self.norm1.weight, self.norm1.bias), build)
         if not self.no_ffn:
@@ -83,6 +84,14 @@ class TransformerBlock(EmipModule):
         return self.packed("in5", (sa.q_proj.weight, sa.k_proj.weight, sa.v_proj.weight, ca.k_proj.weight, ca.v_proj.weight),
                            lambda *ws_: torch.cat([t.detach() for t in ws_], 0).to(dt).contiguous())
 
+    def fused_in4(self):
+        """[k | v of the self attention | k | v of the cross attention] as one [4C, C] weight: the form used when both q projections
+        run inside their attention launches (emip_window_attention_merge with wq_pack)"""
+        dt = self.cdtype
+        sa, ca = self.self_attn, self.cross_attn_ffn
+        return self.packed("in4", (sa.k_proj.weight, sa.v_proj.weight, ca.k_proj.weight, ca.v_proj.weight),
+                           lambda *ws_: torch.cat([t.detach() for t in ws_], 0).to(dt).contiguous())
+
     def __init__(self, d_model=256, nhead=1, attention_type='swin', ffn_dim_expansion=4, with_shift=False, **kw):
         super().__init__()
         self.self_attn = TransformerLayer(d_model, nhead, attention_type, no_ffn=True,
@@ -106,6 +115,7 @@ def _window_attention(q, k, v, B2, h, w, C, ldq, ldk, ldv, shift, splits, kv_rot
     return out
 
 
+WATTN_QPROJ = True      # ... and the q projection in its prologue (the fused input GEMM then makes k | v | k' | v' only)
 WATTN_MERGE = True      # emip_window_attention_merge: attention + merge + norm1 (+ residual) in one launch (bf16 inference)
 FFN_BLOCK = True        # emip_ffn_block: mlp[0] + GELU + mlp[2] + norm2 + residual in one launch (bf16 inference)
 
@@ -159,11 +169,28 @@ class FeatureTransformer(EmipModule):
             shift = blk.self_attn.with_shift
             # one GEMM: q | k | v of the self attention and k | v of the cross attention, whose source is the OTHER frame as it
             # is at block start -- read in place from the other half of the batch (kv_rot = B)
+            fused = WATTN_MERGE and ws.get("mfrag") is not None and 64 <= (h // attn_num_splits) * (w // attn_num_splits) <= 512
+            qin = fused and WATTN_QPROJ and ws.get("qfrag") is not None and wc.get("qfrag") is not None and wc.get("mfrag") is not None \
+                and (h // attn_num_splits) * (w // attn_num_splits) > 128
+            if qin:
+                # both q projections run in the prologue of their attention launch: k | v | k' | v' only
+                big = ops.gemm(c0, blk.fused_in4())                              # [2B, n, 4C]
+                rows_t, gid_t = window_tables(h, w, attn_num_splits, shift, c0.device)
+                gm = gid_t if shift else None
+                ops.window_attention_merge(c0, big[..., :C], big[..., C:2 * C], c0, rows_t, gm, n, C ** -0.5, ws["mfrag"],
+                                           ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, res=c0, wq_pack=ws["qfrag"])
+                msg = torch.empty((B2, n, C), dtype=dt, device=c0.device)
+                ops.window_attention_merge(c0, big[..., 2 * C:3 * C], big[..., 3 * C:], msg, rows_t, gm, n, C ** -0.5, wc["mfrag"],
+                                           wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps, kv_rot=B, wq_pack=wc["qfrag"])
+                ops.ffn_block(c0, msg, wc["ffn"][0], wc["ffn"][1], wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps,
+                              res=c0, out=c0) if (FFN_BLOCK and wc.get("ffn") is not None) else ops.gemm_ln_out(
+                    ops.gemm(c0, wc["m0"], a2=msg, act=ops.ACT_GELU), wc["m2"], wc["n2"][0], wc["n2"][1],
+                    blk.cross_attn_ffn.norm2.eps, res=c0, out=c0)
+                continue
             big = ops.gemm(c0, blk.fused_in())                                   # [2B, n, 5C]
             ck, cv, ldc5, rot = big[..., 3 * C:], big[..., 4 * C:], 5 * C, B
             ldb = big.shape[-1]
             # ---- self attention (no FFN): c0 += LN(merge(attn))
-            fused = WATTN_MERGE and ws.get("mfrag") is not None and 64 <= (h // attn_num_splits) * (w // attn_num_splits) <= 512
             if fused:      # attention + merge + norm1 + residual in one launch: c0 += LN(merge(attn))
                 rows_t, gid_t = window_tables(h, w, attn_num_splits, shift, c0.device)
                 ops.window_attention_merge(big[..., :C], big[..., C:2 * C], big[..., 2 * C:3 * C], c0, rows_t,

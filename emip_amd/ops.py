@@ -546,8 +546,20 @@ def wattn_merge_pack(wm, dtype=torch.bfloat16):
     return w.permute(0, 2, 3, 4, 1, 5).contiguous().view(-1)                              # [dd][d][sp][h][r][j]
 
 
-def window_attention_merge(q, k, v, out, rows, gid, tokens, scale, wm_pack, gamma, beta, eps, res=None, kv_rot=0):
-    """emip_window_attention_merge: out = res + LayerNorm(merge(window attention)) * gamma + beta, one launch"""
+def wattn_q_pack(wq, dtype=torch.bfloat16):
+    """q_proj.weight [128, 128] for the prologue of emip_window_attention_merge: [row tile dd][k-step ks][h][rho][j] =
+    Wq[32 dd + swap23(rho)][16 ks + 8 h + j]; with bits 2 and 3 of the row index swapped inside every 16 the accumulator registers
+    of Q^T = Wq X^T come out in the channel order an MFMA B fragment wants"""
+    assert tuple(wq.shape) == (128, 128)
+    rho = torch.arange(32)
+    src = ((rho & ~12) | ((rho & 4) << 1) | ((rho & 8) >> 1)).to(wq.device)
+    w = wq.detach().to(dtype).view(4, 32, 8, 2, 8)[:, src]                               # [dd][rho][ks][h][j]
+    return w.permute(0, 2, 3, 1, 4).contiguous().view(-1)                                # [dd][ks][h][rho][j]
+
+
+def window_attention_merge(q, k, v, out, rows, gid, tokens, scale, wm_pack, gamma, beta, eps, res=None, kv_rot=0, wq_pack=None):
+    """emip_window_attention_merge: out = res + LayerNorm(merge(window attention)) * gamma + beta, one launch; wq_pack: q is the
+    token matrix and the q projection runs in the launch too"""
     _dev(q)
     B = q.shape[0]
     nwin, L = rows.shape
@@ -557,7 +569,7 @@ def window_attention_merge(q, k, v, out, rows, gid, tokens, scale, wm_pack, gamm
     _lib.call("emip_window_attention_merge", _p(q), _p(k), _p(v), _p(out), B, nwin, L, q.stride(1), k.stride(1), v.stride(1),
               out.stride(1), q.stride(0), k.stride(0), v.stride(0), out.stride(0), _p(rows), _p(gid), int(tokens), int(kv_rot),
               float(scale), _p(wm_pack), _p(gamma), _p(beta), float(eps), _p(res), res.stride(1) if res is not None else 0,
-              res.stride(0) if res is not None else 0, _stream())
+              res.stride(0) if res is not None else 0, _p(wq_pack), _stream())
     return out
 
 

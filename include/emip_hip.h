@@ -278,11 +278,12 @@ int emip_window_attention(const void* Q, const void* K, const void* V, void* O, 
 
 /* emip_window_attention followed IN THE LAUNCH by the layer's merge Linear, norm1 and the residual (gmflow/transformer.py:330-338):
  * O = Res + LayerNorm(attention Wm^T) * gamma + beta; the attention output never reaches memory.  Wm: merge.weight [128][128] in
- * MFMA-fragment order (emip_amd.ops.wattn_merge_pack); Res NULL or the residual tokens (may be O itself). */
+ * MFMA-fragment order (emip_amd.ops.wattn_merge_pack); Res NULL or the residual tokens (may be O itself).  Wq: NULL, or q_proj.weight
+ * in fragment order (emip_amd.ops.wattn_q_pack): Q then points at the token rows and q = tokens Wq^T is computed in the prologue. */
 int emip_window_attention_merge(const void* Q, const void* K, const void* V, void* O, int B, int nwin, int L, long ldq, long ldk,
                                 long ldv, long ldo, long q_bs, long k_bs, long v_bs, long o_bs, const int* rows, const int* gid,
                                 int tokens, int kv_rot, float scale, const void* Wm, const float* gamma, const float* beta,
-                                float eps, const void* Res, long ldr, long r_bs, void* stream);
+                                float eps, const void* Res, long ldr, long r_bs, const void* Wq, void* stream);
 
 /* Backward of emip_window_attention in three launches (train.py:52-58 through transformer.py:46-105; GMFlow is frozen,
  * train.py:340-342, only the token gradients exist): delta = rowsum(dO o O); dQ with the queries stationary; dK, dV with the keys

@@ -117,3 +117,17 @@ def test_window_attention_with_merge_norm_residual(B2, shift, rot, residual):
     e_ref, e_two = (out.float() - ref).abs().max().item(), (out.float() - two.float()).abs().max().item()
     print(f"  B2={B2} shift={shift} rot={rot}: vs PyTorch {e_ref:.4f}, vs the two launches {e_two:.4f} (values up to {scale:.1f})")
     assert e_ref < 4e-2 * scale and e_two < 4e-2 * scale
+    # the q projection in the launch too: q = tokens Wq^T computed in the prologue from the (residual) token rows
+    wq = (torch.randn(C, C, generator=g) / C ** 0.5).cuda()
+    toks = c0.clone()
+    qq = ops.gemm(toks, wq.to(torch.bfloat16).contiguous())
+    want = torch.empty_like(c0)
+    ops.window_attention_merge(qq, k, v, want, rows, gm, n, C ** -0.5, ops.wattn_merge_pack(wm), gamma, beta, 1e-5,
+                               res=toks if residual else None, kv_rot=rot)
+    got = toks.clone()
+    ops.window_attention_merge(got, k, v, got, rows, gm, n, C ** -0.5, ops.wattn_merge_pack(wm), gamma, beta, 1e-5,
+                               res=got if residual else None, kv_rot=rot, wq_pack=ops.wattn_q_pack(wq))
+    torch.cuda.synchronize()
+    e_q = (got.float() - want.float()).abs().max().item()
+    print(f"     with the q projection in the prologue: vs the separate q GEMM {e_q:.4f}")
+    assert e_q < 4e-2 * max(1.0, want.float().abs().max().item())
