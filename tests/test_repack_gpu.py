@@ -179,15 +179,43 @@ def _bf16_train_grads(model_args, short_sd, B, defer, arena, seed=7):
 
 
 def test_bf16_deferred_weight_gradients_equal_the_immediate_ones(model_args, short_sd):
-    """bf16, batch 2 (the default training path: gradient arena, grouped deferred weight gradients, padded GDFN width):
-    EVERY parameter gradient with deferral equals the one without it up to the run-to-run noise of the bf16 path, no
-    trainable gradient that the plain path produces is missing or all zero, and nothing needed a fix-up (every deferred
-    result was the parameter's .grad)."""
-    from emip_amd import ops
+    """bf16, batch 2 (the default training path: gradient arena, grouped deferred weight gradients, padded GDFN width).
+    1. The mechanism, free of the model's conditioning: every problem the step deferred is recomputed by the immediate launch
+       from the SAME operands right behind the grouped launch and equals its arena slice to f32 summation order.
+    2. Book-keeping: nothing needed a fix-up (every deferred result IS its parameter's .grad), no gradient the plain path
+       produces is missing or all zero.
+    3. The whole step: every parameter gradient has the plain path's value up to the repeatability of the bf16 step.  That
+       repeatability is coarse and bimodal: the f32 atomics of the forward (MDTA Gram, statistics) differ in the last bit from
+       run to run, one bf16 rounding falls the other way about one run in three, and the random-weight GMFlow amplifies it
+       (tools/dbg_trace.py finds the first differing launch, tools/dbg_defer.py shows 5-10 % run to run on backbone norm
+       gradients even over ONE retained forward).  So the bound per tensor is the magnitude (a result in the wrong slice or a
+       lost term is O(1) off) and the bound on the median over all tensors is the measured noise."""
+    from emip_amd import _lib, ops
     plain, req = _bf16_train_grads(model_args, short_sd, 2, defer=False, arena=False)
     plain2, _ = _bf16_train_grads(model_args, short_sd, 2, defer=False, arena=True)
     ops.WGRADS.fixed = 0
-    got, _ = _bf16_train_grads(model_args, short_sd, 2, defer=True, arena=True)
+    checked = []
+    real_flush = ops.WgradQueue.flush
+
+    def checking_flush():
+        items = list(ops.WGRADS.items)
+        real_flush(ops.WGRADS)
+        for a, b, c, db, M, N, K, lda, ldb in items:
+            c2 = torch.zeros_like(c)
+            db2 = torch.zeros_like(db) if db is not None else None
+            _lib.call("emip_gemm_tn_into", ops._p(a), ops._p(b), ops._p(c2), ops._p(db2), M, N, K, lda, ldb, K,
+                      ops.dt_code(a.dtype), ops._stream())
+            checked.append(((c - c2).abs().max().item() / (c2.abs().max().item() + 1e-30), (M, N, K)))
+            if db is not None:
+                checked.append(((db - db2).abs().max().item() / (db2.abs().max().item() + 1e-30), (M, N, 0)))
+    ops.WGRADS.flush = checking_flush
+    try:
+        got, _ = _bf16_train_grads(model_args, short_sd, 2, defer=True, arena=True)
+    finally:
+        del ops.WGRADS.flush
+    assert len(checked) >= 100, len(checked)                # both passes' eligible Linear layers (backbone, GMFlow, feeders)
+    print("  deferred problems recomputed by the immediate launch: %d, worst %r" % (len(checked), max(checked)))
+    assert max(checked)[0] <= 2e-4, sorted(checked, reverse=True)[:4]
     assert ops.WGRADS.fixed == 0 and not ops.WGRADS.owners and not ops.WGRADS.items
     assert set(got) == set(plain) == set(plain2)
     zero = [n for n in got if not got[n].any() and plain[n].any()]
@@ -198,9 +226,20 @@ def test_bf16_deferred_weight_gradients_equal_the_immediate_ones(model_args, sho
     def rel(a, b):
         return {n: ((a[n] - b[n]).abs().max() / (b[n].abs().max() + 1e-30)).item() for n in b}
     noise, dev = rel(plain2, plain), rel(got, plain)
-    worst = sorted(((dev[n] / (4.0 * noise[n] + 2e-2), dev[n], noise[n], n) for n in plain), reverse=True)[:3]
-    print("  largest deferred-vs-immediate deviations (ratio to the bound, deviation, run-to-run noise, name):", worst)
-    assert all(dev[n] <= 4.0 * noise[n] + 2e-2 for n in plain), worst
+    # `injector.*` receives gradient through the flow loss and the random-weight GMFlow only (cosine 0.2-0.4 against the f32
+    # mode for EVERY variant of the backward: tools/dbg_wattn_grad.py); a bias in front of a normalisation has a zero true gradient
+    chaotic = {n for n in plain if n.startswith("injector.") or plain[n].abs().max() < 1e-6 * max(v.abs().max() for v in plain.values())}
+    chaotic |= {n for n in plain if n.endswith(".bias") and noise[n] > 0.5}
+    steady = sorted(n for n in plain if n not in chaotic)
+    med = lambda d: sorted(d[n] for n in steady)[len(steady) // 2]
+    worst = sorted(((dev[n], noise[n], n) for n in steady), reverse=True)[:3]
+    print("  deferred vs immediate: median deviation %.3g (run-to-run median %.3g); largest (deviation, noise, name): %r"
+          % (med(dev), med(noise), worst))
+    assert med(dev) <= 4.0 * med(noise) + 2e-2, (med(dev), med(noise))
+    assert all(dev[n] <= max(4.0 * noise[n] + 2e-2, 0.5) for n in steady), worst
+    for n in chaotic:
+        a, b = got[n].norm().item(), plain[n].norm().item()
+        assert torch.isfinite(got[n]).all() and (b == 0 or (a > 0 and 0.1 * b <= a <= 10.0 * b)), (n, a, b)
 
 
 def test_deferred_result_of_a_weight_used_twice_is_fixed_up():
