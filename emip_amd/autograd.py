@@ -18,6 +18,16 @@ def colsum_f32(dy):
     return ops.colsum(dy)
 
 
+def conv_weight_grad(dy, x, weight, k, s, p, cin_pad=None):
+    """the weight gradient of a k x k convolution in the parameter's [Cout, Cin, k, k] layout; inside a training step the
+    contraction joins the step's grouped weight-gradient launch where it is eligible (ops.conv2d_wgrad)"""
+    cout, cin = weight.shape[0], weight.shape[1]
+    cp = cin_pad or cin
+    lazy = lambda t: t.view(cout, k, k, cp)[..., :cin].permute(0, 3, 1, 2)        # strided view: fixup() adds it in one pass
+    dwp, g = ops.conv2d_wgrad(dy, x, k, k, s, p, defer_to=(weight if weight.is_leaf else None, lazy))
+    return g if g is not None else unpack_conv_grad(dwp, cout, cin, k, cin_pad)
+
+
 def unpack_conv_grad(dw_packed, cout, cin, k, cin_pad=None, perm=None):
     """[Cout, k*k*Cin_pad] (ci fastest) -> [Cout, Cin, k, k] in the reference's parameter layout"""
     cp = cin_pad or cin
@@ -116,7 +126,7 @@ class ConvFn(Function):
                 z = ops.zero_insert(dy, H, W, s)
                 dx = ops.conv2d(z, wdg, k, k, 1, k - 1 - p)
         if ctx.needs_input_grad[1]:
-            dw = unpack_conv_grad(ops.conv2d_wgrad(dy, x, k, k, s, p), cout, cin, k, cin_pad)
+            dw = conv_weight_grad(dy, x, weight, k, s, p, cin_pad)
         if has_bias and ctx.needs_input_grad[2]:
             db = colsum_f32(dy)
         return dx, dw, db, None, None, None, None, None, None
@@ -196,7 +206,7 @@ class QSrFn(Function):
         elif has_bq and ctx.needs_input_grad[2]:
             dbq = colsum_f32(dq)
         if ctx.needs_input_grad[3]:
-            dwsr = unpack_conv_grad(ops.conv2d_wgrad(ds, h, k, k, k, 0), wsr.shape[0], wsr.shape[1], k)
+            dwsr = conv_weight_grad(ds, h, wsr, k, k, 0)
         if has_bsr and ctx.needs_input_grad[4]:
             dbsr = colsum_f32(ds)
         return dh, dwq, dbq, dwsr, dbsr, None, None, None, None, None

@@ -100,13 +100,24 @@ class WgradQueue:
 
     def __init__(self):
         self.items, self.enabled = [], True
-        self.stage = None
+        self.stage = {}
         self.owners = []                # (arena slice, parameter) of every deferred result of this step
+        self.post = []                  # (packed result, parameter, unpack): convolution gradients, added to .grad by fixup()
         self.fixed = 0                  # results fixup() had to add by hand (diagnostics / tests)
 
     def add(self, a, b, c, db, M, N, K, lda, ldb, owners=()):
-        self.items.append((a, b, c, db, M, N, K, lda, ldb))
+        # wide (256 x 320) tiles where the output shape fills them (gemm_tn16.hip), 128 x 128 otherwise (gemm_tn8.hip)
+        kind = 16 if WIDE_WGRAD and _lib.load().emip_gemm_tn16_eligible(M, N, K, lda, ldb) else 8
+        self.items.append((a, b, c, db, M, N, K, lda, ldb, kind, None))
         self.owners += [(t, p) for t, p in owners if t is not None and p is not None]
+        if len(self.items) >= self.MAX:
+            self.flush()
+
+    def add_conv(self, dy, x, dw, cv, param, unpack):
+        B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad = cv
+        Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        self.items.append((dy, x, dw, None, B * Ho * Wo, Cout, kh * kw * Cin, lddy, ldx, 16, cv))
+        self.post.append((dw, param, unpack))
         if len(self.items) >= self.MAX:
             self.flush()
 
@@ -117,11 +128,20 @@ class WgradQueue:
         sum or clone the zeros out of place, and the result would land in an orphaned slice.  Call after flush(): every
         result whose parameter's `.grad` is not the slice is added to that `.grad`.  params: restrict to these parameters
         (a gradient bucket about to leave); owners whose gradient is not assigned yet stay registered."""
-        if not self.owners:
+        if not self.owners and not self.post:
             return
         assert not self.items, "fixup() runs behind flush()"
         keep = []
         only = None if params is None else {id(p) for p in params}
+        later = []
+        for t, p, unpack in self.post:             # convolution gradients: packed [Cout][ky][kx][ci] -> the parameter's layout
+            if (only is not None and id(p) not in only) or (p.grad is None and params is not None):
+                later.append((t, p, unpack))
+                continue
+            if p.grad is None:
+                raise _lib.EmipLibraryError("a deferred weight gradient has no parameter .grad to live in")
+            p.grad.add_(unpack(t).to(p.grad.dtype))
+        self.post = later
         for t, p in self.owners:
             if only is not None and id(p) not in only:
                 keep.append((t, p))
@@ -141,31 +161,45 @@ class WgradQueue:
         if not self.items:
             return
         items, self.items = self.items, []
+        for kind in (8, 16):
+            sel = [it for it in items if it[9] == kind]
+            if sel:
+                self._launch(sel, kind)
+
+    def _launch(self, items, kind):
         lib = _lib.load()
-        rs = lib.emip_gemm_tn8_group_recsize()
+        rs = lib.emip_gemm_tn8_group_recsize() if kind == 8 else lib.emip_gemm_tn16_recsize()
         dev = items[0][0].device
         # The records go to the device through one of two pinned staging buffers and a non-blocking copy: a pageable .to()
         # is stream-ordered AND blocking, i.e. it stalls the host until the GPU has caught up (5 ms per flush, measured).
-        if self.stage is None or self.stage[0].numel() < rs * self.MAX:
-            self.stage = [torch.empty(rs * self.MAX, dtype=torch.uint8).pin_memory() for _ in range(2)]
-            self.events, self.turn = [None, None], 0
-        k = self.turn = self.turn ^ 1
-        if self.events[k] is not None:
-            self.events[k].synchronize()           # the copy that read this buffer two flushes ago (long done)
-        host = self.stage[k]
+        st = self.stage.get(kind)
+        if st is None or st[0][0].numel() < rs * self.MAX:
+            st = self.stage[kind] = [[torch.empty(rs * self.MAX, dtype=torch.uint8).pin_memory() for _ in range(2)], [None, None], 0]
+        k = st[2] = st[2] ^ 1
+        if st[1][k] is not None:
+            st[1][k].synchronize()                 # the copy that read this buffer two flushes ago (long done)
+        host = st[0][k]
         total = 0
-        for i, (a, b, c, db, M, N, K, lda, ldb) in enumerate(items):
-            n = lib.emip_gemm_tn8_group_plan(host.data_ptr() + i * rs, _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, total)
+        for i, (a, b, c, db, M, N, K, lda, ldb, _, cv) in enumerate(items):
+            rec = host.data_ptr() + i * rs
+            if kind == 8:
+                n = lib.emip_gemm_tn8_group_plan(rec, _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, total)
+            elif cv is None:
+                n = lib.emip_gemm_tn16_plan(rec, _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, total, 0)
+            else:
+                n = lib.emip_conv_wgrad16_plan(rec, _p(a), _p(b), _p(c), *cv, total, 0)
             if n <= 0:
-                raise _lib.EmipLibraryError("emip_gemm_tn8_group_plan failed for %r" % ((M, N, K, lda, ldb),))
+                raise _lib.EmipLibraryError("weight-gradient plan (%d) failed for %r" % (kind, (M, N, K, lda, ldb, cv)))
             total += n
         with torch.cuda.device(dev):
             table = torch.empty(rs * len(items), dtype=torch.uint8, device=dev)
             table.copy_(host[:rs * len(items)], non_blocking=True)
-            self.events[k] = torch.cuda.Event()
-            self.events[k].record()
-            _lib.call("emip_gemm_tn8_group", _p(table), len(items), total, _stream())
+            st[1][k] = torch.cuda.Event()
+            st[1][k].record()
+            _lib.call("emip_gemm_tn8_group" if kind == 8 else "emip_gemm_tn16_group", _p(table), len(items), total, _stream())
 
+
+WIDE_WGRAD = True      # deferred weight gradients on the 256 x 320 tiles of gemm_tn16.hip where the shape fills them (else all on gemm_tn8)
 
 WGRADS = WgradQueue()
 
@@ -988,8 +1022,11 @@ def gemm_tn_batched(a, b, batch, M, N, K, lda, ldb, bsA, bsB):
     return c
 
 
-def conv2d_wgrad(dy, x, kh, kw, stride, pad):
-    """dy [B,Ho,Wo,Cout], x [B,H,W,Cin] channels-last -> dW f32 [Cout, kh*kw*Cin] (packed like the forward weights)"""
+def conv2d_wgrad(dy, x, kh, kw, stride, pad, defer_to=None):
+    """dy [B,Ho,Wo,Cout], x [B,H,W,Cin] channels-last -> dW f32 [Cout, kh*kw*Cin] (packed like the forward weights).
+    defer_to = (parameter, unpack): the caller wants the gradient in the parameter's layout, unpack(dW) -> that layout.  Inside a
+    training step the contraction may then wait for flush_wgrads() (grouped launch); the return value is (None, zeros of the
+    parameter's shape from the arena) and WgradQueue.fixup() adds unpack(dW) to the parameter's .grad.  Otherwise (dW, None)."""
     _dev(x)
     B, H, W, Cin = x.shape
     Cout = dy.shape[-1]
@@ -997,13 +1034,20 @@ def conv2d_wgrad(dy, x, kh, kw, stride, pad):
     _, _, lddy = rows(dy)
     if ARENA.active:
         dw = grad_zeros((Cout, kh * kw * Cin), x.device)
+        if (defer_to is not None and defer_to[0] is not None and WGRADS.enabled and WIDE_WGRAD and x.dtype == torch.bfloat16
+                and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0
+                and _lib.load().emip_conv_wgrad16_eligible(B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad)):
+            param, unpack = defer_to
+            g = grad_zeros(tuple(param.shape), x.device)
+            WGRADS.add_conv(dy, x, dw, (B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad), param, unpack)
+            return None, g
         _lib.call("emip_conv2d_wgrad_into", _p(dy), _p(x), _p(dw), B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad,
                   dt_code(x.dtype), _stream())
-        return dw
+        return dw, None
     dw = torch.empty((Cout, kh * kw * Cin), dtype=torch.float32, device=x.device)
     _lib.call("emip_conv2d_wgrad", _p(dy), _p(x), _p(dw), B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad,
               dt_code(x.dtype), _stream())
-    return dw
+    return dw, None
 
 
 def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta):

@@ -475,6 +475,23 @@ int emip_gemm_tn8_group_plan(void* rec, const void* A, const void* B, float* C, 
                              long ldb, long ldc, int item0);
 int emip_gemm_tn8_group(const void* probs, int nprob, int total, void* stream);
 
+/* The same grouped launch on 256 x 320 / 320 x 256 output tiles (eight waves, gemm_tn16.hip) for the weight gradients whose
+ * shape fills such tiles -- PVTv2-b5's third stage (C = 320: 40 of 52 blocks) and conv_corr -- Linear AND convolution
+ * (reference: train.py:52-58 loss.backward() through lib/pvt_v2.py:45-54,101-129, model/EMIP_short/model.py conv_corr).
+ * emip_gemm_tn16_eligible: 0 = leave the contraction to the 128 x 128 tiles above, else 1 + tile orientation.  The plan
+ * functions fill one HOST record (emip_gemm_tn16_recsize() bytes) for an accumulation into PRE-CLEARED outputs and return the
+ * problem's work-item count (a multiple of 8; negative = error); splits = m ranges (0: by length).  The convolution form
+ * reads X [B,H,W,Cin] through its im2col view: dW[co][ky][kx][ci] += sum_pixels dY[pix][co] X[pix + tap][ci]. */
+int emip_gemm_tn16_eligible(long M, int N, int K, long lda, long ldb);
+int emip_conv_wgrad16_eligible(int B, int H, int Wd, int Cin, long ldx, int Cout, long lddy, int KH, int KW, int stride,
+                               int pad);
+int emip_gemm_tn16_recsize(void);
+int emip_gemm_tn16_plan(void* rec, const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda,
+                        long ldb, long ldc, int item0, int splits);
+int emip_conv_wgrad16_plan(void* rec, const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx,
+                           int Cout, long lddy, int KH, int KW, int stride, int pad, int item0, int splits);
+int emip_gemm_tn16_group(const void* probs, int nprob, int total, void* stream);
+
 /* LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (f32 atomics).  mean/rstd are recomputed from x.  Workgroup b
  * accumulates into dgamma/dbeta + (b % nparts) * part_stride: nparts > 1 spreads the atomics over partial buffers that
  * the caller sums (nparts = 1: plain accumulation). */

@@ -200,14 +200,17 @@ def test_bf16_deferred_weight_gradients_equal_the_immediate_ones(model_args, sho
     def checking_flush():
         items = list(ops.WGRADS.items)
         real_flush(ops.WGRADS)
-        for a, b, c, db, M, N, K, lda, ldb in items:
+        for a, b, c, db, M, N, K, lda, ldb, kind, cv in items:
             c2 = torch.zeros_like(c)
             db2 = torch.zeros_like(db) if db is not None else None
-            _lib.call("emip_gemm_tn_into", ops._p(a), ops._p(b), ops._p(c2), ops._p(db2), M, N, K, lda, ldb, K,
-                      ops.dt_code(a.dtype), ops._stream())
-            checked.append(((c - c2).abs().max().item() / (c2.abs().max().item() + 1e-30), (M, N, K)))
+            if cv is None:
+                _lib.call("emip_gemm_tn_into", ops._p(a), ops._p(b), ops._p(c2), ops._p(db2), M, N, K, lda, ldb, K,
+                          ops.dt_code(a.dtype), ops._stream())
+            else:                                   # a convolution's weight gradient (dy, x, packed dW)
+                _lib.call("emip_conv2d_wgrad_into", ops._p(a), ops._p(b), ops._p(c2), *cv, ops.dt_code(a.dtype), ops._stream())
+            checked.append(((c - c2).abs().max().item() / (c2.abs().max().item() + 1e-30), (M, N, K, kind, cv is not None)))
             if db is not None:
-                checked.append(((db - db2).abs().max().item() / (db2.abs().max().item() + 1e-30), (M, N, 0)))
+                checked.append(((db - db2).abs().max().item() / (db2.abs().max().item() + 1e-30), (M, N, 0, kind, False)))
     ops.WGRADS.flush = checking_flush
     try:
         got, _ = _bf16_train_grads(model_args, short_sd, 2, defer=True, arena=True)
@@ -216,7 +219,8 @@ def test_bf16_deferred_weight_gradients_equal_the_immediate_ones(model_args, sho
     assert len(checked) >= 100, len(checked)                # both passes' eligible Linear layers (backbone, GMFlow, feeders)
     print("  deferred problems recomputed by the immediate launch: %d, worst %r" % (len(checked), max(checked)))
     assert max(checked)[0] <= 2e-4, sorted(checked, reverse=True)[:4]
-    assert ops.WGRADS.fixed == 0 and not ops.WGRADS.owners and not ops.WGRADS.items
+    assert {k[3] for _, k in checked} == {8, 16} and any(k[4] for _, k in checked)      # both tile families, Linear and convolution
+    assert ops.WGRADS.fixed == 0 and not ops.WGRADS.owners and not ops.WGRADS.items and not ops.WGRADS.post
     assert set(got) == set(plain) == set(plain2)
     zero = [n for n in got if not got[n].any() and plain[n].any()]
     assert not zero, zero                                   # the advisor's case: ...ffn.project_out.weight stayed zero
