@@ -18,14 +18,20 @@ def colsum_f32(dy):
     return ops.colsum(dy)
 
 
-def conv_weight_grad(dy, x, weight, k, s, p, cin_pad=None):
-    """the weight gradient of a k x k convolution in the parameter's [Cout, Cin, k, k] layout; inside a training step the
-    contraction joins the step's grouped weight-gradient launch where it is eligible (ops.conv2d_wgrad)"""
+def conv_weight_grad(dy, x, weight, k, s, p, cin_pad=None, bias=None):
+    """(weight gradient of a k x k convolution in the parameter's [Cout, Cin, k, k] layout, bias gradient or None); inside a
+    training step the contraction joins the step's grouped weight-gradient launch where it is eligible (ops.conv2d_wgrad),
+    which then also sums the columns of dy.  bias: the bias PARAMETER when its gradient is wanted (else None)."""
     cout, cin = weight.shape[0], weight.shape[1]
     cp = cin_pad or cin
     lazy = lambda t: t.view(cout, k, k, cp)[..., :cin].permute(0, 3, 1, 2)        # strided view: fixup() adds it in one pass
-    dwp, g = ops.conv2d_wgrad(dy, x, k, k, s, p, defer_to=(weight if weight.is_leaf else None, lazy))
-    return g if g is not None else unpack_conv_grad(dwp, cout, cin, k, cin_pad)
+    dwp, g, db = ops.conv2d_wgrad(dy, x, k, k, s, p, defer_to=(weight if weight.is_leaf else None, lazy),
+                                  want_db=bias is not None, bias_param=bias if (bias is not None and bias.is_leaf) else None)
+    if g is None:
+        g = unpack_conv_grad(dwp, cout, cin, k, cin_pad)
+    if bias is not None and db is None:
+        db = colsum_f32(dy)
+    return g, (db[:] if db is not None else None)          # a fresh view object (AccumulateGrad steals only unshared tensors)
 
 
 def unpack_conv_grad(dw_packed, cout, cin, k, cin_pad=None, perm=None):
@@ -106,6 +112,7 @@ class ConvFn(Function):
         y = ops.conv2d(x, wp, k, k, s, p, bias=bias)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (wdg, k, s, p, cin_pad, bias is not None)
+        ctx.bias_param = bias if (bias is not None and bias.is_leaf) else None
         return y
 
     @staticmethod
@@ -125,9 +132,11 @@ class ConvFn(Function):
             else:                            # transposed conv = stride-1 conv of the zero-inserted gradient
                 z = ops.zero_insert(dy, H, W, s)
                 dx = ops.conv2d(z, wdg, k, k, 1, k - 1 - p)
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = conv_weight_grad(dy, x, weight, k, s, p, cin_pad)
-        if has_bias and ctx.needs_input_grad[2]:
+            # the bias gradient rides the same (grouped) launch when the bias is a leaf parameter
+            dw, db = conv_weight_grad(dy, x, weight, k, s, p, cin_pad, bias=ctx.bias_param if want_db else None)
+        if want_db and db is None:
             db = colsum_f32(dy)
         return dx, dw, db, None, None, None, None, None, None
 
@@ -182,6 +191,7 @@ class QSrFn(Function):
         ctx.save_for_backward(h, wq, wsr)
         ctx.cfg = (wq_t, wsr_d, k, bq is not None, bsr is not None)
         ctx.bq_param = bq if (bq is not None and bq.is_leaf) else None
+        ctx.bsr_param = bsr if (bsr is not None and bsr.is_leaf) else None
         return q, s
 
     @staticmethod
@@ -205,9 +215,10 @@ class QSrFn(Function):
             dbq = dbq[:] if dbq is not None else None          # fresh view objects, as in LinearFn.backward
         elif has_bq and ctx.needs_input_grad[2]:
             dbq = colsum_f32(dq)
+        want_dbsr = has_bsr and ctx.needs_input_grad[4]
         if ctx.needs_input_grad[3]:
-            dwsr = conv_weight_grad(ds, h, wsr, k, k, 0)
-        if has_bsr and ctx.needs_input_grad[4]:
+            dwsr, dbsr = conv_weight_grad(ds, h, wsr, k, k, 0, bias=ctx.bsr_param if want_dbsr else None)
+        if want_dbsr and dbsr is None:
             dbsr = colsum_f32(ds)
         return dh, dwq, dbq, dwsr, dbsr, None, None, None, None, None
 

@@ -353,14 +353,14 @@ extern "C" int emip_gemm_tn16_plan(void* rec, const void* A, const void* B, floa
 }
 
 // ... the same for a convolution weight gradient: dW[co][ky][kx][ci] += sum_pixels dY[pix][co] X[pix shifted by the tap][ci]
-extern "C" int emip_conv_wgrad16_plan(void* rec, const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx,
-                                      int Cout, long lddy, int KH, int KW, int stride, int pad, int item0, int splits) {
+extern "C" int emip_conv_wgrad16_plan(void* rec, const void* dY, const void* X, float* dW, float* db, int B, int H, int Wd, int Cin,
+                                      long ldx, int Cout, long lddy, int KH, int KW, int stride, int pad, int item0, int splits) {
     if (!(rec && dY && X && dW && (item0 & 7) == 0)) return EMIP_E_INVALID;
     if (!(emip_conv_wgrad16_eligible(B, H, Wd, Cin, ldx, Cout, lddy, KH, KW, stride, pad) && aligned16(dY) && aligned16(X)))
         return EMIP_E_INVALID;
     const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
     Tn16Args a{};
-    a.A = (const bf16_t*)dY; a.B = (const bf16_t*)X; a.C = dW; a.db = nullptr;
+    a.A = (const bf16_t*)dY; a.B = (const bf16_t*)X; a.C = dW; a.db = db;      // db (optional): the bias gradient, column sums of dY
     a.M = (long)B * Ho * Wo; a.N = Cout; a.K = KH * KW * Cin; a.lda = lddy; a.ldb = ldx; a.ldc = a.K;
     a.H = H; a.Wd = Wd; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.KW = KW; a.stride = stride; a.pad = pad;
     a.a_bytes = (unsigned)(((a.M - 1) * lddy + Cout) * 2);

@@ -113,11 +113,13 @@ class WgradQueue:
         if len(self.items) >= self.MAX:
             self.flush()
 
-    def add_conv(self, dy, x, dw, cv, param, unpack):
+    def add_conv(self, dy, x, dw, db, cv, param, unpack, bias_param=None):
         B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad = cv
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-        self.items.append((dy, x, dw, None, B * Ho * Wo, Cout, kh * kw * Cin, lddy, ldx, 16, cv))
+        self.items.append((dy, x, dw, db, B * Ho * Wo, Cout, kh * kw * Cin, lddy, ldx, 16, cv))
         self.post.append((dw, param, unpack))
+        if db is not None and bias_param is not None:
+            self.owners.append((db, bias_param))
         if len(self.items) >= self.MAX:
             self.flush()
 
@@ -187,7 +189,7 @@ class WgradQueue:
             elif cv is None:
                 n = lib.emip_gemm_tn16_plan(rec, _p(a), _p(b), _p(c), _p(db), M, N, K, lda, ldb, K, total, 0)
             else:
-                n = lib.emip_conv_wgrad16_plan(rec, _p(a), _p(b), _p(c), *cv, total, 0)
+                n = lib.emip_conv_wgrad16_plan(rec, _p(a), _p(b), _p(c), _p(db), *cv, total, 0)
             if n <= 0:
                 raise _lib.EmipLibraryError("weight-gradient plan (%d) failed for %r" % (kind, (M, N, K, lda, ldb, cv)))
             total += n
@@ -1022,11 +1024,13 @@ def gemm_tn_batched(a, b, batch, M, N, K, lda, ldb, bsA, bsB):
     return c
 
 
-def conv2d_wgrad(dy, x, kh, kw, stride, pad, defer_to=None):
+def conv2d_wgrad(dy, x, kh, kw, stride, pad, defer_to=None, want_db=False, bias_param=None):
     """dy [B,Ho,Wo,Cout], x [B,H,W,Cin] channels-last -> dW f32 [Cout, kh*kw*Cin] (packed like the forward weights).
     defer_to = (parameter, unpack): the caller wants the gradient in the parameter's layout, unpack(dW) -> that layout.  Inside a
     training step the contraction may then wait for flush_wgrads() (grouped launch); the return value is (None, zeros of the
-    parameter's shape from the arena) and WgradQueue.fixup() adds unpack(dW) to the parameter's .grad.  Otherwise (dW, None)."""
+    parameter's shape from the arena, db) and WgradQueue.fixup() adds unpack(dW) to the parameter's .grad; with want_db the
+    bias gradient (column sums of dy) comes out of the same launch into an arena slice the caller hands to autograd as it is.
+    Otherwise (dW, None, None): the caller computes the bias gradient itself."""
     _dev(x)
     B, H, W, Cin = x.shape
     Cout = dy.shape[-1]
@@ -1039,15 +1043,16 @@ def conv2d_wgrad(dy, x, kh, kw, stride, pad, defer_to=None):
                 and _lib.load().emip_conv_wgrad16_eligible(B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad)):
             param, unpack = defer_to
             g = grad_zeros(tuple(param.shape), x.device)
-            WGRADS.add_conv(dy, x, dw, (B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad), param, unpack)
-            return None, g
+            db = grad_zeros((Cout,), x.device) if want_db else None
+            WGRADS.add_conv(dy, x, dw, db, (B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad), param, unpack, bias_param)
+            return None, g, db
         _lib.call("emip_conv2d_wgrad_into", _p(dy), _p(x), _p(dw), B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad,
                   dt_code(x.dtype), _stream())
-        return dw, None
+        return dw, None, None
     dw = torch.empty((Cout, kh * kw * Cin), dtype=torch.float32, device=x.device)
     _lib.call("emip_conv2d_wgrad", _p(dy), _p(x), _p(dw), B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad,
               dt_code(x.dtype), _stream())
-    return dw, None
+    return dw, None, None
 
 
 def layernorm_bwd(x, dy, gamma, eps, dgamma, dbeta):

@@ -481,15 +481,16 @@ int emip_gemm_tn8_group(const void* probs, int nprob, int total, void* stream);
  * emip_gemm_tn16_eligible: 0 = leave the contraction to the 128 x 128 tiles above, else 1 + tile orientation.  The plan
  * functions fill one HOST record (emip_gemm_tn16_recsize() bytes) for an accumulation into PRE-CLEARED outputs and return the
  * problem's work-item count (a multiple of 8; negative = error); splits = m ranges (0: by length).  The convolution form
- * reads X [B,H,W,Cin] through its im2col view: dW[co][ky][kx][ci] += sum_pixels dY[pix][co] X[pix + tap][ci]. */
+ * reads X [B,H,W,Cin] through its im2col view: dW[co][ky][kx][ci] += sum_pixels dY[pix][co] X[pix + tap][ci]; db (may be
+ * NULL) += sum_pixels dY[pix][co], the bias gradient. */
 int emip_gemm_tn16_eligible(long M, int N, int K, long lda, long ldb);
 int emip_conv_wgrad16_eligible(int B, int H, int Wd, int Cin, long ldx, int Cout, long lddy, int KH, int KW, int stride,
                                int pad);
 int emip_gemm_tn16_recsize(void);
 int emip_gemm_tn16_plan(void* rec, const void* A, const void* B, float* C, float* db, long M, int N, int K, long lda,
                         long ldb, long ldc, int item0, int splits);
-int emip_conv_wgrad16_plan(void* rec, const void* dY, const void* X, float* dW, int B, int H, int Wd, int Cin, long ldx,
-                           int Cout, long lddy, int KH, int KW, int stride, int pad, int item0, int splits);
+int emip_conv_wgrad16_plan(void* rec, const void* dY, const void* X, float* dW, float* db, int B, int H, int Wd, int Cin,
+                           long ldx, int Cout, long lddy, int KH, int KW, int stride, int pad, int item0, int splits);
 int emip_gemm_tn16_group(const void* probs, int nprob, int total, void* stream);
 
 /* LayerNorm backward: dx, and dgamma/dbeta ACCUMULATED (f32 atomics).  mean/rstd are recomputed from x.  Workgroup b

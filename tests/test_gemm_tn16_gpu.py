@@ -66,12 +66,13 @@ def test_grouped_convolution_problem_matches_f32(B, H, W, Cin, Cout, k, s, p):
     Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     dy = torch.randn(B, Ho, Wo, Cout, device="cuda").to(torch.bfloat16)
     w = torch.nn.Parameter(torch.zeros(Cout, Cin, k, k, device="cuda"))
+    bias = torch.nn.Parameter(torch.zeros(Cout, device="cuda"))
     ops.ARENA.begin("cuda:0")
     try:
-        g = conv_weight_grad(dy, x, w, k, s, p)
+        g, db = conv_weight_grad(dy, x, w, k, s, p, bias=bias)
         assert len(ops.WGRADS.items) == 1 and ops.WGRADS.items[0][10] is not None      # it waits for the grouped launch
-        assert not g.any()
-        w.grad = g                                   # what AccumulateGrad does with the first gradient of a parameter
+        assert not g.any() and not db.any()
+        w.grad, bias.grad = g, db                    # what AccumulateGrad does with the first gradient of a parameter
     finally:
         ops.ARENA.end()                              # flush + fixup: the unpacked result is added to .grad
     assert not ops.WGRADS.post and not ops.WGRADS.items
@@ -79,6 +80,8 @@ def test_grouped_convolution_problem_matches_f32(B, H, W, Cin, Cout, k, s, p):
     y = torch.nn.functional.conv2d(x.float().permute(0, 3, 1, 2), wf, stride=s, padding=p)
     y.backward(dy.float().permute(0, 3, 1, 2))
     assert (w.grad - wf.grad).abs().max() <= 3e-5 * wf.grad.abs().max()
+    rdb = dy.float().sum((0, 1, 2))
+    assert (bias.grad - rdb).abs().max() <= 3e-5 * rdb.abs().max() + 1e-3           # the bias gradient of the same launch
 
 
 def test_wide_and_narrow_problems_share_a_flush():
