@@ -1547,6 +1547,46 @@ extern "C" int emip_dwconv3x3_dual(const void* X, long ldx, void* Y, long ldy, v
     return emip_launch_status();
 }
 
+// The 3 x 3 patch matrix of a channels-last map: Y[(b, y, x)][(ky * 3 + kx) * C + c] = X[b][y + ky - 1][x + kx - 1][c], zero outside
+// the image.  The A operand of a convolution whose WEIGHTS differ per image (CoUpdater.run_conv_corr_factored: the correlation
+// volume in front of conv_corr, model/EMIP_short/model.py:59,96, is a rank-128 product, so its 3 x 3 convolution is a
+// per-image GEMM against this matrix).
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ X, long ldx, T* __restrict__ Y, long ldy, int B,
+                                                        int H, int Wd, int C) {
+    constexpr int NV = 16 / sizeof(T);
+    const int ncg = C / NV;
+    const long total = (long)B * H * Wd * 9 * ncg;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % ncg);
+        long r = idx / ncg;
+        const int tap = (int)(r % 9);
+        r /= 9;
+        const int x = (int)(r % Wd);
+        r /= Wd;
+        const int y = (int)(r % H);
+        const long b = r / H;
+        const int iy = y + tap / 3 - 1, ix = x + tap % 3 - 1;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)Wd)
+            v = *reinterpret_cast<const uint4*>(X + ((b * H + iy) * (long)Wd + ix) * ldx + cg * NV);
+        *reinterpret_cast<uint4*>(Y + ((b * H + y) * (long)Wd + x) * ldy + (long)tap * C + cg * NV) = v;
+    }
+}
+}  // namespace
+
+extern "C" int emip_im2col3x3(const void* X, long ldx, void* Y, long ldy, int B, int H, int Wd, int C, int dtype, void* stream) {
+    REQ_DT(dtype);
+    const int nv = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(X && Y && B > 0 && H > 0 && Wd > 0 && C >= nv && C % nv == 0 && ldx % nv == 0 && ldx >= C && ldy % nv == 0 &&
+                 ldy >= 9L * C && aligned16(X) && aligned16(Y));
+    const long total = (long)B * H * Wd * 9 * (C / nv);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(im2col3x3_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)X, ldx, (T*)Y, ldy, B, H, Wd, C));
+    return emip_launch_status();
+}
+
 extern "C" int emip_dwconv3x3_gated(const void* X, long ldx, void* Y, long ldy, const float* Wt, const float* bias,
                                     int B, int H, int Wd, int C2, int Cout_pad, int dtype, void* stream) {
     REQ_DT(dtype);

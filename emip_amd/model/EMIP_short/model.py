@@ -28,6 +28,9 @@ from .motion.PromptInteract import Injector
 # the same order (tests/test_timed_config_gpu.py runs both orders against each other).
 CNN_FIRST = False
 STAGGER = True
+# eval mode: conv_corr.0 computed from the rank-128 factors of the correlation volume (run_conv_corr_factored: 8.6 instead of
+# 65 GFLOP per pair, no 7.5-MB volume per pair); False = the reference's literal order, the 3 x 3 conv over 1936 channels
+CONV_CORR_FACTORED = True
 
 class CoUpdater(EmipModule):
     def __init__(self, args=None):
@@ -84,6 +87,54 @@ class CoUpdater(EmipModule):
             y = ops.conv2d(x, w0, 3, 3, 1, 1, bias=b0, act=ops.ACT_RELU)
         return ops.conv2d(y, w3, 3, 3, 1, 1, bias=b3)
 
+    def run_conv_corr_factored(self, tokens, B, h, w):
+        """conv_corr (model.py:59-62,96) of the correlation volume WITHOUT the volume (eval mode).  The reference convolves
+        corr[b, q, p] = <F0[b, p], F1[b, q]> / sqrt(C) (matching.py:16-20: raw global correlation, target position q as the
+        channel) with conv_corr.0 (1936 -> 968 channels, 3 x 3): 65 GFLOP per pair.  corr is a rank-C product (C = 128), so
+            out[b, p, co] = sum_tap sum_q W[co, q, tap] corr[b, q, p + tap]
+                          = sum_tap sum_d F0[b, p + tap, d] * G[b, co, tap, d],   G[b] = (W' / sqrt(C)) F1[b]
+        i.e. a per-image GEMM that turns the weights into a 128-channel 3 x 3 kernel G[b] ([968 * 9, 1936] x [1936, 128]) and
+        a per-image 3 x 3 convolution of F0 with it (patch matrix [1936, 1152] x G[b]^T): 8.6 GFLOP per pair, and the 7.5 MB
+        volume per pair is neither written nor read.  Zero padding of corr along p is zero padding of F0.  BatchNorm (eval) is
+        folded into W' / the bias, ReLU in the epilogue; the sums are the reference's, re-associated (f32 mode: 1e-6).
+        tokens: GMFlow's final features [2B, h*w, C] (frame 1 | frame 2)."""
+        dt = self.cdtype
+        n, C = h * w, tokens.shape[-1]
+        c0, bn, c3 = self.conv_corr[0], self.conv_corr[1], self.conv_corr[3]
+        cout = c0.weight.shape[0]
+
+        def build(cw, cb, *_):
+            wf, bf = fold_bn(cw, cb, bn)                                         # [968, 1936, 3, 3] f32
+            wr = (wf * C ** -0.5).permute(0, 2, 3, 1).reshape(cout * 9, n)       # rows (co, tap), columns q
+            return wr.to(dt).contiguous(), bf
+        wr, b0 = self.packed("ccf", (c0.weight, c0.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var), build)
+        w3, b3 = self.packed("cc3", (c3.weight, c3.bias), lambda a, b: (pack_conv(a, dt), f32(b)))
+        f0, f1 = tokens[:B], tokens[B:]
+        f1t = ops.transpose_pad(f1, n)                                           # [B, C, n]
+        g = torch.empty((B, cout * 9, C), dtype=dt, device=tokens.device)        # = per-image conv weights [968][(tap, d)]
+        ops.gemm_batched(wr, f1t, g, B, cout * 9, C, n, n, n, C, 0, C * n, cout * 9 * C)
+        pm = ops.im2col3x3(f0.reshape(B, h, w, C))                               # [B, n, 9 C]
+        y = torch.empty((B, h, w, cout), dtype=dt, device=tokens.device)
+        ops.gemm_batched_bias(pm, g, y, B, n, cout, 9 * C, 9 * C, 9 * C, cout, n * 9 * C, cout * 9 * C, n * cout,
+                              bias=b0, act=ops.ACT_RELU)
+        return ops.conv2d(y, w3, 3, 3, 1, 1, bias=b3)
+
+    def last_corr(self):
+        """the raw correlation volume [B, src, tgt] of the last run() (computed on demand when the factored conv_corr ran)"""
+        L = self.last
+        if L.get("corr") is None:
+            c0 = self.GMFlow.last["tokens"]
+            B = c0.shape[0] // 2
+            n, C = c0.shape[1], c0.shape[2]
+            wdt = int(round(n ** 0.5))
+            corr = torch.empty((B, n, n), dtype=c0.dtype, device=c0.device)
+            if c0.dtype == torch.bfloat16 and C == 128:
+                ops.match(c0[:B], c0[B:], wdt, C ** -0.5, scores=corr)
+            else:
+                corr = torch.matmul(c0[:B].float(), c0[B:].float().transpose(1, 2)).mul_(C ** -0.5).to(c0.dtype)
+            L["corr"] = corr
+        return L["corr"]
+
     def run(self, image1, image2, tail=True):
         """Planar images [B,3,H,W] -> (mask planar f32, flow predictions [2B,2,H,W] list, intermediates).
         tail=False: stop behind the motion collector (`conv_corr`) -- EMIP-long reads the backbone features and the
@@ -106,9 +157,14 @@ class CoUpdater(EmipModule):
         ab = self.injector.run(gm, fea[0])                             # camouflage feeder (shared weights)
         if torch.is_grad_enabled() and ab.requires_grad:
             preds, corr = self.GMFlow.run_train(ab)
+            cc = self.run_conv_corr(corr)                              # motion collector, part 1
+        elif CONV_CORR_FACTORED and not self.training and not torch.is_grad_enabled():
+            # eval: conv_corr.0 through the rank-128 factors of the volume; the volume itself is never materialised
+            preds, corr = self.GMFlow.run(ab[:B], ab[B:], flows=tail, corr=False)
+            cc = self.run_conv_corr_factored(self.GMFlow.last["tokens"], B, ab.shape[1], ab.shape[2])
         else:
             preds, corr = self.GMFlow.run(ab[:B], ab[B:], flows=tail)
-        cc = self.run_conv_corr(corr)                                  # motion collector, part 1
+            cc = self.run_conv_corr(corr)
         if not tail:
             self.last = dict(fea=fea, gm=gm, ab=ab, corr=corr, conv_corr=cc)
             return None, preds

@@ -72,9 +72,10 @@ class GMFlow(EmipModule):
         self.last = dict(tokens=c0, flow_prop=flow)
         return preds, corr
 
-    def run(self, a, b, flows=True):
+    def run(self, a, b, flows=True, corr=True):
         """a, b: channels-last prompted features [B,h,w,C] of frame 1 / frame 2.
         Returns (flow predictions: list of planar f32 [2B,2,8h,8w], corr [B, h*w(src), h*w(tgt)]).
+        corr=False: the raw correlation volume is not written (the caller works from self.last["tokens"]); returns None for it.
         flows=False (EMIP-long's short-term part: only the correlation volume is read): no backward-direction matching, no
         flow propagation, no upsampling; returns ([], corr)."""
         dt = self.cdtype
@@ -88,12 +89,14 @@ class GMFlow(EmipModule):
         c0 = self.transformer.run(c0, h, w, splits)
 
         # ---- global correlation + softmax -> correspondence (both directions)
-        corr = torch.empty((B, n, n), dtype=dt, device=a.device)
+        want_corr = corr
+        corr = torch.empty((B, n, n), dtype=dt, device=a.device) if want_corr else None
         if dt == torch.bfloat16 and C == 128:
             # one launch for both directions (emip_match): batch z < B = frame 1 against frame 2 with the raw correlation written
             # out, z >= B the reverse; the flow leaves the kernel as f32 [2B, h, w, 2]
             if not flows:
-                ops.match(c0[:B], c0[B:], w, C ** -0.5, scores=corr)
+                if want_corr:
+                    ops.match(c0[:B], c0[B:], w, C ** -0.5, scores=corr)
                 self.last = dict(tokens=c0)
                 return [], corr
             flow = ops.match(c0, c0, w, C ** -0.5, scores=corr, kv_rot=B).view(2 * B, h, w, 2)
@@ -102,10 +105,15 @@ class GMFlow(EmipModule):
         o = torch.empty((2 * B, n, 32), dtype=torch.float32, device=a.device)
         common = dict(batch=B, heads=1, nwin=1, Lq=n, Lk=n, D=C, DV=32, q_bs=n * C, k_bs=n * C, v_bs=0, o_bs=n * 32,
                       ldq=C, ldk=C, ldv=32, ldo=32, scale=C ** -0.5)
-        ops.attention(c0[:B], c0[B:], grid, o[:B], scores=corr, s_bs=n * n, lds=n, **common)
         if not flows:
+            if want_corr:
+                ops.attention(c0[:B], c0[B:], grid, o[:B], scores=corr, s_bs=n * n, lds=n, **common)
             self.last = dict(tokens=c0)
             return [], corr
+        if want_corr:
+            ops.attention(c0[:B], c0[B:], grid, o[:B], scores=corr, s_bs=n * n, lds=n, **common)
+        else:
+            ops.attention(c0[:B], c0[B:], grid, o[:B], **common)
         ops.attention(c0[B:], c0[:B], grid, o[B:], **common)
         flow = ops.corresp_to_flow(o, 2 * B, h, w, True)      # f32 [2B,h,w,2]
         return self._finish(c0, flow, corr, B, h, w, C)

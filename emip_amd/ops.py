@@ -341,6 +341,24 @@ def gemm_batched(a, w, out, batch, M, N, K, lda, ldw, ldc, bsA, bsW, bsC):
     return out
 
 
+def gemm_batched_bias(a, w, out, batch, M, N, K, lda, ldw, ldc, bsA, bsW, bsC, bias=None, act=ACT_NONE):
+    """gemm_batched with the bias / activation epilogue (bias f32 [N], shared by the batch)"""
+    _dev(a)
+    _lib.call("emip_gemm", _p(a), None, _p(w), _p(out), _p(bias), None, M, N, K, K, lda, 0, ldw, ldc, 0, act, batch,
+              bsA, bsW, bsC, 0, dt_code(a.dtype), _stream())
+    return out
+
+
+def im2col3x3(x):
+    """x [B,H,W,C] channels-last -> the 3 x 3 patch matrix [B, H*W, 9*C] (zero padding, tap-major columns)"""
+    _dev(x)
+    B, H, W, C = x.shape
+    _, _, ldx = rows(x)
+    y = torch.empty((B, H * W, 9 * C), dtype=x.dtype, device=x.device)
+    _lib.call("emip_im2col3x3", _p(x), ldx, _p(y), 9 * C, B, H, W, C, dt_code(x.dtype), _stream())
+    return y
+
+
 def conv2d_splitk(x, w, kh, kw, stride, pad, bias, acc, ksplit, ln_stats=None, ln_eps=0.0, zero=None):
     """split-K conv: partial sums (bias included once) are ADDED into acc f32 [B*Ho*Wo, Cout] (zero beforehand)"""
     _dev(x)

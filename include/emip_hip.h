@@ -523,6 +523,11 @@ int emip_gemm_heads(const void* A, const void* W, void* C, int M, int N, int K, 
 int emip_gemm_tn_heads(const void* A, const void* B, float* C, long M, int N, int K, long lda, long ldb, long ldc,
                        int batch, int heads, long bsA, long hsA, long bsB, long hsB, long bsC, long hsC, int dtype,
                        void* stream);
+/* Y[(b, y, x)][(ky * 3 + kx) * C + c] = X[b][y + ky - 1][x + kx - 1][c] (zero outside the image): the 3 x 3 patch matrix of a
+ * channels-last map, the A operand of a convolution whose weights differ per image (the factored conv_corr.0 of
+ * model/EMIP_short/model.py:59,96 -- see emip_amd/model/EMIP_short/model.py run_conv_corr_factored). */
+int emip_im2col3x3(const void* X, long ldx, void* Y, long ldy, int B, int H, int Wd, int C, int dtype, void* stream);
+
 int emip_transpose_pad_heads(const void* X, long ldx, long bsx, long hsx, void* Y, int batch, int heads, int R, int C,
                              int Rpad, int dtype, void* stream);
 

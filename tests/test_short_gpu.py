@@ -47,7 +47,7 @@ def test_f32_stages_and_mask_vs_reference_golden(short_f32, golden):
     assert _rel(_planar(L["fea"][2][:1]), g["pvt1_s4"]) < 1e-3
     assert _rel(_planar(L["gm"][:1])[:, :, ::2, ::2], g["gm1"]) < 1e-3
     assert _rel(_planar(L["ab"][:1])[:, :, ::2, ::2], g["inj_a"]) < 1e-3
-    corr = L["corr"].float().cpu()          # [B, src, tgt]; golden block is [tgt<64, src<64]
+    corr = short_f32.last_corr().float().cpu()          # [B, src, tgt]; golden block is [tgt<64, src<64]
     assert _rel(corr[:, :64, :64].transpose(1, 2), g["corr_block"]) < 1e-3
     assert _rel(_planar(L["conv_corr"])[:, :, ::2, ::2], g["conv_corr"]) < 1e-3
     assert _rel(_planar(L["inj1"])[:, :, ::2, ::2], g["inj1"]) < 1e-3

@@ -128,7 +128,7 @@ def stage_table(net, g, im1, im2):
     with torch.no_grad():
         mask = net(im1.cuda(), im2.cuda())[0]
     L = net.last
-    corr = L["corr"].float().cpu()
+    corr = net.last_corr().float().cpu()
     return {"pvt_s2": rel(pl(L["fea"][0][:1])[:, :, ::2, ::2], g["pvt1_s2"]), "pvt_s3": rel(pl(L["fea"][1][:1]), g["pvt1_s3"]),
             "pvt_s4": rel(pl(L["fea"][2][:1]), g["pvt1_s4"]), "gm": rel(pl(L["gm"][:1])[:, :, ::2, ::2], g["gm1"]),
             "inj_a": rel(pl(L["ab"][:1])[:, :, ::2, ::2], g["inj_a"]),
