@@ -141,6 +141,59 @@ class ConvFn(Function):
         return dx, dw, db, None, None, None, None, None, None
 
 
+class ConvCorr0Fn(Function):
+    """conv_corr.0 (model/EMIP_short/model.py:59,96: Conv2d(44*44, 968, 3, 1, 1) on the raw correlation volume of
+    matching.py:16-20) from the volume's rank-C factors -- see CoUpdater.run_conv_corr_factored for the algebra.
+        tokens [2B, n, C] (frame 1 | frame 2), weight [Cout, n, 3, 3], bias [Cout]
+        wr  [Cout * 9, n]: weight / sqrt(C), rows (co, tap);  wrt [n, Cout * 9]: its transpose (activation-dtype packs)
+        -> y [B, h, w, Cout] = bias + sum_tap sum_d F0[p + tap, d] G[b][co, tap, d],   G[b] = wr F1[b]
+    The backward is four per-image GEMMs, one stacked TN contraction and a gather: dP = dY G2 (G2 = G as [Cout, 9 C]), dF0 =
+    col2im(dP), dG2 = dY^T P, dF1 = wr^T dG, dwr = sum_b dG[b] F1[b]^T.  Neither the volume nor its gradient exists."""
+
+    @staticmethod
+    def forward(ctx, tokens, weight, bias, wr, wrt, h, w):
+        B2, n, C = tokens.shape
+        B, cout, dt = B2 // 2, weight.shape[0], tokens.dtype
+        f0, f1 = tokens[:B], tokens[B:]
+        f1t = ops.transpose_pad(f1, n)                                           # [B, C, n]
+        g = torch.empty((B, cout * 9, C), dtype=dt, device=tokens.device)
+        ops.gemm_batched(wr, f1t, g, B, cout * 9, C, n, n, n, C, 0, C * n, cout * 9 * C)
+        pm = ops.im2col3x3(f0.reshape(B, h, w, C))                               # [B, n, 9 C]
+        y = torch.empty((B, h, w, cout), dtype=dt, device=tokens.device)
+        ops.gemm_batched_bias(pm, g, y, B, n, cout, 9 * C, 9 * C, 9 * C, cout, n * 9 * C, cout * 9 * C, n * cout,
+                              bias=bias.detach().float() if bias is not None else None)
+        ctx.save_for_backward(f1t, g, pm, weight)
+        ctx.cfg = (wrt, h, w, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        f1t, g, pm, weight = ctx.saved_tensors
+        wrt, h, w, has_bias = ctx.cfg
+        B, C, n = f1t.shape
+        cout, dt = weight.shape[0], f1t.dtype
+        dy = dy.contiguous().view(B, n, cout)
+        dtok = dw = db = None
+        if has_bias and ctx.needs_input_grad[2]:
+            db = colsum_f32(dy)
+        dg = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            dg2 = ops.gemm_tn_batched(dy, pm, B, n, cout, 9 * C, cout, 9 * C, n * cout, n * 9 * C)     # f32 [B, Cout, 9 C]
+            dg = dg2.to(dt).view(B, cout * 9, C)
+            dgt = ops.transpose_pad(dg, cout * 9)                                # [B, C, Cout * 9]
+        if ctx.needs_input_grad[0]:
+            g2t = ops.transpose_pad(g.view(B, cout, 9 * C), cout)                # [B, 9 C, Cout]
+            dp = torch.empty((B, n, 9 * C), dtype=dt, device=dy.device)
+            ops.gemm_batched(dy, g2t, dp, B, n, 9 * C, cout, cout, cout, 9 * C, n * cout, 9 * C * cout, n * 9 * C)
+            dtok = torch.empty((2 * B, n, C), dtype=dt, device=dy.device)
+            ops.col2im3x3(dp, B, h, w, C, out=dtok[:B])
+            ops.gemm_batched(wrt, dgt, dtok[B:], B, n, C, cout * 9, cout * 9, cout * 9, C, 0, C * cout * 9, n * C)
+        if ctx.needs_input_grad[1]:
+            dwr = ops.gemm_tn(dgt.view(B * C, cout * 9), f1t.view(B * C, n))     # f32 [Cout * 9, n]
+            dw = (dwr.view(cout, 3, 3, n).permute(0, 3, 1, 2) * C ** -0.5).contiguous()
+        return dtok, dw, db, None, None, None, None
+
+
 class LayerNormFn(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -663,10 +716,11 @@ class GlobalMatchFn(Function):
     [B, n(src), n(tgt)]).  bf16 at 128 channels: emip_match forward (one launch, leaves the log-sum-exp) and emip_match_bwd."""
 
     @staticmethod
-    def forward(ctx, c0, grid, W):
+    def forward(ctx, c0, grid, W, want_corr=True):
         B2, n, C = c0.shape
         B = B2 // 2
-        corr = torch.empty((B, n, n), dtype=c0.dtype, device=c0.device)
+        # want_corr=False (fused path only): nobody convolves the volume (ConvCorr0Fn works from the tokens), it is not written
+        corr = torch.empty((B, n, n), dtype=c0.dtype, device=c0.device) if (want_corr or not _match_fused(c0)) else None
         if _match_fused(c0):
             lse = torch.empty((B2, n), dtype=torch.float32, device=c0.device)
             o = ops.match(c0, c0, W, C ** -0.5, scores=corr, kv_rot=B, sub_grid=False, lse=lse)
@@ -688,9 +742,10 @@ class GlobalMatchFn(Function):
         if fused:
             c0, o, lse = ctx.saved_tensors
             B2, n, C = c0.shape
-            dtok, _ = ops.match_bwd(c0, c0, W, C ** -0.5, o, do.contiguous(), lse, dscores=dcorr.contiguous(), kv_rot=B2 // 2,
+            dtok, _ = ops.match_bwd(c0, c0, W, C ** -0.5, o, do.contiguous(), lse,
+                                    dscores=dcorr.contiguous() if dcorr is not None else None, kv_rot=B2 // 2,
                                     sub_grid=False, accum=True)
-            return dtok, None, None
+            return dtok, None, None, None
         c0, grid = ctx.saved_tensors
         B2, n, C = c0.shape
         B = B2 // 2
@@ -699,13 +754,13 @@ class GlobalMatchFn(Function):
         doT = _to_act(do.contiguous(), dt)
         f0, f1 = c0[:B], c0[B:]
         scale = C ** -0.5
-        dq_f, dk_f, _ = dense_attention_bwd(f0, f1, grid[None], doT[:B], n, scale, dscore=dcorr.contiguous(),
-                                            need_dv=False)
+        dq_f, dk_f, _ = dense_attention_bwd(f0, f1, grid[None], doT[:B], n, scale,
+                                            dscore=dcorr.contiguous() if dcorr is not None else None, need_dv=False)
         dq_b, dk_b, _ = dense_attention_bwd(f1, f0, grid[None], doT[B:], n, scale, need_dv=False)
         dc0 = torch.empty_like(c0)
         ops.axpby(dq_f, _to_act(dk_b, dt), 1.0, 1.0, out=dc0[:B])
         ops.axpby(dq_b, _to_act(dk_f, dt), 1.0, 1.0, out=dc0[B:])
-        return dc0, None, None
+        return dc0, None, None, None
 
 
 class FlowPropFn(Function):

@@ -73,7 +73,8 @@ struct RepackRec {
     long s0, s1, s2, s3;  // source strides in elements
     long base;
     int d1, d2, d3, valid3;
-    int dst_bf16, pad_;
+    int dst_bf16;
+    float scale;          // the copy is multiplied by it; 0 (the all-zero record tail of older tables) = 1
 };
 
 constexpr int RCHUNK = 2048;  // dst elements per workgroup: 256 threads x 8
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackRec* __restrict
     const long i = (long)bm.y * RCHUNK + threadIdx.x * 8;
     if (i >= r.n) return;
     float v[8];
+    const float sc = r.scale != 0.f ? r.scale : 1.f;
     long q = i / r.d3;
     int i3 = (int)(i - q * r.d3);
     long q2 = q / r.d2;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void repack_kernel(const RepackRec* __restrict
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const bool in = i + j < r.n;
-        v[j] = (in && i3 < r.valid3) ? r.src[r.base + i0 * r.s0 + i1 * r.s1 + i2 * r.s2 + i3 * r.s3] : 0.f;
+        v[j] = (in && i3 < r.valid3) ? sc * r.src[r.base + i0 * r.s0 + i1 * r.s1 + i2 * r.s2 + i3 * r.s3] : 0.f;
         if (++i3 == r.d3) {
             i3 = 0;
             if (++i2 == r.d2) {

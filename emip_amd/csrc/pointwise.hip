@@ -1576,6 +1576,55 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(const T* __restrict__ X,
 }
 }  // namespace
 
+// ... and its adjoint: DX[b][y][x][c] = sum_taps DY[(b, y - (ky - 1), x - (kx - 1))][(ky * 3 + kx) * C + c] over the taps whose
+// source pixel lies inside the image (a gather: every output element is written once, f32 sums, one rounding)
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void col2im3x3_kernel(const T* __restrict__ DY, long lddy, T* __restrict__ DX, long lddx, int B,
+                                                        int H, int Wd, int C) {
+    constexpr int NV = 16 / sizeof(T);
+    const int ncg = C / NV;
+    const long total = (long)B * H * Wd * ncg;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int cg = (int)(idx % ncg);
+        long r = idx / ncg;
+        const int x = (int)(r % Wd);
+        r /= Wd;
+        const int y = (int)(r % H);
+        const long b = r / H;
+        float acc[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int py = y - (tap / 3 - 1), px = x - (tap % 3 - 1);
+            if ((unsigned)py < (unsigned)H && (unsigned)px < (unsigned)Wd) {
+                const uint4 raw = *reinterpret_cast<const uint4*>(DY + ((b * H + py) * (long)Wd + px) * lddy + (long)tap * C + cg * NV);
+                const T* tv = reinterpret_cast<const T*>(&raw);
+#pragma unroll
+                for (int j = 0; j < NV; ++j) acc[j] += to_f32<T>(tv[j]);
+            }
+        }
+        uint4 out;
+        T* ov = reinterpret_cast<T*>(&out);
+#pragma unroll
+        for (int j = 0; j < NV; ++j) ov[j] = from_f32<T>(acc[j]);
+        *reinterpret_cast<uint4*>(DX + ((b * H + y) * (long)Wd + x) * lddx + cg * NV) = out;
+    }
+}
+}  // namespace
+
+extern "C" int emip_col2im3x3(const void* DY, long lddy, void* DX, long lddx, int B, int H, int Wd, int C, int dtype, void* stream) {
+    REQ_DT(dtype);
+    const int nv = dtype == EMIP_F32 ? 4 : 8;
+    EMIP_REQUIRE(DY && DX && B > 0 && H > 0 && Wd > 0 && C >= nv && C % nv == 0 && lddx % nv == 0 && lddx >= C && lddy % nv == 0 &&
+                 lddy >= 9L * C && aligned16(DY) && aligned16(DX));
+    const long total = (long)B * H * Wd * (C / nv);
+    DISPATCH_T(dtype, hipLaunchKernelGGL(col2im3x3_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                                         (const T*)DY, lddy, (T*)DX, lddx, B, H, Wd, C));
+    return emip_launch_status();
+}
+
 extern "C" int emip_im2col3x3(const void* X, long ldx, void* Y, long ldy, int B, int H, int Wd, int C, int dtype, void* stream) {
     REQ_DT(dtype);
     const int nv = dtype == EMIP_F32 ? 4 : 8;

@@ -15,7 +15,7 @@ import torch
 import torch.nn as nn
 
 from ... import ops
-from ...nn_base import EmipModule, f32, conv_dgrad_pack, fold_bn, pack_conv, to_cl
+from ...nn_base import EmipModule, _record, f32, conv_dgrad_pack, fold_bn, pack_conv, to_cl
 from .create_backbone import DimensionalReduction, NeighborConnectionDecoder, Network, conv_bn_train
 from .motion.common import LayerNorm2d
 from .motion.gmflow.gmflow import GMFlow
@@ -119,6 +119,31 @@ class CoUpdater(EmipModule):
                               bias=b0, act=ops.ACT_RELU)
         return ops.conv2d(y, w3, 3, 3, 1, 1, bias=b3)
 
+    def run_conv_corr_factored_train(self, tokens, h, w):
+        """the training form of run_conv_corr_factored: conv_corr.0 through autograd.ConvCorr0Fn, then BatchNorm on batch
+        statistics + ReLU and conv_corr.3 as in run_conv_corr"""
+        from ...autograd import BNReluFn, ConvCorr0Fn, ConvFn
+        from .create_backbone import _update_running_stats
+        dt = self.cdtype
+        n, C = tokens.shape[1], tokens.shape[2]
+        c0, bn, c3 = self.conv_corr[0], self.conv_corr[1], self.conv_corr[3]
+        cout = c0.weight.shape[0]
+
+        def build(cw):
+            sc = C ** -0.5
+            wr = (cw.detach().float() * sc).permute(0, 2, 3, 1).reshape(cout * 9, n).to(dt).contiguous()
+            wrt = wr.t().contiguous()
+            # both are strided copies of the parameter: kept current by the one-launch refresh after the optimizer step
+            _record(cw, wr, (1, cout, 9, n), (0, n * 9, 1, 9), scale=sc)
+            _record(cw, wrt, (1, n, cout, 9), (0, 9, n * 9, 1), scale=sc)
+            return wr, wrt
+        wr, wrt = self.packed("ccft", (c0.weight,), build)
+        y = ConvCorr0Fn.apply(tokens, c0.weight, c0.bias, wr, wrt, h, w)
+        y, sums = BNReluFn.apply(y, bn.weight, bn.bias, bn.eps, True)
+        _update_running_stats(bn, sums, y.shape[0] * y.shape[1] * y.shape[2])
+        w3p, w3d = self.packed("cc3t", (c3.weight,), lambda a: (pack_conv(a, dt), conv_dgrad_pack(a, dt, 3, 1, 1)))
+        return ConvFn.apply(y, c3.weight, c3.bias, w3p, w3d, 3, 1, 1, None)
+
     def last_corr(self):
         """the raw correlation volume [B, src, tgt] of the last run() (computed on demand when the factored conv_corr ran)"""
         L = self.last
@@ -156,8 +181,12 @@ class CoUpdater(EmipModule):
             gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
         ab = self.injector.run(gm, fea[0])                             # camouflage feeder (shared weights)
         if torch.is_grad_enabled() and ab.requires_grad:
-            preds, corr = self.GMFlow.run_train(ab)
-            cc = self.run_conv_corr(corr)                              # motion collector, part 1
+            if CONV_CORR_FACTORED and self.training:
+                preds, corr = self.GMFlow.run_train(ab, corr=False)
+                cc = self.run_conv_corr_factored_train(self.GMFlow.last["tokens"], ab.shape[1], ab.shape[2])
+            else:
+                preds, corr = self.GMFlow.run_train(ab)
+                cc = self.run_conv_corr(corr)                          # motion collector, part 1
         elif CONV_CORR_FACTORED and not self.training and not torch.is_grad_enabled():
             # eval: conv_corr.0 through the rank-128 factors of the volume; the volume itself is never materialised
             preds, corr = self.GMFlow.run(ab[:B], ab[B:], flows=tail, corr=False)

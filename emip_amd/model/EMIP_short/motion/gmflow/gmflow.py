@@ -39,9 +39,10 @@ class GMFlow(EmipModule):
         assert self.corr_radius_list == [-1] and self.prop_radius_list == [-1] and self.pred_bidir_flow, \
             "only the shipped configuration (global matching, bidirectional) is built"
 
-    def run_train(self, ab):
+    def run_train(self, ab, corr=True):
         """differentiable variant of run(): ab = prompted features of both frames [2B,h,w,C] (frame 1 | frame 2).
-        The GMFlow weights are frozen (model.py:61-63), so only input gradients flow."""
+        The GMFlow weights are frozen (model.py:61-63), so only input gradients flow.  corr=False: the correlation volume is
+        not written (the caller convolves it through its factors, self.last["tokens"]); None is returned for it."""
         dt = self.cdtype
         B2, h, w, C = ab.shape
         n = h * w
@@ -49,7 +50,7 @@ class GMFlow(EmipModule):
         pos = position_table(h, w, C, splits, dt, ab.device)
         c0 = BcastAddFn.apply(ab.view(B2, n, C), pos, n)
         c0 = self.transformer.run_train(c0, h, w, splits)
-        o, corr = GlobalMatchFn.apply(c0, grid_values(h, w, dt, ab.device), w)
+        o, corr = GlobalMatchFn.apply(c0, grid_values(h, w, dt, ab.device), w, corr)
         flow = CorrespToFlowFn.apply(o, B2, h, w, True)
         preds = []
         if self.training:

@@ -52,16 +52,16 @@ class _Entry:
         self.sig, self.val, self.recs, self.tensors, self.mode = sig, val, recs, tensors, mode
 
 
-def _record(src, dst, dims, strides, base=0, valid3=None):
-    """dst (contiguous) = src.flatten()[base + sum_i idx_i * strides_i] over `dims` (4 entries, leading ones padded with 1),
-    zero where idx_3 >= valid3"""
+def _record(src, dst, dims, strides, base=0, valid3=None, scale=1.0):
+    """dst (contiguous) = scale * src.flatten()[base + sum_i idx_i * strides_i] over `dims` (4 entries, leading ones padded
+    with 1), zero where idx_3 >= valid3"""
     if _REC is None or src.dtype != torch.float32 or not src.is_contiguous():
         return
     if dst.untyped_storage().data_ptr() == src.untyped_storage().data_ptr():
         return                                   # f32 mode: the "pack" is the parameter itself
     assert dst.is_contiguous() and dst.numel() >= dims[0] * dims[1] * dims[2] * dims[3]      # a prefix may be enough
     _REC.append((src, dst, tuple(int(d) for d in dims), tuple(int(x) for x in strides), int(base),
-                 int(dims[3] if valid3 is None else valid3)))
+                 int(dims[3] if valid3 is None else valid3), float(scale)))
 
 
 def _flat_tensors(v, out):
@@ -107,10 +107,10 @@ def refresh_packs():
             recs, bmap = bytearray(), []
             i = 0
             for e in ents:
-                for (src, dst, d, st, base, valid3) in e.recs:
+                for (src, dst, d, st, base, valid3, scale) in e.recs:
                     n = d[0] * d[1] * d[2] * d[3]
-                    recs += struct.pack("<QQqqqqqqiiiiii", src.data_ptr(), dst.data_ptr(), n, st[0], st[1], st[2], st[3],
-                                        base, d[1], d[2], d[3], valid3, 1 if dst.dtype == torch.bfloat16 else 0, 0)
+                    recs += struct.pack("<QQqqqqqqiiiiif", src.data_ptr(), dst.data_ptr(), n, st[0], st[1], st[2], st[3],
+                                        base, d[1], d[2], d[3], valid3, 1 if dst.dtype == torch.bfloat16 else 0, scale)
                     bmap += [(i, c) for c in range((n + chunk - 1) // chunk)]
                     i += 1
             if not bmap:

@@ -359,6 +359,15 @@ def im2col3x3(x):
     return y
 
 
+def col2im3x3(dy, B, H, W, C, out=None):
+    """adjoint of im2col3x3: dy [B, H*W, 9*C] -> [B, H*W, C] (out: a contiguous tensor of that shape to write into)"""
+    _dev(dy)
+    dx = out if out is not None else torch.empty((B, H * W, C), dtype=dy.dtype, device=dy.device)
+    assert dx.is_contiguous() and dx.numel() == B * H * W * C and dy.is_contiguous()
+    _lib.call("emip_col2im3x3", _p(dy), 9 * C, _p(dx), C, B, H, W, C, dt_code(dy.dtype), _stream())
+    return dx
+
+
 def conv2d_splitk(x, w, kh, kw, stride, pad, bias, acc, ksplit, ln_stats=None, ln_eps=0.0, zero=None):
     """split-K conv: partial sums (bias included once) are ADDED into acc f32 [B*Ho*Wo, Cout] (zero beforehand)"""
     _dev(x)

@@ -527,6 +527,8 @@ int emip_gemm_tn_heads(const void* A, const void* B, float* C, long M, int N, in
  * channels-last map, the A operand of a convolution whose weights differ per image (the factored conv_corr.0 of
  * model/EMIP_short/model.py:59,96 -- see emip_amd/model/EMIP_short/model.py run_conv_corr_factored). */
 int emip_im2col3x3(const void* X, long ldx, void* Y, long ldy, int B, int H, int Wd, int C, int dtype, void* stream);
+/* the adjoint of emip_im2col3x3: DX[b][y][x][c] = the sum over the taps of DY at the patch rows that read pixel (y, x) */
+int emip_col2im3x3(const void* DY, long lddy, void* DX, long lddx, int B, int H, int Wd, int C, int dtype, void* stream);
 
 int emip_transpose_pad_heads(const void* X, long ldx, long bsx, long hsx, void* Y, int batch, int heads, int R, int C,
                              int Rpad, int dtype, void* stream);

@@ -8,8 +8,8 @@ from emip_amd import nn_base
 
 
 def _emulate(rec):
-    src, dst, d, st, base, valid3 = rec
-    flat = src.detach().float().reshape(-1).numpy()
+    src, dst, d, st, base, valid3, scale = rec
+    flat = src.detach().float().reshape(-1).numpy() * np.float32(scale)
     idx = np.indices(d).reshape(4, -1)
     off = base + sum(idx[i].astype(np.int64) * st[i] for i in range(4))
     ok = idx[3] < valid3

@@ -11,8 +11,8 @@ pytestmark = pytest.mark.gpu
 
 
 def _expected(rec):
-    src, dst, d, st, base, valid3 = rec
-    flat = src.detach().reshape(-1)
+    src, dst, d, st, base, valid3, scale = rec
+    flat = src.detach().reshape(-1) * scale
     idx = torch.meshgrid(*[torch.arange(n, device=src.device) for n in d], indexing="ij")
     off = base + sum(idx[i] * st[i] for i in range(4))
     ok = idx[3] < valid3
