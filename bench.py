@@ -24,7 +24,13 @@ sys.path.insert(0, ROOT)
 
 PAIRS_PER_GPU = 16
 PEAK_BF16_TFLOPS = 2500.0      # dense bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
-F_ALG_PAIR_GFLOP = 270.63      # algorithmic forward FLOPs per frame pair
+F_ALG_PAIR_GFLOP = 270.63      # algorithmic forward FLOPs per frame pair IN THE REFERENCE'S FORMULATION
+# conv_corr.0 convolves the rank-128 correlation volume: 2 * 1936 * 968 * 17424 = 65.31 GFLOP per pair as the reference writes
+# it, 2 * (8712 * 1936 * 128 + 1936 * 968 * 1152) = 8.64 through the volume's factors (CoUpdater.run_conv_corr_factored, the
+# product path).  The utilisation figures below price the FLOPs the launches EXECUTE; the reference-formulation rate is
+# reported beside them and is NOT a utilisation.
+CONV_CORR_REF_GFLOP, CONV_CORR_EXEC_GFLOP = 65.31, 8.64
+F_EXEC_PAIR_GFLOP = F_ALG_PAIR_GFLOP - CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP
 
 
 PEAK_HBM_TBS = 8.0             # HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -273,7 +279,7 @@ def cpu_baseline(sd):
             rates = [1.0 / t for t in ts]
             recs[nt] = {"value": len(ts) / sum(ts), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
                         "median": round(_pct(rates, 0.5), 4), "p10": round(_pct(rates, 0.1), 4), "p90": round(_pct(rates, 0.9), 4),
-                        "gflops": round(len(ts) / sum(ts) * F_ALG_PAIR_GFLOP, 1),
+                        "gflops": round(len(ts) / sum(ts) * F_EXEC_PAIR_GFLOP, 1),
                         "sample": "%d fp32 batch-1 EMIP-short forwards of the CPU oracle (oracle/emip_oracle.py, PyTorch-CPU, "
                                   "%d threads, host has %d logical CPUs)" % (len(ts), torch.get_num_threads(), ncpu)}
     return recs[16], recs[8], ref_mask
@@ -420,6 +426,10 @@ F_ALG_TRAIN_PAIR_GFLOP = 702.0   # fwd F + dgrad where a
 # launches the long step does not make because nobody reads their results (model_long.py:68-117 decodes on its own):
 # flow propagation 2.20, convex upsampler 3.46, the short-term injector1 0.86, its reductions / decoder 1.23
 F_ALG_LONG_FRAME_GFLOP = 270.63 + 10.0 - 2.20 - 3.46 - 0.86 - 1.23
+F_EXEC_LONG_FRAME_GFLOP = F_ALG_LONG_FRAME_GFLOP - CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP
+# training: conv_corr.0 forward + input gradient + weight gradient = 3 x 65.31 in the reference's formulation; the factored
+# form runs 8.64 forward + four 4.32-GFLOP contractions backward
+F_EXEC_TRAIN_PAIR_GFLOP = F_ALG_TRAIN_PAIR_GFLOP - 3 * CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP + 4 * 4.32
 
 
 def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allreduce", comm="f32"):
@@ -468,9 +478,12 @@ def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allre
                    "parallelism": "dp%d (bucketed gradient exchange over RCCL: %s, %s on the wire)" % (
                        world, "one all-reduce per 64-MB bucket" if algo == "allreduce" else
                        "direct reduce-scatter + all-gather on the xGMI mesh", comm)},
-        "achieved_TFLOPs_per_gpu": round(value / world * F_ALG_TRAIN_PAIR_GFLOP / 1e3, 1),
-        "frac_of_bf16_mfma_peak": round(value / world * F_ALG_TRAIN_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
-        "flops_convention": "702 GFLOP per pair (SURVEY.md 8d)",
+        "achieved_TFLOPs_per_gpu": round(value / world * F_EXEC_TRAIN_PAIR_GFLOP / 1e3, 1),
+        "frac_of_bf16_mfma_peak": round(value / world * F_EXEC_TRAIN_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
+        "reference_formulation_TFLOPs_per_gpu": round(value / world * F_ALG_TRAIN_PAIR_GFLOP / 1e3, 1),
+        "flops_convention": "executed: %.1f GFLOP per pair = 702 (SURVEY.md 8d, the reference's formulation) - 3 x 65.31 (conv_corr.0 "
+                            "forward / input gradient / weight gradient over the correlation volume) + 8.64 + 4 x 4.32 (the same through "
+                            "the volume's rank-128 factors)" % F_EXEC_TRAIN_PAIR_GFLOP,
         "last_loss": [round(float(x), 5) for x in loss],
         "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
     if red is not None:
@@ -556,10 +569,12 @@ def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=Fal
                            "pairs), several groups in flight; the memory read + long decoder of step t waits for the key / value "
                            "pairs of frames t-4 .. t",
                    "parallelism": "dp%d (independent replicas, no collective)" % world},
-        "achieved_TFLOPs_per_gpu": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3, 1),
-        "frac_of_bf16_mfma_peak": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
-        "flops_convention": "%.2f GFLOP per stream-frame = F_alg(short) 270.63 + 10 (SURVEY.md 8d) - 7.75 for the flow "
-                               "head / upsampler / short-term injector1 + decoder the long step never launches" % F_ALG_LONG_FRAME_GFLOP}
+        "achieved_TFLOPs_per_gpu": round(value / world * F_EXEC_LONG_FRAME_GFLOP / 1e3, 1),
+        "frac_of_bf16_mfma_peak": round(value / world * F_EXEC_LONG_FRAME_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
+        "reference_formulation_TFLOPs_per_gpu": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3, 1),
+        "flops_convention": "executed: %.2f GFLOP per stream-frame = F_alg(short) 270.63 + 10 (SURVEY.md 8d) - 7.75 for the flow "
+                               "head / upsampler / short-term injector1 + decoder the long step never launches - 56.67 (conv_corr.0 "
+                               "through the correlation volume's factors: 8.64 instead of 65.31)" % F_EXEC_LONG_FRAME_GFLOP}
     del net
     if not no_graph:
         del runner
@@ -812,8 +827,12 @@ def main():
                                 "streams in turn and overlap, like independent requests of a serving loop; per_step.latency_ms "
                                 "is one such step alone" % args.inflight) if pipelined else
                                "one step at a time, its batch split into sub-batch graphs on concurrent streams"},
-            "end_to_end": {"achieved_TFLOPs": round(value / world * F_ALG_PAIR_GFLOP / 1e3, 2),
-                           "frac_of_bf16_mfma_peak": round(value / world * F_ALG_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4)},
+            "end_to_end": {"achieved_TFLOPs": round(value / world * F_EXEC_PAIR_GFLOP / 1e3, 2),
+                           "frac_of_bf16_mfma_peak": round(value / world * F_EXEC_PAIR_GFLOP / 1e3 / PEAK_BF16_TFLOPS, 4),
+                           "reference_formulation_TFLOPs": round(value / world * F_ALG_PAIR_GFLOP / 1e3, 2),
+                           "flops_convention": "executed: %.2f GFLOP per pair = 270.63 (SURVEY.md 8d, the reference's formulation) "
+                                               "- 65.31 + 8.64 (conv_corr.0 through the rank-128 factors of the correlation "
+                                               "volume); the reference-formulation rate is not a utilisation" % F_EXEC_PAIR_GFLOP},
             "roofline": ({"bound": "hbm", "kernel": dom, "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_TBS * 1e3,
                           "unit": "GB/s", "frac": round(tbs / PEAK_HBM_TBS, 4)} if hbm_bound else
                          {"bound": "mfma", "kernel": dom, "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS,
@@ -857,10 +876,16 @@ def main():
                                   "only, gmflow/transformer.py:316-345 (emip_ffn_block)"),
             "sra_attention_only": named_roofline(agg, "sra_kernel",
                                                  "softmax(q k^T / 8) v alone (the 11x11 stage, sr_ratio 1), lib/pvt_v2.py:113-125"),
-            "correlation": named_roofline(agg, "match_kernel+scores",
-                                          "GMFlow all-pairs correlation + softmax expectation of BOTH matching directions in "
-                                          "one launch, raw correlation of the forward direction written once as [src][tgt], "
-                                          "gmflow/matching.py:13-41 (emip_match)")}
+            "correlation": (named_roofline(agg, "match_kernel",
+                                           "GMFlow all-pairs correlation + softmax expectation of BOTH matching directions in "
+                                           "one launch, gmflow/matching.py:13-41 (emip_match); the raw correlation volume is no "
+                                           "longer written: conv_corr.0 works from its rank-128 factors (run_conv_corr_factored), so "
+                                           "the launch reads the features and writes the flows only and is bound by the MFMA / exp "
+                                           "pipes, not by HBM")
+                            or named_roofline(agg, "match_kernel+scores",
+                                              "GMFlow all-pairs correlation + softmax expectation of BOTH matching directions in one "
+                                              "launch, raw correlation of the forward direction written once as [src][tgt], "
+                                              "gmflow/matching.py:13-41 (emip_match)"))}
         out["kernel_breakdown_ms"] = {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}
         out["parity"] = {"timed_outputs": timed_parity}
         if world == 1 and not args.no_cpu_baseline:
