@@ -30,7 +30,11 @@ F_ALG_PAIR_GFLOP = 270.63      # algorithmic forward FLO
 # product path).  The utilisation figures below price the FLOPs the launches EXECUTE; the reference-formulation rate is
 # reported beside them and is NOT a utilisation.
 CONV_CORR_REF_GFLOP, CONV_CORR_EXEC_GFLOP = 65.31, 8.64
-F_EXEC_PAIR_GFLOP = F_ALG_PAIR_GFLOP - CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP
+# The reference runs PVTv2-b5 on both frames (model.py:87-88, 60.56 GFLOP per image) and reads only stage 2 of the second one
+# (:92): stages 3 and 4 of that frame (40 + 3 blocks and their patch embeddings: 49.40 + 2.74 GFLOP) feed nothing.  The product
+# path runs them for one frame (CoUpdater PVT_DEEP_ONE_FRAME); they are not executed, so they are not priced either.
+PVT_DEEP_IMAGE_GFLOP = 52.14
+F_EXEC_PAIR_GFLOP = F_ALG_PAIR_GFLOP - CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP - PVT_DEEP_IMAGE_GFLOP
 
 
 PEAK_HBM_TBS = 8.0             # HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
@@ -426,10 +430,11 @@ F_ALG_TRAIN_PAIR_GFLOP = 702.0   # fwd F + dgrad where a
 # launches the long step does not make because nobody reads their results (model_long.py:68-117 decodes on its own):
 # flow propagation 2.20, convex upsampler 3.46, the short-term injector1 0.86, its reductions / decoder 1.23
 F_ALG_LONG_FRAME_GFLOP = 270.63 + 10.0 - 2.20 - 3.46 - 0.86 - 1.23
-F_EXEC_LONG_FRAME_GFLOP = F_ALG_LONG_FRAME_GFLOP - CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP
+F_EXEC_LONG_FRAME_GFLOP = F_ALG_LONG_FRAME_GFLOP - CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP - PVT_DEEP_IMAGE_GFLOP
 # training: conv_corr.0 forward + input gradient + weight gradient = 3 x 65.31 in the reference's formulation; the factored
 # form runs 8.64 forward + four 4.32-GFLOP contractions backward
-F_EXEC_TRAIN_PAIR_GFLOP = F_ALG_TRAIN_PAIR_GFLOP - 3 * CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP + 4 * 4.32
+# ... and the dead stages of the second frame cost forward + input gradient + weight gradient in the reference's formulation
+F_EXEC_TRAIN_PAIR_GFLOP = F_ALG_TRAIN_PAIR_GFLOP - 3 * CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP + 4 * 4.32 - 3 * PVT_DEEP_IMAGE_GFLOP
 
 
 def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allreduce", comm="f32"):
@@ -483,7 +488,8 @@ def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allre
         "reference_formulation_TFLOPs_per_gpu": round(value / world * F_ALG_TRAIN_PAIR_GFLOP / 1e3, 1),
         "flops_convention": "executed: %.1f GFLOP per pair = 702 (SURVEY.md 8d, the reference's formulation) - 3 x 65.31 (conv_corr.0 "
                             "forward / input gradient / weight gradient over the correlation volume) + 8.64 + 4 x 4.32 (the same through "
-                            "the volume's rank-128 factors)" % F_EXEC_TRAIN_PAIR_GFLOP,
+                            "the volume's rank-128 factors) - 3 x 52.14 (PVT stages 3-4 of the second frame, whose outputs nothing reads: "
+                            "forward / input gradient / weight gradient)" % F_EXEC_TRAIN_PAIR_GFLOP,
         "last_loss": [round(float(x), 5) for x in loss],
         "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
     if red is not None:
@@ -574,7 +580,8 @@ def measure_long(S, steps, warmup, world, rank, dev, dist, red_dev, no_graph=Fal
         "reference_formulation_TFLOPs_per_gpu": round(value / world * F_ALG_LONG_FRAME_GFLOP / 1e3, 1),
         "flops_convention": "executed: %.2f GFLOP per stream-frame = F_alg(short) 270.63 + 10 (SURVEY.md 8d) - 7.75 for the flow "
                                "head / upsampler / short-term injector1 + decoder the long step never launches - 56.67 (conv_corr.0 "
-                               "through the correlation volume's factors: 8.64 instead of 65.31)" % F_EXEC_LONG_FRAME_GFLOP}
+                               "through the correlation volume's factors: 8.64 instead of 65.31) - 52.14 (PVT stages 3-4 of the FIRST frame, "
+                               "which the long step never reads)" % F_EXEC_LONG_FRAME_GFLOP}
     del net
     if not no_graph:
         del runner
@@ -832,7 +839,8 @@ def main():
                            "reference_formulation_TFLOPs": round(value / world * F_ALG_PAIR_GFLOP / 1e3, 2),
                            "flops_convention": "executed: %.2f GFLOP per pair = 270.63 (SURVEY.md 8d, the reference's formulation) "
                                                "- 65.31 + 8.64 (conv_corr.0 through the rank-128 factors of the correlation "
-                                               "volume); the reference-formulation rate is not a utilisation" % F_EXEC_PAIR_GFLOP},
+                                               "volume) - 52.14 (PVT stages 3-4 of the second frame: model.py:87-92 reads fea_2[0] "
+                                               "only); the reference-formulation rate is not a utilisation" % F_EXEC_PAIR_GFLOP},
             "roofline": ({"bound": "hbm", "kernel": dom, "achieved": round(tbs * 1e3, 1), "peak": PEAK_HBM_TBS * 1e3,
                           "unit": "GB/s", "frac": round(tbs / PEAK_HBM_TBS, 4)} if hbm_bound else
                          {"bound": "mfma", "kernel": dom, "achieved": round(tflops, 2), "peak": PEAK_BF16_TFLOPS,

@@ -184,7 +184,11 @@ class Block(EmipModule):
         if forced is None and pre is not None and pre[tag][1].shape == (B, C) and pre[tag][1].device == x.device:
             return pre[tag]
         if forced is not None:
-            sb = forced[tag].to(device=x.device, dtype=torch.float32).contiguous()
+            sb = forced[tag].to(device=x.device, dtype=torch.float32)
+            if sb.numel() != B:          # factors of the whole batch, this block sees images _batch_lo .. _batch_lo + B - 1 (run(deep=))
+                lo = getattr(self, "_batch_lo", 0)
+                sb = sb[lo:lo + B]
+            sb = sb.contiguous()
         else:
             keep = 1.0 - self.drop_path_rate
             sb = torch.floor(keep + torch.rand(B, device=x.device)) / keep
@@ -416,12 +420,19 @@ class PyramidVisionTransformerV2(EmipModule):
             setattr(self, f"norm{i + 1}", norm_layer(embed_dims[i]))
             cur += depths[i]
 
-    def run(self, x):
-        """x: channels-last image [B,H,W,8] -> list of the 4 stage outputs, channels-last."""
+    def run(self, x, deep=None):
+        """x: channels-last image [B,H,W,8] -> list of the 4 stage outputs, channels-last.
+        deep = (lo, hi): only the images lo .. hi - 1 of the batch go on past stage 2 (the outputs of stages 3 and 4 then hold
+        hi - lo images) -- for callers that read the deep features of part of the batch only (CoUpdater.run)."""
         outs = []
         for i in range(self.num_stages):
+            if i == 2 and deep is not None:
+                x = x[deep[0]:deep[1]]
             pe = getattr(self, f"patch_embed{i + 1}")
             blocks = getattr(self, f"block{i + 1}")
+            if self.training:
+                for blk in blocks:       # which images of the caller's batch the block sees (forced DropPath factors are per image)
+                    object.__setattr__(blk, "_batch_lo", deep[0] if (deep is not None and i >= 2) else 0)
             if FUSED_LN and not torch.is_grad_enabled() and not (self.training and any(b.drop_path_rate > 0 for b in blocks)):
                 # no LayerNorm launches inside the blocks: row statistics travel with the residual stream
                 st = pe.stride

@@ -89,8 +89,9 @@ class Model_long(EmipModule):
             L = st.last
             fea, cc = L["fea"], L["conv_corr"]
             h, w = fea[0].shape[1:3]
-            f2_2 = st.dr2.run(fea[1][S:])
-            f2_3 = st.dr3.run(fea[2][S:])
+            # the deep features of the SECOND frame (with PVT_DEEP_ONE_FRAME the short-term part computed only those)
+            f2_2 = st.dr2.run(fea[1][S:] if fea[1].shape[0] == 2 * S else fea[1])
+            f2_3 = st.dr3.run(fea[2][S:] if fea[2].shape[0] == 2 * S else fea[2])
         pk, pv = self.LTM.memorize_cl(fea[0][:S], cc)                  # [S,h,w,128] each
         return fea[0][S:], f2_2, f2_3, pk.view(S, 1, h * w, -1), pv.view(S, 1, h * w, -1)
 

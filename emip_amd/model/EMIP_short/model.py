@@ -31,6 +31,11 @@ STAGGER = True
 # eval mode: conv_corr.0 computed from the rank-128 factors of the correlation volume (run_conv_corr_factored: 8.6 instead of
 # 65 GFLOP per pair, no 7.5-MB volume per pair); False = the reference's literal order, the 3 x 3 conv over 1936 channels
 CONV_CORR_FACTORED = True
+# The reference runs the whole PVT backbone on BOTH frames (model.py:87-88) and then reads fea_2[0] only (:92; fea_1[1], fea_1[2]
+# feed the decoder, :99-100): stages 3 and 4 of the second frame -- 43 of the 52 blocks -- produce values nothing reads, in the
+# forward and (zero gradient) in the backward.  True: those stages run on the frame whose deep features are read (frame 1;
+# frame 2 for EMIP-long's steps, model_long.py:71,89-90,113-116).  Outputs and gradients are the reference's; False: literal order.
+PVT_DEEP_ONE_FRAME = True
 
 class CoUpdater(EmipModule):
     def __init__(self, args=None):
@@ -173,11 +178,13 @@ class CoUpdater(EmipModule):
             imgs = torch.empty((2 * B,) + tuple(image1.shape[2:]) + (8,), dtype=dt, device=image1.device)
             ops.planar_to_cl(image1.contiguous(), dt, 8, out=imgs[:B])
             ops.planar_to_cl(image2.contiguous(), dt, 8, out=imgs[B:])
+        # stage 2 of both frames; stages 3, 4 of the frame whose deep features are read (tail=False: EMIP-long reads frame 2's)
+        deep = ((0, B) if tail else (B, 2 * B)) if PVT_DEEP_ONE_FRAME else None
         if CNN_FIRST:
             gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
-            fea = self.backbone.feat_net.run(imgs)
+            fea = self.backbone.feat_net.run(imgs, deep=deep)
         else:
-            fea = self.backbone.feat_net.run(imgs)                     # stages 2..4 of both frames
+            fea = self.backbone.feat_net.run(imgs, deep=deep)
             gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
         ab = self.injector.run(gm, fea[0])                             # camouflage feeder (shared weights)
         if torch.is_grad_enabled() and ab.requires_grad:

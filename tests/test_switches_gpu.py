@@ -19,12 +19,14 @@ INFERENCE = [("emip_amd.lib.pvt_v2", "SRA_FUSED", False), ("emip_amd.lib.pvt_v2"
              ("emip_amd.model.EMIP_short.create_backbone", "KSPLIT", True),
              ("emip_amd.model.EMIP_short.model", "CNN_FIRST", True),
              ("emip_amd.model.EMIP_short.model", "CONV_CORR_FACTORED", False),
+             ("emip_amd.model.EMIP_short.model", "PVT_DEEP_ONE_FRAME", False),
              ("emip_amd.model.EMIP_short.motion.gmflow.transformer", "WATTN_QPROJ", False),
              ("emip_amd.model.EMIP_short.motion.gmflow.transformer", "WATTN_MERGE", False),
              ("emip_amd.model.EMIP_short.motion.gmflow.transformer", "FFN_BLOCK", False)]
 TRAINING = [("emip_amd.autograd", "DW_BWD_FUSED", False), ("emip_amd.autograd", "WATTN_BWD_FUSED", False),
             ("emip_amd.autograd", "MATCH_BWD_FUSED", False), ("emip_amd.ops", "WIDE_WGRAD", False),
-            ("emip_amd.model.EMIP_short.model", "CONV_CORR_FACTORED", False)]
+            ("emip_amd.model.EMIP_short.model", "CONV_CORR_FACTORED", False),
+            ("emip_amd.model.EMIP_short.model", "PVT_DEEP_ONE_FRAME", False)]
 
 
 def _iou(a, b):
