@@ -182,7 +182,9 @@ PROFILE_CSV = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
 if not os.path.exists(PROFILE_CSV):
     PROFILE_CSV = os.path.join(ROOT, "profiles", "r02c_bench_kernel_stats.csv")
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-# algorithmic (compulsory) HBM bytes of one 16-pair step, SURVEY.md section 8(d): 18 MB per pair + the 213 MB of bf16 weights once
+# algorithmic (compulsory) HBM bytes of one 16-pair step, SURVEY.md section 8(d): 18 MB per pair + the 213 MB of bf16 weights once;
+# 15 of the 18 MB were the correlation volume (written by the matching, read by conv_corr), which the product path no longer
+# materialises (run_conv_corr_factored) -- kept in the figure: it is the reference formulation's floor, a stricter yardstick now
 COMPULSORY_STEP_BYTES = PAIRS_PER_GPU * 18e6 + 213e6
 
 
