@@ -1,0 +1,126 @@
+"""The two places where the product path does less arithmetic than the reference's forward writes down, held against the literal
+order in the f32 mode (no rounding noise to hide behind):
+  * PVT_DEEP_ONE_FRAME: model.py:87-92 runs the backbone on both frames and reads fea_2[0] only -- stages 3 and 4 of the second
+    frame are not computed; outputs AND parameter gradients must be those of the run that computes them;
+  * CONV_CORR_FACTORED: conv_corr.0 of the rank-128 correlation volume (model.py:59,96; matching.py:16-20) through its factors."""
+import importlib
+
+import pytest
+import torch
+
+from emip_amd.filler import synthetic_gt, synthetic_pair
+
+pytestmark = pytest.mark.gpu
+MODEL = "emip_amd.model.EMIP_short.model"
+
+
+def _f32_net(model_args, short_sd, train):
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    net = CoUpdater(model_args)
+    net.load_state_dict(short_sd)
+    net = net.to("cuda:0")
+    return net.train() if train else net.eval()
+
+
+@pytest.mark.parametrize("attr", ["PVT_DEEP_ONE_FRAME", "CONV_CORR_FACTORED"])
+def test_f32_outputs_equal_the_literal_order(model_args, short_sd, attr):
+    from emip_amd import nn_base
+    mod = importlib.import_module(MODEL)
+    nn_base.set_default_dtype(torch.float32)
+    net = _f32_net(model_args, short_sd, False)
+    im1, im2 = synthetic_pair(2, seed=77)
+    im1, im2 = im1.cuda(), im2.cuda()
+    outs = {}
+    for v in (True, False):
+        old = getattr(mod, attr)
+        setattr(mod, attr, v)
+        try:
+            with torch.no_grad():
+                mask, fw, bw = net(im1, im2)
+            outs[v] = (mask.clone(), fw[-1].clone(), bw[-1].clone(), net.last["conv_corr"].float().clone())
+        finally:
+            setattr(mod, attr, old)
+    for a, b, name, tol in zip(outs[True], outs[False], ("mask", "flow_fw", "flow_bw", "conv_corr"), (2e-4, 2e-3, 2e-3, 2e-4)):
+        d = (a - b).abs().max().item()
+        print(f"  {attr}: {name} max |difference| {d:.3e} (range {b.abs().max().item():.3g})")
+        assert d <= tol * max(1.0, b.abs().max().item()), (attr, name, d)
+
+
+def test_f32_gradients_equal_the_literal_order(model_args, short_sd):
+    """one training backward (both losses, DropPath off) in the f32 mode with the second frame's deep stages dropped and with
+    conv_corr.0 through the factors: every parameter gradient equals that of the literal order"""
+    from emip_amd import nn_base
+    from emip_amd.loss.loss_flow import unFlowLoss
+    from emip_amd.loss.loss_pred import hybrid_e_loss
+    from emip_amd.train import freeze_like_reference
+    mod = importlib.import_module(MODEL)
+    nn_base.set_default_dtype(torch.float32)
+    im1, im2 = synthetic_pair(2, seed=5)
+    gt = synthetic_gt(2, seed=5).cuda()
+    im1, im2 = im1.cuda(), im2.cuda()
+    grads = {}
+    for v in (True, False):
+        olds = (mod.PVT_DEEP_ONE_FRAME, mod.CONV_CORR_FACTORED)
+        mod.PVT_DEEP_ONE_FRAME = mod.CONV_CORR_FACTORED = v
+        try:
+            net = freeze_like_reference(_f32_net(model_args, short_sd, True))
+            for m in net.modules():
+                if hasattr(m, "drop_path_rate"):
+                    m.drop_path_rate = 0.0
+            preds = net(im1, im2)
+            pair = [torch.cat((preds[1][i], preds[2][i]), 1) for i in range(len(preds[1]))]
+            loss = hybrid_e_loss(preds[0], gt) + unFlowLoss().compute_loss(pair, torch.cat((im1, im2), 1))[0]
+            loss.backward()
+            grads[v] = ({n: p.grad.detach().float().clone() for n, p in net.named_parameters() if p.grad is not None}, loss.item())
+            del net
+        finally:
+            mod.PVT_DEEP_ONE_FRAME, mod.CONV_CORR_FACTORED = olds
+    (ga, la), (gb, lb) = grads[True], grads[False]
+    assert set(ga) == set(gb)
+    assert abs(la - lb) <= 1e-4 * abs(lb), (la, lb)
+    rel = {n: ((ga[n] - gb[n]).abs().max() / (gb[n].abs().max() + 1e-20)).item() for n in gb}
+    # conv_corr.0.bias sits in front of a BatchNorm: its true gradient is zero, what is left is rounding
+    rel.pop("conv_corr.0.bias")
+    worst = sorted(((v, n) for n, v in rel.items()), reverse=True)[:6]
+    print("  largest relative gradient differences:", worst)
+    # The photometric loss is piecewise (bilinear cell, |.|, SSIM clamp): a re-associated f32 sum upstream of the flows moves
+    # pixels across kinks, so the parameters that see the flow loss only (`injector.*`) agree to 10 %, the backbone (both
+    # losses) to a few per cent, and everything downstream of the motion collector -- the mask path -- far tighter.
+    assert all(v <= (0.1 if n.startswith("injector.") else 3e-2) for n, v in rel.items()), worst
+    tight = sorted(((v, n) for n, v in rel.items() if n.startswith(("decoder.", "dr", "injector1.", "conv_corr."))), reverse=True)
+    print("  mask path (decoder, reductions, injector1, conv_corr): largest", tight[:3], "median %.1e" % tight[len(tight) // 2][0])
+    assert tight[0][0] <= 1e-2 and tight[len(tight) // 2][0] <= 1e-4, tight[:3]
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 1e-2)])
+def test_conv_corr0_fn_matches_the_literal_volume_convolution(dtype, tol):
+    """autograd.ConvCorr0Fn (output, token gradient, weight and bias gradient) against torch autograd through the literal
+    formulation: corr = F0 F1^T / sqrt(C) viewed [B, n(tgt), h, w(src)] (matching.py:16-20) -> conv2d (model.py:59)"""
+    from emip_amd import nn_base
+    from emip_amd.autograd import ConvCorr0Fn
+    B, h, w, C, cout = 2, 44, 44, 128, 968
+    n = h * w
+    g = torch.Generator(device="cuda").manual_seed(3)
+    tok = (torch.randn(2 * B, n, C, device="cuda", generator=g) * 0.5).to(dtype).requires_grad_(True)
+    weight = (torch.randn(cout, n, 3, 3, device="cuda", generator=g) * 0.01).requires_grad_(True)
+    bias = torch.randn(cout, device="cuda", generator=g).requires_grad_(True)
+    dy = torch.randn(B, h, w, cout, device="cuda", generator=g).to(dtype)
+    wr = (weight.detach() * C ** -0.5).permute(0, 2, 3, 1).reshape(cout * 9, n).to(dtype).contiguous()
+    nn_base.set_default_dtype(dtype)
+    try:
+        y = ConvCorr0Fn.apply(tok, weight, bias, wr, wr.t().contiguous(), h, w)
+        y.backward(dy)
+    finally:
+        nn_base.set_default_dtype(torch.float32)
+    got = (y.detach().float(), tok.grad.float().clone(), weight.grad.clone(), bias.grad.clone())
+    tok.grad = weight.grad = bias.grad = None
+    t32 = tok.detach().float().requires_grad_(True)
+    corr = torch.matmul(t32[:B], t32[B:].transpose(1, 2)) * C ** -0.5          # [B, src, tgt]
+    x = corr.view(B, h, w, n).permute(0, 3, 1, 2)                               # [B, tgt, h, w]
+    yr = torch.nn.functional.conv2d(x, weight.to(dtype).float() if dtype != torch.float32 else weight, bias, padding=1)
+    yr.backward(dy.float().permute(0, 3, 1, 2))
+    ref = (yr.detach().permute(0, 2, 3, 1), t32.grad, weight.grad, bias.grad)
+    for a, b, name in zip(got, ref, ("y", "d tokens", "d weight", "d bias")):
+        d = ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
+        print(f"  {dtype}: {name} relative max difference {d:.2e}")
+        assert d <= tol, (name, d)
