@@ -285,7 +285,7 @@ def cpu_baseline(sd):
             rates = [1.0 / t for t in ts]
             recs[nt] = {"value": len(ts) / sum(ts), "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
                         "median": round(_pct(rates, 0.5), 4), "p10": round(_pct(rates, 0.1), 4), "p90": round(_pct(rates, 0.9), 4),
-                        "gflops": round(len(ts) / sum(ts) * F_EXEC_PAIR_GFLOP, 1),
+                        "gflops": round(len(ts) / sum(ts) * F_ALG_PAIR_GFLOP, 1),      # the oracle runs the reference's literal formulation
                         "sample": "%d fp32 batch-1 EMIP-short forwards of the CPU oracle (oracle/emip_oracle.py, PyTorch-CPU, "
                                   "%d threads, host has %d logical CPUs)" % (len(ts), torch.get_num_threads(), ncpu)}
     return recs[16], recs[8], ref_mask

@@ -84,45 +84,54 @@ __global__ __launch_bounds__(256) void occ_corner_kernel(const float* __restrict
     }
 }
 
-// The occlusion map with the scatter INSIDE the CU: a workgroup owns a band of OCC_TH target rows of one map as f32 in LDS,
+// The occlusion map with the scatter INSIDE the CU: a workgroup owns a band of TH target rows of one map as f32 in LDS,
 // scans every source pixel of that map (the flow is 1 MB: it stays in L2), adds the corner weights that land in its band with
 // LDS atomics and writes the thresholded band.  The global scatter above is bound by L2 atomic throughput on a field that
 // scatters to unrelated cells (32 M atomics at 352 x 352 x 64 maps: 0.89 ms per launch, and every untrained GMFlow produces
 // such a field); here the same adds run at LDS rate, the clear / scatter / threshold passes and the workspace are gone.
-constexpr int OCC_TH = 32;
-__global__ __launch_bounds__(512) void occ_band_kernel(const float* __restrict__ F, float* __restrict__ occ, int H, int W, float th,
-                                                       int complement) {
-    extern __shared__ float band[];                    // [OCC_TH][W]
+__global__ __launch_bounds__(512) void occ_band_kernel(const float* __restrict__ F, float* __restrict__ occ, int H, int W, int TH,
+                                                       float th, int complement) {
+    extern __shared__ float band[];                    // [TH][W]
     const int b = blockIdx.y;
-    const int r0 = blockIdx.x * OCC_TH, r1 = min(H, r0 + OCC_TH);
+    const int r0 = blockIdx.x * TH, r1 = min(H, r0 + TH);
     const int n = H * W, nb = (r1 - r0) * W;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) band[i] = 0.f;
     __syncthreads();
     const float* fx = F + ((long)b * 2) * n;
     const float* fy = fx + n;
     const float wm = (float)(W - 1), hm = (float)(H - 1);
-    for (int pix = threadIdx.x; pix < n; pix += blockDim.x) {
-        const int py = pix / W, px = pix - py * W;
-        const float x = (float)px + fx[pix], y = (float)py + fy[pix];
-        const float x1 = floorf(x), y1 = floorf(y);
-        // rows this pixel can touch: y1 and y1 + 1 after clamping -- skip early when neither is in the band
-        const float yf = fminf(fmaxf(y1, 0.f), hm), y0 = y1 + 1.f, yc = fminf(fmaxf(y0, 0.f), hm);
-        const int iyf = (int)yf, iyc = (int)yc;
-        const bool inf = iyf >= r0 && iyf < r1, inc = iyc >= r0 && iyc < r1;
-        if (!inf && !inc) continue;
-        const float xf = fminf(fmaxf(x1, 0.f), wm), x0 = x1 + 1.f, xc = fminf(fmaxf(x0, 0.f), wm);
-        const bool xco = x0 != xc, yco = y0 != yc, xfo = x1 != xf, yfo = y1 != yf;
-        const float wxc = 1.f - fabsf(x - xc), wxf = 1.f - fabsf(x - xf);
-        const float wyc = 1.f - fabsf(y - yc), wyf = 1.f - fabsf(y - yf);
-        const int ixc = (int)xc, ixf = (int)xf;
-        // the four corners of occ_corner_kernel, in its order; clamped (out-of-frame) corners carry weight 0
-        if (inc) {
-            if (!(xco || yco)) { const float v = wxc * wyc; if (v != 0.f) atomicAdd(&band[(iyc - r0) * W + ixc], v); }
-            if (!(xfo || yco)) { const float v = wxf * wyc; if (v != 0.f) atomicAdd(&band[(iyc - r0) * W + ixf], v); }
-        }
-        if (inf) {
-            if (!(xco || yfo)) { const float v = wxc * wyf; if (v != 0.f) atomicAdd(&band[(iyf - r0) * W + ixc], v); }
-            if (!(xfo || yfo)) { const float v = wxf * wyf; if (v != 0.f) atomicAdd(&band[(iyf - r0) * W + ixf], v); }
+    // four consecutive pixels per thread and sweep (16-byte loads of both components: the scan is bound by load latency);
+    // n is a multiple of 4 (host check)
+    for (int p4 = threadIdx.x * 4; p4 < n; p4 += blockDim.x * 4) {
+        const float4 vx = *reinterpret_cast<const float4*>(fx + p4), vy = *reinterpret_cast<const float4*>(fy + p4);
+        const float ax[4] = {vx.x, vx.y, vx.z, vx.w}, ay[4] = {vy.x, vy.y, vy.z, vy.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int pix = p4 + j;
+            const int py = pix / W, px = pix - py * W;
+            const float y = (float)py + ay[j];
+            const float y1 = floorf(y);
+            // rows this pixel can touch: y1 and y1 + 1 after clamping -- skip when neither is in the band
+            const float yf = fminf(fmaxf(y1, 0.f), hm), y0 = y1 + 1.f, yc = fminf(fmaxf(y0, 0.f), hm);
+            const int iyf = (int)yf, iyc = (int)yc;
+            const bool inf = iyf >= r0 && iyf < r1, inc = iyc >= r0 && iyc < r1;
+            if (!inf && !inc) continue;
+            const float x = (float)px + ax[j];
+            const float x1 = floorf(x);
+            const float xf = fminf(fmaxf(x1, 0.f), wm), x0 = x1 + 1.f, xc = fminf(fmaxf(x0, 0.f), wm);
+            const bool xco = x0 != xc, yco = y0 != yc, xfo = x1 != xf, yfo = y1 != yf;
+            const float wxc = 1.f - fabsf(x - xc), wxf = 1.f - fabsf(x - xf);
+            const float wyc = 1.f - fabsf(y - yc), wyf = 1.f - fabsf(y - yf);
+            const int ixc = (int)xc, ixf = (int)xf;
+            // the four corners of occ_corner_kernel; clamped (out-of-frame) corners carry weight 0
+            if (inc) {
+                if (!(xco || yco)) { const float v = wxc * wyc; if (v != 0.f) atomicAdd(&band[(iyc - r0) * W + ixc], v); }
+                if (!(xfo || yco)) { const float v = wxf * wyc; if (v != 0.f) atomicAdd(&band[(iyc - r0) * W + ixf], v); }
+            }
+            if (inf) {
+                if (!(xco || yfo)) { const float v = wxc * wyf; if (v != 0.f) atomicAdd(&band[(iyf - r0) * W + ixc], v); }
+                if (!(xfo || yfo)) { const float v = wxf * wyf; if (v != 0.f) atomicAdd(&band[(iyf - r0) * W + ixf], v); }
+            }
         }
     }
     __syncthreads();
@@ -166,10 +175,12 @@ extern "C" int emip_occ_mask_backward(const float* flow, float* cmap_ws, float* 
     EMIP_REQUIRE(flow && occ && B > 0 && H > 1 && W > 1 && (long)H * W < (1L << 24));
     hipStream_t s = (hipStream_t)stream;
     const long total = (long)B * H * W;
-    if ((size_t)OCC_TH * W * sizeof(float) <= 64 * 1024 && B < 65536) {
-        // band form: no workspace (cmap_ws may be NULL), one launch
-        hipLaunchKernelGGL(occ_band_kernel, dim3((H + OCC_TH - 1) / OCC_TH, B), dim3(512), (size_t)OCC_TH * W * sizeof(float), s,
-                           flow, occ, H, W, th, complement);
+    // bands of 32 rows (45 KB of LDS at W = 352: three workgroups per CU keep enough loads in flight; four bands of 88 rows,
+    // one workgroup per CU, took 487 us against 305)
+    const int TH = 32;
+    if ((size_t)TH * W * sizeof(float) <= 64 * 1024 && B < 65536 && ((long)H * W) % 4 == 0 && aligned16(flow)) {
+        hipLaunchKernelGGL(occ_band_kernel, dim3((H + TH - 1) / TH, B), dim3(512), (size_t)TH * W * sizeof(float), s, flow, occ,
+                           H, W, TH, th, complement);
         return emip_launch_status();
     }
     EMIP_REQUIRE(cmap_ws);
