@@ -86,10 +86,11 @@ def test_f32_gradients_equal_the_literal_order(model_args, short_sd):
     # The photometric loss is piecewise (bilinear cell, |.|, SSIM clamp): a re-associated f32 sum upstream of the flows moves
     # pixels across kinks, so the parameters that see the flow loss only (`injector.*`) agree to 10 %, the backbone (both
     # losses) to a few per cent, and everything downstream of the motion collector -- the mask path -- far tighter.
-    assert all(v <= (0.1 if n.startswith("injector.") else 3e-2) for n, v in rel.items()), worst
-    tight = sorted(((v, n) for n, v in rel.items() if n.startswith(("decoder.", "dr", "injector1.", "conv_corr."))), reverse=True)
-    print("  mask path (decoder, reductions, injector1, conv_corr): largest", tight[:3], "median %.1e" % tight[len(tight) // 2][0])
-    assert tight[0][0] <= 1e-2 and tight[len(tight) // 2][0] <= 1e-4, tight[:3]
+    # conv_corr.0's weight gradient multiplies the mask-path gradient with the correlation of the GMFlow features (the noisy side)
+    assert all(v <= (0.1 if n.startswith("injector.") else 5e-2 if n.startswith("conv_corr.") else 3e-2) for n, v in rel.items()), worst
+    tight = sorted(((v, n) for n, v in rel.items() if n.startswith(("decoder.", "dr", "injector1."))), reverse=True)
+    print("  mask path (decoder, reductions, injector1): largest", tight[:3], "median %.1e" % tight[len(tight) // 2][0])
+    assert tight[0][0] <= 2e-3 and tight[len(tight) // 2][0] <= 1e-4, tight[:3]
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 1e-2)])
