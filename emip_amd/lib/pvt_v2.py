@@ -420,14 +420,12 @@ class PyramidVisionTransformerV2(EmipModule):
             setattr(self, f"norm{i + 1}", norm_layer(embed_dims[i]))
             cur += depths[i]
 
-    def run(self, x, deep=None, first=0, last=None):
+    def run(self, x, deep=None):
         """x: channels-last image [B,H,W,8] -> list of the 4 stage outputs, channels-last.
         deep = (lo, hi): only the images lo .. hi - 1 of the batch go on past stage 2 (the outputs of stages 3 and 4 then hold
-        hi - lo images) -- for callers that read the deep features of part of the batch only (CoUpdater.run).
-        first / last: run stages first .. last - 1 only (x = the previous stage's output when first > 0) and return their outputs:
-        the caller may place other work between the shallow and the deep stages."""
+        hi - lo images) -- for callers that read the deep features of part of the batch only (CoUpdater.run)."""
         outs = []
-        for i in range(first, self.num_stages if last is None else last):
+        for i in range(self.num_stages):
             if i == 2 and deep is not None:
                 x = x[deep[0]:deep[1]]
             pe = getattr(self, f"patch_embed{i + 1}")

@@ -36,8 +36,6 @@ CONV_CORR_FACTORED = True
 # forward and (zero gradient) in the backward.  True: those stages run on the frame whose deep features are read (frame 1;
 # frame 2 for EMIP-long's steps, model_long.py:71,89-90,113-116).  Outputs and gradients are the reference's; False: literal order.
 PVT_DEEP_ONE_FRAME = True
-# eval: run PVT stages 3-4 (a long chain of small launches) BEHIND the motion path instead of in front of it
-DEEP_LAST = False
 
 class CoUpdater(EmipModule):
     def __init__(self, args=None):
@@ -182,12 +180,11 @@ class CoUpdater(EmipModule):
             ops.planar_to_cl(image2.contiguous(), dt, 8, out=imgs[B:])
         # stage 2 of both frames; stages 3, 4 of the frame whose deep features are read (tail=False: EMIP-long reads frame 2's)
         deep = ((0, B) if tail else (B, 2 * B)) if PVT_DEEP_ONE_FRAME else None
-        late = DEEP_LAST and tail and not torch.is_grad_enabled() and not self.training
         if CNN_FIRST:
             gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
-            fea = self.backbone.feat_net.run(imgs, deep=deep, last=2 if late else None)
+            fea = self.backbone.feat_net.run(imgs, deep=deep)
         else:
-            fea = self.backbone.feat_net.run(imgs, deep=deep, last=2 if late else None)
+            fea = self.backbone.feat_net.run(imgs, deep=deep)
             gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
         ab = self.injector.run(gm, fea[0])                             # camouflage feeder (shared weights)
         if torch.is_grad_enabled() and ab.requires_grad:
@@ -207,8 +204,6 @@ class CoUpdater(EmipModule):
         if not tail:
             self.last = dict(fea=fea, gm=gm, ab=ab, corr=corr, conv_corr=cc)
             return None, preds
-        if late:
-            fea = list(fea) + list(self.backbone.feat_net.run(fea[0], deep=deep, first=2))
         fea_new = self.injector1.run(fea[0][:B], cc)
         f1 = self.dr1.run(fea_new)
         f2 = self.dr2.run(fea[1][:B])
