@@ -389,7 +389,8 @@ def report_rows(out, world):
              "achieved_TFLOPs": out.get("end_to_end", {}).get("achieved_TFLOPs"),
              "frac_of_bf16_mfma_peak": out.get("end_to_end", {}).get("frac_of_bf16_mfma_peak"),
              "mask_max_abs_err_f32_mode": par.get("mask_logit_max_abs_err_f32_vs_cpu_ref"),
-             "mask_iou_vs_ref": par.get("mask_iou_bf16_vs_cpu_ref"), "warp_indices": None}]
+             "mask_iou_vs_ref": par.get("mask_iou_bf16_vs_cpu_ref"), "warp_indices": None,
+             "rate_in_the_references_literal_order": (out.get("literal_order") or {}).get("value")}]
     t = out.get("train")
     if isinstance(t, dict) and "value" in t:
         rows.append({"config": "short train step B=32 bf16 (configs[2]%s)" % (" / DP configs[4]" if world > 1 else ""),
@@ -499,6 +500,45 @@ def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allre
     del net, opt, red
     torch.cuda.empty_cache()
     return rec
+
+
+def measure_literal_order(net, B, im1, im2, dev, inflight, steps=12, warmup=4):
+    """The same 16-pair step with the two re-orderings of the product path switched off -- PVT stages 3-4 on BOTH frames and
+    conv_corr.0 as a 3 x 3 convolution over the materialised correlation volume, i.e. the reference's forward as written
+    (model.py:86-102) -- timed the same way (whole-batch graphs, steps in flight), and the bf16 masks of the two orders on the
+    same pairs.  The headline is the product order; this record is the like-for-like yardstick beside it."""
+    import emip_amd.model.EMIP_short.model as M
+    from emip_amd.graph import PipelinedShort
+    old = (M.PVT_DEEP_ONE_FRAME, M.CONV_CORR_FACTORED)
+    M.PVT_DEEP_ONE_FRAME = M.CONV_CORR_FACTORED = False
+    try:
+        r = PipelinedShort(net, B, inflight=inflight, device=dev)
+        r.load(im1, im2)
+        for _ in range(warmup):
+            r.replay_free()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r.replay_free()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        with torch.no_grad():
+            lit = net.run(im1[:4], im2[:4])[0].float().clone()
+        del r
+    finally:
+        M.PVT_DEEP_ONE_FRAME, M.CONV_CORR_FACTORED = old
+    with torch.no_grad():
+        prod = net.run(im1[:4], im2[:4])[0].float()
+        again = net.run(im1[:4], im2[:4])[0].float()
+    iou = lambda a, b: float(((a > 0) & (b > 0)).sum().item() + 1e-9) / float(((a > 0) | (b > 0)).sum().item() + 1e-9)
+    torch.cuda.empty_cache()
+    return {"value": round(B * steps / dt, 1), "unit": "pairs/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "what": "the reference's forward as written: PVT stages 3-4 on both frames (model.py:87-88; fea_2[1:] is never read) and "
+                    "conv_corr.0 over the materialised correlation volume (model.py:59,96), same graphs / steps in flight",
+            "max_abs_dlogit_product_vs_literal_bf16": round((prod - lit).abs().max().item(), 3),
+            "mask_iou_product_vs_literal_bf16": round(iou(prod, lit), 5),
+            "max_abs_dlogit_product_run_to_run_bf16": round((prod - again).abs().max().item(), 3),
+            "flops_per_pair_gflop": {"literal": F_ALG_PAIR_GFLOP, "product": round(F_EXEC_PAIR_GFLOP, 2)}}
 
 
 def main_train(args):
@@ -909,6 +949,11 @@ def main():
         if not args.no_graph:
             del runner
         torch.cuda.empty_cache()
+        if world == 1 and not args.no_graph and args.inflight > 1:
+            try:
+                sub["literal_order"] = measure_literal_order(net, B, im1, im2, dev, args.inflight)
+            except Exception as e:                               # noqa: BLE001
+                sub["literal_order"] = {"error": repr(e)[:300]}
         try:
             sub["train"] = measure_train(32, 6, 4, world, rank, dev, dist, red_dev, args.dp_algo, args.dp_comm)
         except Exception as e:                                   # noqa: BLE001

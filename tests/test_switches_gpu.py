@@ -116,6 +116,9 @@ def test_training_switch(model_args, short_sd, modname, attr, value):
         ref = g0[n].abs().max().item() + 1e-12
         jit = (g0b[n] - g0[n]).abs().max().item() / ref
         d = (g1[n] - g0[n]).abs().max().item() / ref
-        print(f"  {attr} = {value!r} {n}: rel {d:.4f} (two default runs: {jit:.4f})")
-        assert d <= 3.0 * jit + 0.12, (n, d, jit)
+        cos = torch.nn.functional.cosine_similarity(g1[n].flatten(), g0[n].flatten(), dim=0).item()
+        print(f"  {attr} = {value!r} {n}: rel {d:.4f} (two default runs: {jit:.4f}), cosine {cos:.4f}")
+        # the bf16 step is bimodal (tests/test_repack_gpu.py): two default runs can coincide to 1e-7 while a third lands 10-20 %
+        # away, so the band has a floor; the direction of the gradient is the sharper check against a wrong backward
+        assert d <= 3.0 * jit + 0.3 and cos >= 0.95, (n, d, jit, cos)
     assert abs(l1[0] - l0[0]) <= 3.0 * abs(l0b[0] - l0[0]) + 0.05 * abs(l0[0])
