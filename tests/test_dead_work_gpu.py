@@ -130,3 +130,23 @@ def test_conv_corr0_fn_matches_the_literal_volume_convolution(dtype, tol):
         d = ((a - b).abs().max() / (b.abs().max() + 1e-20)).item()
         print(f"  {dtype}: {name} relative max difference {d:.2e}")
         assert d <= tol, (name, d)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,H,W,C", [(2, 44, 44, 128), (3, 7, 5, 16), (1, 1, 9, 8)])
+def test_patch_matrix_and_its_adjoint(dtype, B, H, W, C):
+    """emip_im2col3x3 against torch unfold (tap-major columns, zero padding) and emip_col2im3x3 against its autograd adjoint"""
+    from emip_amd import ops
+    torch.manual_seed(H * W + C)
+    x = torch.randn(B, H, W, C, device="cuda").to(dtype)
+    pm = ops.im2col3x3(x)                                                   # [B, H W, 9 C]
+    unf = torch.nn.functional.unfold(x.float().permute(0, 3, 1, 2), 3, padding=1)          # [B, C * 9, H W], channel-major
+    ref = unf.view(B, C, 9, H * W).permute(0, 3, 2, 1).reshape(B, H * W, 9 * C)            # -> tap-major columns
+    assert torch.equal(pm.float(), ref.to(dtype).float())
+    dy = torch.randn(B, H * W, 9 * C, device="cuda").to(dtype)
+    dx = ops.col2im3x3(dy, B, H, W, C)
+    xr = x.float().requires_grad_(True)
+    u = torch.nn.functional.unfold(xr.permute(0, 3, 1, 2), 3, padding=1).view(B, C, 9, H * W).permute(0, 3, 2, 1).reshape(B, H * W, 9 * C)
+    u.backward(dy.float())
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    assert (dx.float().view(B, H, W, C) - xr.grad).abs().max() <= tol * max(1.0, xr.grad.abs().max().item())
