@@ -160,8 +160,9 @@ class CoUpdater(EmipModule):
             corr = torch.empty((B, n, n), dtype=c0.dtype, device=c0.device)
             if c0.dtype == torch.bfloat16 and C == 128:
                 ops.match(c0[:B], c0[B:], wdt, C ** -0.5, scores=corr)
-            else:
-                corr = torch.matmul(c0[:B].float(), c0[B:].float().transpose(1, 2)).mul_(C ** -0.5).to(c0.dtype)
+            else:       # f32 mode: F0 F1^T per image on the library's own batched GEMM, then the scale
+                ops.gemm_batched(c0[:B], c0[B:], corr, B, n, n, C, C, C, n, n * C, n * C, n * n)
+                corr.mul_(C ** -0.5)
             L["corr"] = corr
         return L["corr"]
 
