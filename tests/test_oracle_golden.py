@@ -209,3 +209,53 @@ def test_short_eval_flow_well_conditioned(golden, short_sd):
     assert (fw[0][:, :, ::4, ::4] - torch.from_numpy(g["fw"])).abs().max().item() < 1e-3
     assert (bw[0][:, :, ::4, ::4] - torch.from_numpy(g["bw"])).abs().max().item() < 1e-3
     assert (m[:, :, ::4, ::4] - torch.from_numpy(g["mask"])).abs().max().item() < 1e-3
+
+
+def test_the_forward_reads_only_stage_two_of_the_second_frame(short_sd, monkeypatch):
+    """The audit behind CoUpdater's PVT_DEEP_ONE_FRAME, on the oracle (the restatement of model/EMIP_short/model.py:86-102 the
+    fixtures above pin): stages 3 and 4 of the SECOND frame are not connected to any output.  The backbone's outputs are
+    replaced by autograd leaves; after a backward from mask + both flows the leaves of fea_2[1], fea_2[2] carry NO gradient
+    (not a small one: none, they are outside the graph), fea_2[0], fea_1[0..2] do."""
+    im1, im2 = synthetic_pair(1, seed=5)
+    real = O.pvt_forward
+    leaves = []
+
+    def tapped(img, sd, p, drop=None):
+        with torch.no_grad():
+            outs = real(img, sd, p, drop)
+        outs = [o.clone().requires_grad_(True) for o in outs]
+        leaves.append(outs)
+        return outs
+    monkeypatch.setattr(O, "pvt_forward", tapped)
+    mask, fw, bw = O.short_forward(im1, im2, short_sd)
+    (mask.sum() + fw[-1].sum() + bw[-1].sum()).backward()
+    f1, f2 = leaves                                  # 4 stage outputs each; the forward takes [1:]
+    assert all(t.grad is not None and t.grad.abs().max() > 0 for t in f1[1:]), "frame 1: stages 2, 3, 4 are read"
+    assert f2[1].grad is not None and f2[1].grad.abs().max() > 0, "frame 2: stage 2 is read (the camouflage feeder's prompt)"
+    assert f2[2].grad is None and f2[3].grad is None, "frame 2: stages 3 and 4 feed nothing"
+    assert f1[0].grad is None and f2[0].grad is None            # stage 1's output is only the next stage's input
+
+
+def test_the_long_step_reads_only_stage_two_of_the_first_frame(long_sd, monkeypatch):
+    """... and the mirror image for Model_long from frame 1 on (model_long.py:89-90,113-116): the deep stages of the FIRST frame
+    feed only the short-term mask, which the step discards.  The short-term part runs under no_grad there, so the audit
+    perturbs instead: with stages 3 and 4 of frame 0 replaced by noise the step's outputs (mask, keys, values) are bit-identical."""
+    f0, f1 = synthetic_pair(1, seed=9)
+    real = O.pvt_forward
+    with torch.no_grad():
+        ref = O.long_forward(f0[0], f1[0], 1, None, None, long_sd)
+    calls = []
+
+    def spoiled(img, sd, p, drop=None):
+        outs = list(real(img, sd, p, drop))
+        calls.append(len(calls))
+        if len(calls) == 1:                       # the first call is frame 0 (short_forward: fea_1, then fea_2)
+            outs[2] = torch.randn_like(outs[2]) * 7.0
+            outs[3] = torch.randn_like(outs[3]) * 7.0
+        return outs
+    monkeypatch.setattr(O, "pvt_forward", spoiled)
+    with torch.no_grad():
+        got = O.long_forward(f0[0], f1[0], 1, None, None, long_sd)
+    assert len(calls) == 2
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
