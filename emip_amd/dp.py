@@ -10,8 +10,12 @@ tensors never receive gradients (dead modules, GMFlow adaptor parameters) and GM
     train, in gradient-ready order (so bucket k is complete -- and its exchange in flight -- while backward still works on
     the layers of bucket k+1; `conv_corr.0.weight`, 67 MB and ready early, travels alone and first).  Parameters that
     never received a gradient are not exchanged; whether any of them got one later is agreed on by a one-word MAX
-    all-reduce per step, and then ALL of them travel in a trailing bucket (zeros where a rank has none), so every rank
-    issues the same collectives whatever its local graph looked like;
+    all-reduce per step ON THE HOST (a gloo control group beside the RCCL one: the local answer is host knowledge --
+    `p.grad is not None` -- so nothing waits for the device), and then ALL of them travel in a trailing bucket (zeros
+    where a rank has none).  Regular buckets leave strictly in index order -- bucket k only once bucket k-1 has left,
+    the rest from finish() -- and a parameter of a regular bucket without a gradient on some rank takes part with
+    zeros there, so every rank issues the same collectives in the same order and receives the same mean whatever its
+    local graph looked like;
   * the buckets are slices of ONE flat transport buffer.  A bucket costs one launch on the way out (emip_grad_pack: a
     table-driven gather of its ~150 gradient tensors, f32 or bf16 on the wire) and the whole step ONE launch on the way
     back (emip_grad_unpack: every `.grad` <- flat slice / world).  The tables are static after calibration; the gradient
@@ -79,11 +83,22 @@ def _make_buckets(order, bucket_bytes, world):
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=64 << 20, group=None, comm_dtype=None, algo="allreduce", record_events=False):
+    def __init__(self, params, bucket_bytes=64 << 20, group=None, comm_dtype=None, algo="allreduce", record_events=False,
+                 single_rank_collectives=False):
+        """single_rank_collectives: with a process group of ONE rank, still run every pack / collective / unpack (a mean
+        over one rank: the gradients come back unchanged) -- the hardware rehearsal of the RCCL calls on a one-GPU box
+        (tests/test_dp_gpu.py); without it a world of one skips the exchange altogether."""
         assert algo in ("allreduce", "direct")
         assert comm_dtype in (None, torch.float32, torch.bfloat16)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.exchange = self.world > 1 or (single_rank_collectives and dist.is_available() and dist.is_initialized())
+        # control group for host-side agreement (the late-bucket decision): gloo, so that a one-word MAX over the ranks
+        # costs an inter-process round trip and no device synchronisation.  A gloo default group serves as it is.
+        self._ctl = group
+        if self.exchange and dist.get_backend(group) != "gloo":
+            self._ctl = dist.new_group(ranks=dist.get_process_group_ranks(group) if group is not None else None,
+                                       backend="gloo")
         self.comm_dtype = comm_dtype or torch.float32
         self.algo = algo
         self.bucket_bytes = bucket_bytes
@@ -102,6 +117,7 @@ class GradReducer:
         self._kev = []                      # record_events: (start, end) event pairs around the pack / unpack launches
         self._side = None
         self._late = None                   # the trailing bucket of the calibration step's dead parameters (built on demand)
+        self._next = 0                      # index of the next regular bucket to leave (buckets leave in index order)
         self._rebind()
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
@@ -157,7 +173,7 @@ class GradReducer:
             if i not in self._seen:         # a second backward before finish() (gradient accumulation) logs nothing new
                 self._seen.add(i)
                 self.ready_order.append(i)
-        if self.world == 1:
+        if not self.exchange:
             return
         bi = self._where.get(p)
         if bi is None:                      # a parameter the calibration step saw without gradient: trailing bucket in finish()
@@ -166,8 +182,12 @@ class GradReducer:
         if b.launched:                      # gradient accumulation: a later backward re-arms nothing; finish() sends what is there
             return
         b.pending -= 1
-        if b.pending == 0:
-            self._launch(b, bi)
+        # strictly in index order (as DDP does): a rank whose local graph completes bucket k before bucket k-1 -- or
+        # lacks one of k-1's gradients altogether, which finish() then supplies as zeros -- must not enqueue k's
+        # collective ahead of k-1's on the shared communicator
+        while self._next < len(self.buckets) and self.buckets[self._next].pending <= 0:
+            self._launch(self.buckets[self._next], self._next)
+            self._next += 1
 
     def _stream(self, dev):
         if dev.type != "cuda":
@@ -178,6 +198,13 @@ class GradReducer:
 
     def _pack(self, b, dev):
         """gradients of bucket b -> its slice of the flat buffer (runs on the side stream)"""
+        if self.calibrated:
+            for p in b.params:
+                if p.grad is None:
+                    # no gradient on THIS rank (a branch its local graph did not take): it sends zeros and receives the mean
+                    # like every other rank (what DDP writes back); left at None the other ranks would step the parameter
+                    # alone.  (The calibration step leaves None alone: those parameters are about to be declared dead.)
+                    p.grad = torch.zeros(p.shape, dtype=torch.float32 if dev.type == "cuda" else p.dtype, device=dev)
         if dev.type != "cuda":
             for p, off in zip(b.params, b.offsets):
                 seg = self._flat[b.lo + off:b.lo + off + p.numel()]
@@ -289,19 +316,21 @@ class GradReducer:
 
     def finish(self):
         """Complete the step: exchange what is still pending, wait, average, write the gradients back."""
-        if self.world > 1 and self.buckets:
+        if self.exchange and self.buckets:
             dev = self.buckets[0].params[0].device
             self._ensure(dev)
-            for bi, b in enumerate(self.buckets):
-                if not b.launched:
-                    self._launch(b, bi)
+            for bi in range(self._next, len(self.buckets)):      # what backward did not complete, still in index order
+                self._launch(self.buckets[bi], bi)
+            self._next = len(self.buckets)
             late = False
             if self._late is not None:
                 # did ANY rank give a calibration-dead parameter a gradient this step?  One word, MAX over the ranks: the
-                # decision is the same everywhere, whatever the local graphs looked like
-                flag = torch.tensor([float(any(p.grad is not None for p in self.dead))], device=dev)
-                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
-                late = bool(flag.item() > 0)
+                # decision is the same everywhere, whatever the local graphs looked like.  The local answer is host
+                # knowledge and the word travels over the gloo control group: the device is not waited for (round 3 read a
+                # device tensor back here, a host <-> device synchronisation at the end of every backward)
+                flag = torch.tensor([float(any(p.grad is not None for p in self.dead))])
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._ctl)
+                late = bool(flag[0] > 0)
             if late:
                 for p in self._late.params:              # ranks without a gradient for it take part with zeros
                     if p.grad is None:
@@ -320,6 +349,7 @@ class GradReducer:
     def _reset(self):
         for b in self._all_buckets():
             b.pending, b.work, b.launched = len(b.params), None, False
+        self._next = 0
 
     def _calibrate(self):
         """after the first step: buckets = the parameters that received a gradient, in the order they became ready (rank 0's

@@ -65,8 +65,15 @@ class GradArena:
             self.buf[:self.limit].zero_()
         self.cursor, self.need, self.active = 0, 0, True
 
-    def end(self):
+    def end(self, failed=False):
+        """failed: the step raised somewhere between begin() and here.  Deferred results then have no complete set of
+        `.grad` tensors to live in, and their arena slices are re-carved by the next begin(): everything queued is DROPPED
+        (WgradQueue.reset) instead of being flushed into gradients the caller will not use -- a fixup() that raises here
+        would mask the original exception and leave stale entries for the next step to add to fresh gradients."""
         self.active = False
+        if failed:
+            WGRADS.reset()
+            return
         WGRADS.flush()                       # nothing deferred outlives the step
         WGRADS.fixup()                       # ... and every deferred result is what its parameter's .grad holds
 
@@ -123,6 +130,10 @@ class WgradQueue:
         if len(self.items) >= self.MAX:
             self.flush()
 
+    def reset(self):
+        """drop everything queued or registered (the exception path of a training step): no launch, no gradient touched"""
+        self.items, self.owners, self.post = [], [], []
+
     def fixup(self, params=None):
         """A deferred result is written into its arena slice AFTER autograd has taken that (still zero) slice as the
         parameter's gradient.  That is only the gradient if AccumulateGrad kept the slice itself as `.grad` -- it does for
@@ -133,31 +144,31 @@ class WgradQueue:
         if not self.owners and not self.post:
             return
         assert not self.items, "fixup() runs behind flush()"
-        keep = []
         only = None if params is None else {id(p) for p in params}
-        later = []
-        for t, p, unpack in self.post:             # convolution gradients: packed [Cout][ky][kx][ci] -> the parameter's layout
+        # the lists are taken over first: whatever happens below (a final fixup that finds a parameter without .grad
+        # raises), no entry of this step survives into the next one, whose arena slices hold other tensors
+        post, owners, self.post, self.owners = self.post, self.owners, [], []
+        later, keep, orphan = [], [], None
+        for t, p, unpack in post:                  # convolution gradients: packed [Cout][ky][kx][ci] -> the parameter's layout
             if (only is not None and id(p) not in only) or (p.grad is None and params is not None):
                 later.append((t, p, unpack))
-                continue
-            if p.grad is None:
-                raise _lib.EmipLibraryError("a deferred weight gradient has no parameter .grad to live in")
-            p.grad.add_(unpack(t).to(p.grad.dtype))
-        self.post = later
-        for t, p in self.owners:
-            if only is not None and id(p) not in only:
-                keep.append((t, p))
-                continue
+            elif p.grad is None:
+                orphan = p
+            else:
+                p.grad.add_(unpack(t).to(p.grad.dtype))
+        for t, p in owners:
             g = p.grad
-            if g is None:
-                if params is None:
-                    raise _lib.EmipLibraryError("a deferred weight gradient has no parameter .grad to live in")
+            if (only is not None and id(p) not in only) or (g is None and params is not None):
                 keep.append((t, p))
-                continue
-            if g.data_ptr() != t.data_ptr() or g.numel() != t.numel():
+            elif g is None:
+                orphan = p
+            elif g.data_ptr() != t.data_ptr() or g.numel() != t.numel():
                 g.add_(t.view_as(g).to(g.dtype))
                 self.fixed += 1
-        self.owners = keep
+        if params is not None:                     # a partial fixup (one gradient bucket): the rest stays registered
+            self.post, self.owners = later, keep
+        if orphan is not None:
+            raise _lib.EmipLibraryError("a deferred weight gradient has no parameter .grad to live in")
 
     def flush(self):
         if not self.items:

@@ -41,6 +41,7 @@ def train_step(model, optimizer, reducer, image1, image2, gts):
     """train.py:43-62.  Returns (loss, loss_pred, loss_flow) as 0-dim device tensors (no host sync here)."""
     optimizer.zero_grad(set_to_none=True)
     ops.ARENA.begin(image1.device)          # one fill clears every gradient accumulator of this step (ops.GradArena)
+    failed = True
     try:
         with torch.enable_grad():
             preds = model(image1, image2)
@@ -51,8 +52,9 @@ def train_step(model, optimizer, reducer, image1, image2, gts):
             loss = loss_pred + loss_flow
             loss.backward()
             ops.flush_wgrads()                  # the Linear weight gradients backward deferred, as one grouped launch
+        failed = False
     finally:
-        ops.ARENA.end()
+        ops.ARENA.end(failed)               # on an exception: the deferred queue is dropped, the original error propagates
     if reducer is not None:
         reducer.finish()
     optimizer.step()

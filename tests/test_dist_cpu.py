@@ -101,6 +101,21 @@ def _dp_worker(rank, world, port, out, algo, comm):
     (net(x).pow(2).sum() + (dead * (rank + 1.0)).sum()).backward()
     red.finish()
     assert torch.allclose(dead.grad, torch.full((3,), 1.5)), dead.grad
+    # a rank whose local graph lacks gradients of REGULAR buckets (rank 1 skips the two last layers here, so
+    # their buckets -- the first ones in ready order -- never complete in its hooks while later buckets do) must still issue
+    # the same collectives in the same order and end with the same mean as rank 0 (zeros for what it did not compute)
+    for p in params:
+        p.grad = None
+    red.begin_step()
+    if rank == 0:
+        net(x).pow(2).sum().backward()
+    else:
+        net[1](net[0](x)).pow(2).sum().backward()
+    mine = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+    in_bwd = list(red.launch_log)
+    red.finish()
+    out.put((rank, "skip", [None if t is None else t.numpy() for t in mine], in_bwd, list(red.launch_log),
+             [p.grad.clone().numpy() for p in net.parameters()]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -113,10 +128,12 @@ def test_grad_reducer_two_ranks_mean_and_unused_params(algo, comm):
     ps = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, algo, comm)) for r in range(2)]
     for p in ps:
         p.start()
-    res = sorted((q.get(timeout=120) for _ in ps), key=lambda t: t[0])
+    got = [q.get(timeout=120) for _ in range(4)]
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
+    res = sorted((t for t in got if not isinstance(t[1], str)), key=lambda t: t[0])
+    skip = sorted((t for t in got if isinstance(t[1], str)), key=lambda t: t[0])
     (_, w0a, la, ra, da, nb, oa, lda, lfa, l2a, r2a), (_, w0b, lb, rb, db, _, ob, ldb, lfb, l2b, r2b) = res
     import numpy as np
     tol = 1e-6 if comm == "f32" else 2e-2                          # bf16 transport: 8-bit mantissa on the wire, f32 sums
@@ -131,6 +148,14 @@ def test_grad_reducer_two_ranks_mean_and_unused_params(algo, comm):
     assert oa == ob and oa[0] in (4, 5) and oa[-1] in (0, 1)
     assert lda == ldb and lfa == lfb == list(range(nb))
     assert lda == list(range(len(lda))) and len(lda) >= nb - 1
+    # the step in which rank 1 skipped two layers: same launch order on both ranks (index order; rank 1 launched nothing
+    # out of order from its hooks), same result on both, = rank 0's gradient / 2 where rank 1 had none, the mean elsewhere
+    (_, _, m0, b0, f0, r0), (_, _, m1, b1, f1, r1) = skip
+    assert f0 == f1 == list(range(nb)) and b1 == list(range(len(b1))) and len(b1) < nb
+    assert sum(t is None for t in m1) == 4 and all(t is not None for t in m0)
+    for a, b, x, y in zip(m0, m1, r0, r1):
+        want = a / 2 if b is None else (a + b) / 2
+        assert np.allclose(x, want, atol=tol * max(1.0, np.abs(a).max())) and np.array_equal(x, y)
 
 
 def _bench(*argv, env=None):

@@ -1,6 +1,9 @@
 """Data-parallel training step on the device, 2 ranks (gloo transport, both ranks on cuda:0): with different data per
 rank, the gradients the reducer leaves in `.grad` are the MEAN of the two ranks' gradients (checked against a single
-process that runs both samples), and after the optimizer step the replicas hold identical parameters."""
+process that runs both samples), and after the optimizer step the replicas hold identical parameters.
+The RCCL calls themselves (backend "nccl": all_reduce / all_to_all_single / all_gather_into_tensor on device tensors, the
+side-stream ordering) run in the one-rank tests at the end of this file: a one-GPU box cannot host two RCCL ranks, so the
+two-rank tests carry the arithmetic over gloo and the one-rank tests carry the transport.  No scaling curve exists yet."""
 import json
 import os
 
@@ -9,6 +12,13 @@ import torch
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
 HERE = os.path.dirname(os.path.abspath(__file__))
 NAMES = ["decoder.conv5.weight", "backbone.feat_net.pvtv2_en.block3.7.mlp.fc1.weight", "conv_corr.3.bias",
          "injector.transformer.attn.temperature"]
@@ -258,7 +268,7 @@ def test_two_rank_bf16_training_step_through_the_reducer(algo, comm):
 def test_gradient_bucket_kernels_roundtrip_and_cost():
     """emip_grad_pack / emip_grad_unpack / emip_shard_sum alone, one process: 1 300 ragged gradient tensors (100 M elements,
     the EMIP-short payload) into the flat buffer and back -- exact in f32, bf16-rounded on a bf16 wire, missing gradients
-    packed as zeros and left alone on the way back -- one launch per bucket out, ONE launch back, under a millisecond of
+    packed as zeros and given the (zero) mean on the way back -- one launch per bucket out, ONE launch back, under a millisecond of
     device time per step in total"""
     from emip_amd import _lib
     from emip_amd.dp import GradReducer
@@ -269,6 +279,7 @@ def test_gradient_bucket_kernels_roundtrip_and_cost():
     for comm in (torch.float32, torch.bfloat16):
         red = GradReducer(params, comm_dtype=comm, record_events=True)
         red.world = 2                                     # layout for two ranks; no collective is issued in this test
+        red.calibrated = True                             # steady state: a missing gradient takes part as zeros
         red.buckets = __import__("emip_amd.dp", fromlist=["_make_buckets"])._make_buckets(list(reversed(red.params)), 64 << 20, 2)
         red._rebind()
         for i, p in enumerate(params):
@@ -288,8 +299,8 @@ def test_gradient_bucket_kernels_roundtrip_and_cost():
         red._timed(red._unpack, dev, False)
         torch.cuda.synchronize()
         for p, w in zip(params, want):
-            if w is None:
-                assert p.grad is None
+            if w is None:          # no gradient on this rank: it took part with zeros and holds the mean of zeros (as under DDP)
+                assert p.grad is not None and not p.grad.any()
             else:
                 assert torch.equal(p.grad, 0.5 * w.to(comm).float())
         ms = red.kernel_ms()
@@ -302,3 +313,66 @@ def test_gradient_bucket_kernels_roundtrip_and_cost():
     out = torch.empty(1_000_003, dtype=torch.bfloat16, device="cuda")
     _lib.call("emip_shard_sum", x.data_ptr(), out.data_ptr(), 8, x.shape[1], 1, torch.cuda.current_stream().cuda_stream)
     assert torch.allclose(out.float(), x.float().sum(0), rtol=1e-2, atol=1e-2)
+
+
+def _nccl_single_worker(port, out):
+    """world size 1, backend nccl (= RCCL): every collective of the reducer on device tensors, the real training graph"""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from emip_amd.dp import GradReducer, broadcast_parameters
+    from emip_amd.train import trainable
+    res = {}
+    net = _build()
+    broadcast_parameters(net)                      # world 1: returns at once
+    im1, im2, gt = _data(0)
+    for algo, comm in (("allreduce", None), ("direct", torch.bfloat16)):
+        red = GradReducer(trainable(net), algo=algo, comm_dtype=comm, single_rank_collectives=True)
+        assert red.exchange and red.world == 1 and dist.get_backend(red._ctl) == "gloo"
+        worst, in_bwd, nb = 0.0, None, None
+        for step in range(2):                      # step 0 calibrates, step 1 runs the calibrated buckets inside backward
+            for q in net.parameters():
+                q.grad = None
+            red.begin_step()
+            with torch.enable_grad():
+                _loss(net, im1, im2, gt).backward()
+            in_bwd = list(red.launch_log)
+            # buckets that left during backward were packed from .grad and have not been written back yet: .grad is still the
+            # local gradient
+            local = {n: q.grad.detach().clone() for n, q in net.named_parameters() if q.grad is not None}
+            red.finish()
+            torch.cuda.synchronize()
+            nb = len(red.buckets)
+            for n, q in net.named_parameters():
+                if n in local:
+                    d = (q.grad - local[n]).abs().max().item()
+                    worst = max(worst, d / (local[n].abs().max().item() + 1e-30))
+        res[algo] = dict(worst=worst, in_bwd=in_bwd, log=list(red.launch_log), nb=nb, dead=len(red.dead))
+        red.remove()
+    dist.barrier()
+    dist.destroy_process_group()
+    out.put(res)
+
+
+def test_single_rank_rccl_exercises_every_collective_on_device():
+    """the RCCL path had never executed anywhere.  One rank, backend "nccl", the reducer forced
+    through its collectives: all_reduce (f32 wire) and all_to_all_single + emip_shard_sum + all_gather_into_tensor (bf16
+    wire) on device tensors, packed on the side stream while backward is still running, the late-bucket agreement over
+    the gloo control group.  A mean over one rank returns the local gradients: exactly on the f32 wire, to bf16 rounding
+    on the bf16 wire."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_single_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=600)
+    p.join(120)
+    assert p.exitcode == 0
+    a, d = res["allreduce"], res["direct"]
+    print("  single-rank RCCL:", res)
+    assert a["worst"] == 0.0                         # f32 wire, world 1: x * 1.0 -- bit for bit
+    assert d["worst"] < 2 ** -8                      # bf16 wire: one rounding of every element
+    for r in (a, d):
+        assert r["nb"] >= 3 and r["log"] == list(range(r["nb"]))           # index order
+        assert len(r["in_bwd"]) >= r["nb"] - 1                              # all but the last bucket left inside backward
+        assert r["dead"] >= 100                                            # the reference's 108 never-trained tensors

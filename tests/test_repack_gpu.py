@@ -307,3 +307,51 @@ def test_packs_die_with_their_module(model_args, short_sd):
     finally:
         nn_base.set_default_dtype(torch.float32)
 
+
+
+def test_a_step_that_raises_drops_its_deferred_gradients_and_keeps_the_error(model_args, short_sd, monkeypatch):
+    """train_step's `finally` ran flush() + fixup() on the exception path; fixup() then raised its own error
+    (masking the original) and left stale (slice, parameter) entries behind that the NEXT step added to fresh gradients.
+    Now the queue is dropped: the original exception propagates, nothing survives, and the following step's gradients are
+    those of a run that never failed."""
+    from emip_amd import nn_base, ops
+    from emip_amd import train as T
+    from emip_amd.model.EMIP_short.model import CoUpdater
+    nn_base.set_default_dtype(torch.float32)
+    net = CoUpdater(model_args)
+    net.load_state_dict(short_sd)
+    net = T.freeze_like_reference(net.to("cuda:0").train())
+    for m in net.modules():
+        if hasattr(m, "drop_path_rate"):
+            m.drop_path_rate = 0.0
+    opt = T.build_optimizer(net, lr=0.0)           # lr 0: the parameters stay, steps are comparable
+    im1, im2 = synthetic_pair(1, seed=7)
+    gt = synthetic_gt(1, seed=7).cuda()
+    im1, im2 = im1.cuda(), im2.cuda()
+
+    def step_grads():
+        T.train_step(net, opt, None, im1, im2, gt)
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+    step_grads()                                    # sizes the arena
+    ref = step_grads()
+
+    class Boom(RuntimeError):
+        pass
+    real = T.hybrid_e_loss
+
+    def failing(pred, gts):
+        loss = real(pred, gts)
+        loss.backward(retain_graph=False)           # part of the backward has run: deferred results are queued
+        raise Boom("injected")
+    monkeypatch.setattr(T, "hybrid_e_loss", failing)
+    with pytest.raises(Boom):                       # not EmipLibraryError('a deferred weight gradient has no parameter .grad')
+        T.train_step(net, opt, None, im1, im2, gt)
+    assert not ops.WGRADS.items and not ops.WGRADS.owners and not ops.WGRADS.post
+    monkeypatch.setattr(T, "hybrid_e_loss", real)
+    got = step_grads()
+    assert set(got) == set(ref)
+    # a stale addition doubles (or corrupts) whole gradients; the run-to-run band of the f32 step (atomics order) is ~1e-3 of
+    # the gradient norm.  Per-parameter maxima are no yardstick here: some gradients are rounding noise around an exact zero
+    num = sum(((got[n] - ref[n]).double() ** 2).sum().item() for n in ref)
+    den = sum((ref[n].double() ** 2).sum().item() for n in ref)
+    assert (num / den) ** 0.5 < 2e-2, (num / den) ** 0.5
