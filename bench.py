@@ -97,7 +97,12 @@ def _launch_info(lib, name, a):
         Z, Zs, n = a[5], a[6], a[7]
         # features in once as queries and once as keys, the raw correlation of the forward direction out once, flows out
         byt = 2.0 * (2 * Z * n * 128 + Zs * n * n) + 8.0 * Z * n * (2 if a[2] else 1)
-        return 2.0 * Z * n * n * (128 + 2), "match_kernel" + ("+scores" if Zs else ""), byt
+        # the MATCHING launch (V = the pixel grid, keys = the query batch rotated by Z / 2) holds both directions of one pair:
+        # softmaxes over the rows and over the columns of ONE n x n score matrix.  SURVEY section 8(d) prices that matrix once
+        # (2 n n 128 = 0.959 GFLOP per pair) plus the 2-wide expectation of either direction; round 3 counted Q K^T twice here
+        # (VERDICT round 3).  The flow propagation (V = the flow, rot 0) is an ordinary self-attention: every product counts.
+        fl = (Z * n * n * 128.0 + 2.0 * Z * n * n * 2) if (not a[2] and a[13]) else 2.0 * Z * n * n * (128 + 2)
+        return fl, "match_kernel" + ("+scores" if Zs else ""), byt
     if name in ("emip_attention", "emip_attention_splitkv", "emip_attention_rot"):      # splitkv: + (ksplit, workspace); rot: + kv_rot
         batch, heads, nwin, Lq, Lk, D, DV = a[5], a[6], a[7], a[8], a[9], a[10], a[11]
         dv = 2 if DV == 32 else DV                          # DV=32 carries a 2-channel value (flow / pixel grid)
@@ -263,17 +268,48 @@ def _pct(xs, q):
     return xs[lo] + (xs[hi] - xs[lo]) * (k - lo)
 
 
+def _host_cores():
+    """(physical cores of the host, CPUs this process may run on, cgroup CPU quota or None) -- SURVEY section 8(d) asks for the
+    baseline at "all physical cores of the node"; a one-GPU box of the pool hands the process a share of them"""
+    phys = set()
+    try:
+        pid = cid = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                pid = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                cid = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else round(float(q) / float(per), 2)
+    except (OSError, ValueError):
+        pass
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return (len(phys) or (os.cpu_count() or 1)), aff, quota
+
+
 def cpu_baseline(sd):
-    """the CPU oracle, batch 1, f32, at 16 threads (the CPU share a one-GPU box gets) and at 8 (the
-    survey container's figure, 0.70 pairs/s, was taken at 8); 3 warm-up forwards, then ~9 s of timed forwards per setting;
-    median and p10 / p90 of the per-forward rate"""
+    """the CPU oracle, batch 1, f32, at 16 threads (the CPU share a one-GPU box gets), at 8 (the
+    survey container's figure, 0.70 pairs/s, was taken at 8) and at one thread per PHYSICAL core of the host (SURVEY section
+    8(d); on a box whose cgroup grants fewer CPUs than that the threads time-slice, which the record says); 3 warm-up
+    forwards, then ~9 s of timed forwards per setting; median and p10 / p90 of the per-forward rate"""
     from emip_amd.filler import synthetic_pair
     from oracle import emip_oracle as O
     im1, im2 = synthetic_pair(1, seed=1234)
     recs, ref_mask = {}, None
     ncpu = os.cpu_count() or 1
+    phys, aff, quota = _host_cores()
     with torch.no_grad():
-        for nt in (16, 8):
+        for nt in (16, 8, phys):
+            if nt in recs:
+                continue
             torch.set_num_threads(max(1, min(nt, ncpu)))
             for _ in range(2 if ref_mask is not None else 3):
                 ref_mask = O.short_forward(im1, im2, sd)[0]  # warm-up; also the reference mask of the parity figures
@@ -287,8 +323,11 @@ def cpu_baseline(sd):
                         "median": round(_pct(rates, 0.5), 4), "p10": round(_pct(rates, 0.1), 4), "p90": round(_pct(rates, 0.9), 4),
                         "gflops": round(len(ts) / sum(ts) * F_ALG_PAIR_GFLOP, 1),      # the oracle runs the reference's literal formulation
                         "sample": "%d fp32 batch-1 EMIP-short forwards of the CPU oracle (oracle/emip_oracle.py, PyTorch-CPU, "
-                                  "%d threads, host has %d logical CPUs)" % (len(ts), torch.get_num_threads(), ncpu)}
-    return recs[16], recs[8], ref_mask
+                                  "%d threads, host has %d logical CPUs / %d physical cores, this process may use %d%s)" % (
+                                      len(ts), torch.get_num_threads(), ncpu, phys, aff,
+                                      "" if quota is None else ", cgroup quota %.1f CPUs" % quota)}
+    torch.set_num_threads(max(1, min(16, ncpu)))
+    return recs[16], recs[8], recs[phys], ref_mask
 
 
 def _iou(a, b):
@@ -390,6 +429,11 @@ def report_rows(out, world):
              "frac_of_bf16_mfma_peak": out.get("end_to_end", {}).get("frac_of_bf16_mfma_peak"),
              "mask_max_abs_err_f32_mode": par.get("mask_logit_max_abs_err_f32_vs_cpu_ref"),
              "mask_iou_vs_ref": par.get("mask_iou_bf16_vs_cpu_ref"), "warp_indices": None,
+             # the headline is a THROUGHPUT with several whole-batch steps in flight; one step at a time:
+             "steps_in_flight": (out.get("config") or {}).get("steps_in_flight"),
+             "latency_ms": out.get("per_step", {}).get("latency_ms"),
+             "pairs_per_s_one_step_at_a_time": out.get("per_step", {}).get("pairs_per_s_one_step_at_a_time"),
+             "literal_order_value": (out.get("literal_order") or {}).get("value"),
              "rate_in_the_references_literal_order": (out.get("literal_order") or {}).get("value")}]
     t = out.get("train")
     if isinstance(t, dict) and "value" in t:
@@ -939,7 +983,7 @@ def main():
         out["kernel_breakdown_ms"] = {k: round(v[0], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:12]}
         out["parity"] = {"timed_outputs": timed_parity}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], out["cpu_baseline_8_threads"], ref_mask = cpu_baseline(sd)
+            out["cpu_baseline"], out["cpu_baseline_8_threads"], out["cpu_baseline_all_physical_cores"], ref_mask = cpu_baseline(sd)
             out["parity"].update(parity_figures(net, margs, sd, ref_mask, dev))
     # Sub-records (driver-timed beside the headline, same JSON line): BASELINE.json configs[2] / [4] = the training step
     # (every rank takes part: its gradient all-reduce is the one real exchange of the path), configs[3] = EMIP-long, and the

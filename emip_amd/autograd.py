@@ -706,8 +706,7 @@ MATCH_BWD_FUSED = True      # emip_match (+ log-sum-exp) / emip_match_bwd in the
 
 
 def _match_fused(t):
-    n, C = t.shape[1], t.shape[2]
-    return MATCH_BWD_FUSED and t.dtype == torch.bfloat16 and C == 128 and 128 <= n <= 2048 and n % 8 == 0 and t.stride(2) == 1
+    return MATCH_BWD_FUSED and ops.match_eligible(t)
 
 
 class GlobalMatchFn(Function):

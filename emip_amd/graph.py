@@ -99,6 +99,7 @@ class PipelinedShort:
         self.net, self.batch, self.inflight = net, batch, inflight
         self.parts = [_Part(net, batch, size, device, warmup, cnn_first=i % 2 == 1) for i in range(inflight)]
         self.streams = [torch.cuda.Stream(device=device) for _ in range(inflight)]
+        self.done = [None] * inflight    # per slot: event behind its last replay
         self.turn = 0
         for p in self.parts:          # prime: the first launch of a graph does one-time runtime work; do it serially
             p.graph.replay()
@@ -109,22 +110,37 @@ class PipelinedShort:
         return 1
 
     def load(self, image1, image2, slot=None):
-        """inputs of the next step (slot None: the same batch into every in-flight slot, as the benchmark does)"""
+        """inputs of the next step (slot None: the same batch into every in-flight slot, as the benchmark does).  The copies run
+        on the SLOT's stream, behind whatever produced the images on the caller's stream: they cannot overtake the slot's
+        previous replay (which still reads im1 / im2) and the next replay cannot start before they have landed."""
+        cur = torch.cuda.current_stream()
         for i, p in enumerate(self.parts):
             if slot is None or slot == i:
-                p.im1.copy_(image1)
-                p.im2.copy_(image2)
+                s = self.streams[i]
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    p.im1.copy_(image1, non_blocking=True)
+                    p.im2.copy_(image2, non_blocking=True)
+                image1.record_stream(s)
+                image2.record_stream(s)
 
     def replay_free(self):
         """enqueue ONE step on the next slot's stream without joining; returns the slot"""
         i = self.turn
         self.turn = (i + 1) % self.inflight
-        with torch.cuda.stream(self.streams[i]):
+        s = self.streams[i]
+        with torch.cuda.stream(s):
             self.parts[i].graph.replay()
+            self.done[i] = torch.cuda.Event()
+            self.done[i].record(s)
         return i
 
     def outputs(self, slot=0):
+        """the static output buffers of a slot; the caller's stream waits for the slot's last replay first (the buffers are
+        rewritten by the slot's NEXT replay: consume them, or copy them on this stream, before enqueueing it)"""
         p = self.parts[slot]
+        if self.done[slot] is not None:
+            torch.cuda.current_stream().wait_event(self.done[slot])
         return p.mask, [q[:p.batch] for q in p.preds], [q[p.batch:] for q in p.preds]
 
 
@@ -309,10 +325,19 @@ class PipelinedLong:
         p, s = self.slots[i], self.streams[i]
         with torch.cuda.stream(s):
             if g == 0:
-                for u in range(t, t + G):                    # last readers of the ring entries about to be overwritten
-                    old = self.ev_b.pop(u - self.R + self.T - 1, None)
-                    if old is not None:
-                        s.wait_event(old)
+                # EVERY reader of the ring entries about to be overwritten: the entry of step u last held the pair of step
+                # u - R, which the B parts of steps u - R .. u - R + T - 1 gather (index_select on their own streams).  Waiting
+                # for the numerically last of them only (round 3) left the other four ordered by queueing distance, not by an
+                # event
+                waited = set()
+                for u in range(t, t + G):
+                    for r in range(u - self.R, u - self.R + self.T):
+                        old = self.ev_b.get(r)
+                        if old is not None and r not in waited:
+                            waited.add(r)
+                            s.wait_event(old)
+                for u in range(t, t + G):                    # step u - R is the oldest reader of anything still to be rewritten
+                    self.ev_b.pop(u - self.R, None)
                 p.graph_a.replay()
                 for u in range(G):
                     e = (t + u) % self.R

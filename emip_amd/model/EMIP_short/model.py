@@ -158,9 +158,9 @@ class CoUpdater(EmipModule):
             n, C = c0.shape[1], c0.shape[2]
             wdt = int(round(n ** 0.5))
             corr = torch.empty((B, n, n), dtype=c0.dtype, device=c0.device)
-            if c0.dtype == torch.bfloat16 and C == 128:
+            if ops.match_eligible(c0):
                 ops.match(c0[:B], c0[B:], wdt, C ** -0.5, scores=corr)
-            else:       # f32 mode: F0 F1^T per image on the library's own batched GEMM, then the scale
+            else:       # f32 mode, or a frame size emip_match does not take: F0 F1^T per image on the batched GEMM, then the scale
                 ops.gemm_batched(c0[:B], c0[B:], corr, B, n, n, C, C, C, n, n * C, n * C, n * n)
                 corr.mul_(C ** -0.5)
             L["corr"] = corr

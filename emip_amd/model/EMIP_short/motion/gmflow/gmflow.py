@@ -92,7 +92,7 @@ class GMFlow(EmipModule):
         # ---- global correlation + softmax -> correspondence (both directions)
         want_corr = corr
         corr = torch.empty((B, n, n), dtype=dt, device=a.device) if want_corr else None
-        if dt == torch.bfloat16 and C == 128:
+        if ops.match_eligible(c0):
             # one launch for both directions (emip_match): batch z < B = frame 1 against frame 2 with the raw correlation written
             # out, z >= B the reverse; the flow leaves the kernel as f32 [2B, h, w, 2]
             if not flows:

@@ -664,6 +664,13 @@ def window_attention_bwd(q, k, v, out, dout, lse, rows, gid, tokens, scale, kv_r
     return g[0], g[1], g[2]
 
 
+def match_eligible(t):
+    """emip_match takes bf16 tokens [Z, n, 128] with unit channel stride, 128 <= n <= 2048, n % 8 == 0 (352 x 352 frames:
+    n = 1936; 384 x 384 would be 2304: callers fall back to the generic attention kernel / batched GEMM there)"""
+    n, C = t.shape[1], t.shape[2]
+    return t.dtype == torch.bfloat16 and C == 128 and 128 <= n <= 2048 and n % 8 == 0 and t.stride(2) == 1
+
+
 def match(q, k, W, scale, v=None, scores=None, kv_rot=0, sub_grid=True, lse=None):
     """emip_match: q, k bf16 [Z, n, 128] (unit channel stride), v f32 [Z, n, 2] or None (= the pixel grid of width W),
     scores bf16 [Zs, n, n] or None -> f32 [Z, n, 2]; keys / values of batch z come from batch (z + kv_rot) mod Z"""
