@@ -1,0 +1,369 @@
+// The Mlp half of a PVTv2 stage-3 block (22 x 22 tokens, C = 320, hidden 1280) per BAND of an image, one launch, the hidden
+// tensor on the CU only (bf16 inference):
+//
+//     out = x + fc2( GELU( dwconv3x3( LN(x) W1^T + b1 ) + bd ) ) + b2          and the row statistics of `out`
+//
+// (/root/reference/lib/pvt_v2.py:45-54 Mlp.forward with DWConv :316-327, inside Block.forward :165-169; norm2 folded into
+// W1 / b1 and applied on the output side from the row statistics that travel with the residual stream, like emip_gemm_lne.)
+//
+// Round 3's emip_mlp_block did the same in one launch and lost to the two launches it replaced (119 against 79 us): its fc1,
+// depthwise and fc2 phases ran one after the other on all ten waves, three barriers per 64-channel chunk, single-buffered
+// weights.  This kernel is built around what that ablation showed:
+//   * a workgroup = one QUARTER of an image's tokens (121, token-contiguous; + 23 halo tokens on either side for the 3 x 3
+//     taps: <= 167 fc1 rows), 8 waves, the whole LDS of a CU.  64 workgroups for a 16-image step: with several steps in
+//     flight the chip fills with the bands of different steps, and what a launch costs the others is its CU-time;
+//   * the hidden dimension is walked in 40 chunks of 32 channels as a THREE-STAGE software pipeline with ONE s_barrier per
+//     iteration: iteration t runs fc1 of chunk t (MFMA; -> H[t & 1] in LDS), the depthwise 3 x 3 + GELU of chunk t - 1 (VALU;
+//     H[(t-1) & 1] -> G[(t-1) & 1]) and fc2 of chunk t - 2 (MFMA; G[t & 1] -> accumulators).  The three touch different
+//     buffers, so waves 0-3 run them as fc1, fc2, depthwise and waves 4-7 as depthwise, fc1, fc2: the two waves of a SIMD are
+//     on different pipes most of the time (the phases of round 3's kernel ran in lockstep);
+//   * fc1: waves 0..5 own one 32-token tile of the band + halo each, their raw tokens as MFMA B fragments in 80 registers for
+//     the whole launch; fc2 (40 tiles of 32 tokens x 32 output channels): waves 6 and 7, which hold no tokens, own ALL ten
+//     channel tiles of token tiles 0 and 1 (160 accumulator registers), waves 0-2 / 3-5 share token tile 2 / 3 as 3 + 3 + 4
+//     channel tiles -- 26-28 MFMAs per wave and chunk for the token-holding waves, 20 for the other two, and no wave holds more
+//     than 160 long-lived registers (tokens and accumulators live in ONE register array: the roles are wave-uniform, the
+//     compiler cannot know they exclude each other); the depthwise pass: wave w owns 8 channels (w & 3) x half of the
+//     band's tokens, ONE token per lane -- the
+//     nine neighbour addresses are loop invariants (taps outside the image point at a zero row: no masks) and the wave's 72 tap
+//     weights + 8 biases are wave-uniform scalars (s_load, no LDS traffic);
+//   * both weight matrices are packed on the host in MFMA-fragment order (one 1-KB piece = the A operand of all 64 lanes), a
+//     pipeline stage t = [W1 chunk t | W2 chunk t - 2 | fc1 bias + column sums of chunk t] = 41 contiguous KB that go through
+//     a 3-slot LDS-DMA ring, two stages in flight, one counted s_waitcnt per iteration; fragment reads are conflict-free
+//     ds_read_b128 at lane * 16;
+//   * epilogue: + b2 + x, one rounding, through an LDS image of the band to whole 128-byte row segments; row sums / sums of
+//     squares by fixed-order lane reductions (no atomics: two runs give the same bits).
+// The halo rows are recomputed by the neighbouring band (fc1 work x 1.38 for the inner bands), the price of no exchange
+// between workgroups inside the launch.
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4 md_rsrc(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    return i32x4{(int)(unsigned)a, (int)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void md_dma16(unsigned lds_dst, unsigned voff, i32x4 rs) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_dst), "v"(voff), "s"(rs)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void md_wait() {
+    // ... and every LDS write of this wave (H, G) has landed before the barrier that follows: a raw s_barrier waits for no counter
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+struct MdArgs {
+    const bf16_t* X;        // [B * 484, ldx] raw residual stream
+    bf16_t* Out;            // [B * 484, ldo] (must not alias X: a band's halo tokens are another band's outputs)
+    const char* Wst;        // [42 stages][41 984 B]: W1 chunk t | W2 chunk t - 2 | b1, column sums of chunk t (ops.mlp_band_packs)
+    const float* taps;      // [40 chunks][10][32]: the 9 depthwise taps and the depthwise bias of the chunk's channels
+    const float* b2;        // [320]
+    const float* ln_stats;  // [B * 484, 2] (sum, sum of squares) of the rows of X
+    float* out_stats;       // [B * 484, 2] of the rows of Out (stored, not accumulated), or null
+    long ldx, ldo;
+    int B, xcd_map;
+    float eps;
+    unsigned wst_bytes;
+};
+
+constexpr int MD_C = 320, MD_N = 1280, MD_CH = 32, MD_NCH = MD_N / MD_CH, MD_NST = MD_NCH + 2;
+constexpr int MD_HW = 22, MD_TOK = MD_HW * MD_HW, MD_NB = 4, MD_BAND = MD_TOK / MD_NB, MD_HALO = MD_HW + 1, MD_HROWS = MD_BAND + 2 * MD_HALO;
+constexpr int MD_STAGE = 41 * 1024, MD_W2OFF = 20 * 1024, MD_COFF = 40 * 1024;
+constexpr int MD_HB = 64 + MD_HROWS * 64, MD_GB = MD_BAND * 64;                 // H buffer: zero row + 167 rows; G buffer: 121 rows
+constexpr int OFF_H = 3 * MD_STAGE, OFF_G = OFF_H + 2 * MD_HB, MD_LDS = 160 * 1024;
+constexpr int MD_OROW = 2 * MD_C + 16;                                          // bytes of a row of the epilogue's output image
+static_assert(OFF_G + 2 * MD_GB + 7 * 64 <= MD_LDS, "fc2 reads token slots 121..127 of the second G buffer");
+static_assert(MD_BAND * MD_OROW <= 3 * MD_STAGE, "the output image lies in the ring");
+static_assert(MD_BAND * MD_NB == MD_TOK && MD_HROWS <= 6 * 32 && MD_BAND <= 4 * 32, "tile counts");
+
+// one wave's share of the launch.  FC1: the wave holds a token tile of the band + halo (waves 0..5); DW_FIRST: the wave runs the
+// depthwise pass ahead of its MFMA phases (waves 4..7).  Three instantiations, entered through wave-uniform branches: every wave
+// executes the same sequence of s_barriers, and each role gets a register allocation of its own.
+template <bool FC1, bool DW_FIRST>
+__device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict__ taps, char* smem, int wave, int lane, int img, int band) {
+    const int lq = lane & 31, h = lane >> 5;
+    const int t0 = band * MD_BAND;                                   // first own token (inside the image)
+    const int h0 = max(t0 - MD_HALO, 0), h1 = min(t0 + MD_BAND + MD_HALO, MD_TOK);
+    const int nh = h1 - h0;                                          // fc1 rows: 144 (outer bands) or 167
+    const long rowbase = (long)img * MD_TOK;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
+    const i32x4 rsW = md_rsrc(p.Wst, p.wst_bytes);
+
+    // ---- weight stream: stage s -> slot s % 3; wave w moves pieces 5 w .. 5 w + 4, wave 0 also piece 40 (the constants)
+    auto issue = [&](int s) {
+        const unsigned base = lds0 + (unsigned)((s % 3) * MD_STAGE);
+        const unsigned src = (unsigned)(s * MD_STAGE + lane * 16);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) md_dma16(base + (5 * wave + j) * 1024, src + (5 * wave + j) * 1024, rsW);
+        if (wave == 0) md_dma16(base + 40 * 1024, src + 40 * 1024, rsW);
+    };
+
+    // ---- fc1 operands: this lane's token of the band + halo, raw, as B fragments; its LayerNorm statistics
+    issue(0);
+    issue(1);
+    u32x4 xf[FC1 ? 20 : 1];
+    float rs = 0.f, mrs = 0.f;
+    const int fr = 32 * wave + lq;                                   // fc1 row (index into band + halo) of this lane
+    if (FC1) {
+        const long tr = rowbase + h0 + min(fr, nh - 1);              // rows beyond the band: clamped (computed, never stored)
+        const bf16_t* xr = p.X + tr * p.ldx + 8 * h;
+#pragma unroll
+        for (int i = 0; i < 20; ++i) xf[i] = *reinterpret_cast<const u32x4*>(xr + 16 * i);
+        const float2 s2 = *reinterpret_cast<const float2*>(p.ln_stats + 2 * tr);
+        const float mu = s2.x * (1.f / MD_C);
+        rs = rsqrtf(fmaxf(s2.y * (1.f / MD_C) - mu * mu, 0.f) + p.eps);
+        mrs = mu * rs;
+        // the compiler's wait for these loads belongs HERE: left to the first use it sits inside the loop, where a vmcnt(0) per
+        // iteration would drain the weight stream the compiler cannot see (the LDS-DMAs are inline asm)
+#pragma unroll
+        for (int i = 0; i < 20; ++i) asm volatile("" : "+v"(xf[i]));
+        asm volatile("" : "+v"(rs), "+v"(mrs));
+    }
+    if (wave == 7 && lane < 32) {                                    // the zero rows in front of both H buffers
+        reinterpret_cast<unsigned*>(smem + OFF_H)[lane & 15] = 0u;
+        reinterpret_cast<unsigned*>(smem + OFF_H + MD_HB)[lane & 15] = 0u;
+    }
+
+    // ---- depthwise pass geometry: wave w = channel group cg = w & 3 (8 channels) x token half w >> 2, one own token per lane
+    const int cg = wave & 3;
+    const int q = 64 * (wave >> 2) + lane;                           // own-token index of this lane
+    const bool q_ok = q < MD_BAND;
+    unsigned hoff[9];                                                // byte offsets into an H buffer of the nine taps' rows
+    {
+        const int pq = t0 + min(q, MD_BAND - 1);                     // token inside the image
+        const int py = pq / MD_HW, px = pq - py * MD_HW;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int yy = py + ky - 1, xx = px + kx - 1;
+                const bool in = (unsigned)yy < (unsigned)MD_HW && (unsigned)xx < (unsigned)MD_HW;
+                const int r = yy * MD_HW + xx - h0;                  // row of the H buffer
+                hoff[3 * ky + kx] = in ? (unsigned)(64 + r * 64 + ((cg ^ ((r >> 2) & 3)) * 16)) : 0u;
+            }
+    }
+    const int qs = min(q, MD_BAND - 1);
+    const unsigned goff = (unsigned)(qs * 64 + ((cg ^ ((qs >> 2) & 3)) * 16));
+
+    // ---- fc2: waves 6, 7: token tile w - 6, channel tiles 0..9; waves 0..5: token tile 2 + w / 3, channel tiles d0 .. d0 + nd - 1
+    // with (d0, nd) = (0, 3), (3, 3), (6, 4) for w % 3 = 0, 1, 2
+    constexpr int NACC = FC1 ? 4 : 10;
+    const int w3 = FC1 ? wave % 3 : 0;
+    const int tw = FC1 ? 2 + wave / 3 : wave - 6;
+    const int d0 = FC1 ? 3 * w3 : 0;
+    const bool four = !FC1 || w3 == 2;                               // (waves 0..5) a fourth channel tile
+    const int n2 = 32 * tw + lq;                                     // own-token index of this lane's fc2 column
+    f32x16 oacc[NACC];
+#pragma unroll
+    for (int d = 0; d < NACC; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
+
+    // the three phases of an iteration ------------------------------------------------------------------------------------------
+    auto fc1 = [&](int t, const char* st) {                          // chunk t: W1 fragments of stage t -> H[t & 1]
+        f32x16 hacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < (FC1 ? 20 : 0); ++i) {
+            const uint4 wf = *reinterpret_cast<const uint4*>(st + i * 1024 + lane * 16);
+            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf[i]), hacc, 0, 0, 0);
+        }
+        // register 4 g + j = hidden channel 8 g + 4 h + j of the chunk, for this lane's token: output-side LayerNorm + bias
+        const float* cs = reinterpret_cast<const float*>(st + MD_COFF);       // [b1 (32) | column sums of W1 (32)]
+        char* hb = smem + OFF_H + (t & 1) * MD_HB + 64 + fr * 64 + 8 * h;
+        const int sw = (fr >> 2) & 3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(cs + 8 * g + 4 * h);
+            const float4 c4 = *reinterpret_cast<const float4*>(cs + 32 + 8 * g + 4 * h);
+            bf16x4 hv;
+            hv[0] = (bf16_t)fmaf(hacc[4 * g + 0], rs, fmaf(-mrs, c4.x, b4.x));
+            hv[1] = (bf16_t)fmaf(hacc[4 * g + 1], rs, fmaf(-mrs, c4.y, b4.y));
+            hv[2] = (bf16_t)fmaf(hacc[4 * g + 2], rs, fmaf(-mrs, c4.z, b4.z));
+            hv[3] = (bf16_t)fmaf(hacc[4 * g + 3], rs, fmaf(-mrs, c4.w, b4.w));
+            if (fr < nh) *reinterpret_cast<bf16x4*>(hb + ((g ^ sw) * 16)) = hv;
+        }
+    };
+    auto dwp = [&](int t) {                                          // chunk t: H[t & 1] -> depthwise 3 x 3 + bias + GELU -> G[t & 1]
+        const float* tp = taps + (long)t * (10 * MD_CH) + 8 * cg;    // wave-uniform: scalar loads
+        const char* hb = smem + OFF_H + (t & 1) * MD_HB;
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = tp[9 * MD_CH + j];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const uint4 raw = *reinterpret_cast<const uint4*>(hb + hoff[k]);
+            const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                o[2 * j] = fmaf(__uint_as_float(rw[j] << 16), tp[k * MD_CH + 2 * j], o[2 * j]);
+                o[2 * j + 1] = fmaf(__uint_as_float(rw[j] & 0xFFFF0000u), tp[k * MD_CH + 2 * j + 1], o[2 * j + 1]);
+            }
+        }
+        bf16x8 ov;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)gelu_poly(o[j]);
+        if (q_ok) *reinterpret_cast<bf16x8*>(smem + OFF_G + (t & 1) * MD_GB + goff) = ov;
+    };
+    auto fc2 = [&](int t, const char* st) {                          // chunk t: G[t & 1] x W2 fragments (stage t + 2) -> accumulators
+        const char* gb = smem + OFF_G + (t & 1) * MD_GB + n2 * 64;
+        const int sw = (n2 >> 2) & 3;
+        const bf16x8 g0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gb + ((h ^ sw) * 16)));
+        const bf16x8 g1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gb + (((2 + h) ^ sw) * 16)));
+        const char* wb = st + MD_W2OFF + d0 * 2048 + lane * 16;
+#pragma unroll
+        for (int d = 0; d < NACC; ++d) {
+            if (FC1 && d == 3 && !four) break;
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb + d * 2048)), g0,
+                                                              oacc[d], 0, 0, 0);
+            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb + d * 2048 + 1024)),
+                                                              g1, oacc[d], 0, 0, 0);
+        }
+    };
+
+#pragma unroll 1
+    for (int t = 0; t < MD_NST; ++t) {
+        // stage t has landed once all but this wave's pieces of stage t + 1 (issued one iteration ago) are done
+        if (t + 1 < MD_NST) {
+            if (wave == 0) md_wait<6>();
+            else md_wait<5>();
+        } else {
+            md_wait<0>();
+        }
+        __builtin_amdgcn_s_barrier();                      // ... for every wave; H / G of the previous iteration are complete, and
+        __builtin_amdgcn_sched_barrier(0);                 // everyone has left stage t - 1's slot and the buffers written next
+        if (t + 2 < MD_NST) issue(t + 2);
+        const char* st = smem + (t % 3) * MD_STAGE;
+        if (DW_FIRST && t >= 1 && t <= MD_NCH) dwp(t - 1);
+        if (FC1 && t < MD_NCH) fc1(t, st);
+        if (t >= 2) fc2(t - 2, st);
+        if (!DW_FIRST && t >= 1 && t <= MD_NCH) dwp(t - 1);
+    }
+
+    // ---- epilogue: + b2 + x in the accumulator layout, one rounding, -> an LDS image of the band (in the idle ring).
+    // register 4 g + j of accumulator tile d = output channel 32 (d0 + d) + 8 g + 4 h + j of token n2
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const bool ok = n2 < MD_BAND;
+        const long tr = rowbase + t0 + min(n2, MD_BAND - 1);
+        const bf16_t* xr = p.X + tr * p.ldx;
+        char* ob = smem + min(n2, MD_BAND - 1) * MD_OROW;
+#pragma unroll
+        for (int d = 0; d < NACC; ++d) {
+            if (FC1 && d == 3 && !four) break;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ch = 32 * (d0 + d) + 8 * g + 4 * h;
+                const float4 bv = *reinterpret_cast<const float4*>(p.b2 + ch);
+                const bf16x4 xv = *reinterpret_cast<const bf16x4*>(xr + ch);
+                bf16x4 ov;
+                ov[0] = (bf16_t)(oacc[d][4 * g + 0] + bv.x + (float)xv[0]);
+                ov[1] = (bf16_t)(oacc[d][4 * g + 1] + bv.y + (float)xv[1]);
+                ov[2] = (bf16_t)(oacc[d][4 * g + 2] + bv.z + (float)xv[2]);
+                ov[3] = (bf16_t)(oacc[d][4 * g + 3] + bv.w + (float)xv[3]);
+                if (ok) *reinterpret_cast<bf16x4*>(ob + ch * 2) = ov;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(512) void mlp_band_kernel(const MdArgs p, const float* __restrict__ taps) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int img, band;
+    if (p.xcd_map) {       // the bands of an image on one XCD: they share its token rows in that L2
+        const int j = blockIdx.x >> 3;
+        band = j % MD_NB;
+        img = (blockIdx.x & 7) + 8 * (j / MD_NB);
+    } else {
+        band = blockIdx.x % MD_NB;
+        img = blockIdx.x / MD_NB;
+    }
+    if (wave < 4) md_run<true, false>(p, taps, smem, wave, lane, img, band);
+    else if (wave < 6) md_run<true, true>(p, taps, smem, wave, lane, img, band);
+    else md_run<false, true>(p, taps, smem, wave, lane, img, band);
+
+    // ---- the band's rows out of the LDS image, whole 128-byte segments, and their statistics
+    __syncthreads();
+    const int t0 = band * MD_BAND;
+    const long rowbase = (long)img * MD_TOK;
+    // 8 lanes per row: lane j of the group moves the 16-byte chunks j, j + 8, .. j + 32 (128-byte segments per group and step)
+    const int grp = tid >> 3, gl = tid & 7;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int row = grp + 64 * pass;
+        const bool ok = row < MD_BAND;
+        const char* ob = smem + min(row, MD_BAND - 1) * MD_OROW;
+        bf16_t* op = p.Out + (rowbase + t0 + min(row, MD_BAND - 1)) * p.ldo;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const uint4 v = *reinterpret_cast<const uint4*>(ob + (gl + 8 * k) * 16);
+            if (ok) *reinterpret_cast<uint4*>(op + (gl + 8 * k) * 8) = v;
+            const unsigned vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = __uint_as_float(vw[j] << 16), b = __uint_as_float(vw[j] & 0xFFFF0000u);
+                s1 += a + b;
+                s2 = fmaf(a, a, fmaf(b, b, s2));
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if (p.out_stats && ok && gl == 0) *reinterpret_cast<float2*>(p.out_stats + 2 * (rowbase + t0 + row)) = make_float2(s1, s2);
+    }
+}
+
+}  // namespace
+
+extern "C" int emip_mlp_band_eligible(int B, int H, int W, int C, int N) {
+    return B > 0 && H == MD_HW && W == MD_HW && C == MD_C && N == MD_N;
+}
+extern "C" int emip_mlp_band_stage_bytes(void) { return MD_NST * MD_STAGE; }
+
+// Out = X + fc2(GELU(dwconv3x3(LN(X) W1^T + b1) + bd)) + b2 per image, out_stats = (sum, sum of squares) of the rows of Out (may
+// be NULL).  X, Out: bf16 [B, 22, 22, 320] with row strides ldx / ldo, Out must not overlap X.  Wst: the 42 pipeline stages of
+// ops.mlp_band_packs (fragment-order W1 with the LayerNorm scale folded in, fragment-order W2, fc1 bias + W1 beta, row sums of the
+// packed W1), taps: f32 [40][10][32] (9 depthwise taps + bias per hidden channel, chunk-major), b2: f32 [320], ln_stats: f32
+// [B 484][2] (sum, sum of squares) of the rows of X.
+extern "C" int emip_mlp_band(const void* X, long ldx, const void* Wst, const float* taps, const float* b2, const float* ln_stats,
+                             float eps, void* Out, long ldo, float* out_stats, int B, int H, int W, int C, int N, void* stream) {
+    EMIP_REQUIRE(X && Wst && taps && b2 && ln_stats && Out && emip_mlp_band_eligible(B, H, W, C, N));
+    EMIP_REQUIRE(ldx >= C && (ldx & 7) == 0 && ldo >= C && (ldo & 7) == 0);
+    EMIP_REQUIRE(aligned16(X) && aligned16(Wst) && aligned16(taps) && aligned16(b2) && aligned16(Out) &&
+                 (reinterpret_cast<uintptr_t>(ln_stats) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out_stats) & 7u) == 0);
+    const long rows = (long)B * H * W;
+    {   // no overlap of the two token tensors
+        const char* x0 = (const char*)X; const char* x1 = x0 + ((rows - 1) * ldx + C) * 2;
+        const char* o0 = (const char*)Out; const char* o1 = o0 + ((rows - 1) * ldo + C) * 2;
+        EMIP_REQUIRE(x1 <= o0 || o1 <= x0);
+    }
+    MdArgs a{};
+    a.X = (const bf16_t*)X; a.Out = (bf16_t*)Out; a.Wst = (const char*)Wst; a.taps = taps; a.b2 = b2;
+    a.ln_stats = ln_stats; a.out_stats = out_stats; a.ldx = ldx; a.ldo = ldo; a.B = B; a.eps = eps;
+    a.xcd_map = (B % 8) == 0;
+    a.wst_bytes = (unsigned)(MD_NST * MD_STAGE);
+    static bool attr = false;
+    if (!attr) {
+        attr = true;
+        if (hipFuncSetAttribute((const void*)mlp_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MD_LDS) != hipSuccess)
+            return EMIP_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(mlp_band_kernel, dim3((unsigned)(B * MD_NB)), dim3(512), MD_LDS, (hipStream_t)stream, a, taps);
+    return emip_launch_status();
+}

@@ -44,6 +44,9 @@ SR_WIDE_TILE = True         # the spatial-reduction conv of the 22 x 22 stage on
 FC1DW_BAND_MIN_ROWS = 3     # banded fc1 + depthwise launch for maps of > 512 tokens when a band has at least this many output rows (0: off;
                             # in-call at 16 pairs: off 1592, the 44 x 44 stage only 1618, the 88 x 88 stage too 1628 pairs/s)
 MLP_BLOCK = False
+# the Mlp half of a 22 x 22-stage block as ONE launch of quarter-image workgroups (emip_mlp_band, round 4): fc1, depthwise + GELU
+# and fc2 as a three-stage software pipeline over 32-channel chunks, one barrier per chunk, the hidden tensor on the CU only
+MLP_BAND = True
 # the spatial-reduction convs with few output tiles and a long K walk (stages 1-2: 61 tiles x 64 / 32 K tiles at 32 images)
 # with K split inside the launch (emip_conv2d_ksplit, the normalising loader) instead of the per-tap ring body.  OFF: shorter
 # alone, but with three steps in flight 1554 against 1587 pairs/s (tools/flag_ab.py) -- the third time a split-K form loses
@@ -229,6 +232,8 @@ class Block(EmipModule):
             if dt == torch.bfloat16 and out["w1"].shape == (1280, 320):
                 # emip_mlp_block: the per-chunk constant blocks (taps, depthwise bias, fc1 bias, column sums of the packed W1)
                 out["mcst"] = ops.mlp_block_consts(out["wd"], out["bd"], out["b1"], out["sw1"])
+                # emip_mlp_band: the pipeline stages (fragment-order W1 | W2 | fc1 constants) and the chunk-major tap table
+                out["mband"] = ops.mlp_band_packs(out["w1"], out["b1"], out["sw1"], out["w2"], out["wd"], out["bd"])
             return out
         params = (self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, a.q.weight, a.q.bias,
                   a.kv.weight, a.kv.bias, a.proj.weight, a.proj.bias, m.fc1.weight, m.fc1.bias,
@@ -310,6 +315,10 @@ class Block(EmipModule):
             ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)
         # ---- Mlp half: x += fc2(GELU(dwconv(fc1(LN(x)))))
         hid = w["w1"].shape[0]
+        if MLP_BAND and alt is not None and "mband" in w and ops.mlp_band_eligible(B, H, W, C, hid):
+            # the whole Mlp half in one launch of B x 4 workgroups (out of place: a band's halo tokens are its neighbours' rows)
+            ops.mlp_band(x, w["mband"][0], w["mband"][1], w["b2"], st1, self.norm2.eps, alt, out_stats=st2)
+            return alt, st2, x
         if MLP_BLOCK and alt is not None and "mcst" in w and ops.mlp_block_eligible(B, H, W, C, hid):
             # the whole Mlp half in one launch: the hidden tensor never leaves the CU (out of place: bands read halo rows)
             ops.mlp_block(x, w["w1"], w["w2"], w["mcst"], w["b2"], st1, self.norm2.eps, alt, out_stats=st2)

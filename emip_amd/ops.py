@@ -857,6 +857,49 @@ def mlp_block(x, w1, w2, cst, b2, ln_stats, eps, out, out_stats=None):
     return out
 
 
+def mlp_band_eligible(B, H, W, C, N):
+    return bool(_lib.load().emip_mlp_band_eligible(B, H, W, C, N))
+
+
+def mlp_band_packs(w1, b1, colsum, w2, wd, bd):
+    """the weight stream of emip_mlp_band (mlp_band.hip).  w1 bf16 [1280, 320] (LayerNorm scale folded in), b1 / colsum f32
+    [1280] (fc1 bias + W1 beta; row sums of the packed w1), w2 bf16 [320, 1280], wd f32 [9, 1280], bd f32 [1280] ->
+    (stages uint8 [42, 41984], taps f32 [40, 10, 32]).  Stage t = [W1 chunk t | W2 chunk t - 2 | b1, colsum of chunk t]: the
+    matrices in MFMA-fragment order -- one 1-KB piece is the A operand (32 rows x 16 k) of all 64 lanes, lane l holding row
+    l & 31, k = 8 (l >> 5) .. + 7 -- so that a chunk is contiguous memory for the LDS-DMA ring and every fragment read is a
+    ds_read_b128 at lane * 16."""
+    N, C = w1.shape
+    assert (N, C) == (1280, 320) and w2.shape == (C, N) and w1.dtype == w2.dtype == torch.bfloat16
+    nch, dev = N // 32, w1.device
+    # W1p[j, i, hh, row, e] = w1[32 j + row, 16 i + 8 hh + e]
+    w1p = w1.view(nch, 32, C // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous().view(nch, -1)             # [40, 10240] bf16
+    # W2p[j, d, sp, hh, row, e] = w2[32 d + row, 32 j + 16 sp + 8 hh + e]
+    w2p = w2.view(C // 32, 32, nch, 2, 2, 8).permute(2, 0, 3, 4, 1, 5).contiguous().view(nch, -1)         # [40, 10240] bf16
+    nst = nch + 2
+    sb = _lib.load().emip_mlp_band_stage_bytes() // nst
+    st = torch.zeros((nst, sb), dtype=torch.uint8, device=dev)
+    st[:nch, :20480] = w1p.view(torch.uint8).view(nch, 20480)
+    st[2:, 20480:40960] = w2p.view(torch.uint8).view(nch, 20480)
+    cst = torch.cat((b1.float().view(nch, 32), colsum.float().view(nch, 32)), 1).contiguous()            # [40, 64] f32
+    st[:nch, 40960:40960 + 256] = cst.view(torch.uint8).view(nch, 256)
+    taps = torch.cat((wd.float(), bd.float().view(1, N)), 0).view(10, nch, 32).permute(1, 0, 2).contiguous()
+    return st, taps
+
+
+def mlp_band(x, stages, taps, b2, ln_stats, eps, out, out_stats=None):
+    """out = x + fc2(GELU(dwconv3x3(LN(x) w1^T + b1) + bd)) + b2, one launch, a quarter image per workgroup (bf16, 22 x 22
+    tokens, C = 320, N = 1280); out must not alias x"""
+    B, H, W, C = x.shape
+    M, _, ldx = rows(x)
+    _, _, ldo = rows(out)
+    assert x.dtype == out.dtype == torch.bfloat16 and stages.dtype == torch.uint8 and stages.is_contiguous()
+    assert taps.shape == (40, 10, 32) and taps.is_contiguous() and taps.dtype == torch.float32
+    assert out.shape == x.shape and out.data_ptr() != x.data_ptr()
+    _lib.call("emip_mlp_band", _p(x), ldx, _p(stages), _p(taps), _p(b2), _p(ln_stats), float(eps), _p(out), ldo,
+              _p(out_stats), B, H, W, C, 1280, _stream())
+    return out
+
+
 def dwconv3x3_dual(x, wt, bias, act):
     """-> (act(dwconv(x)), dwconv(x)): activation output and pre-activation values from one pass"""
     B, H, W, C = x.shape

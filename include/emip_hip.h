@@ -721,6 +721,21 @@ int emip_grad_unpack(const void* recs, const void* blockmap, const void* gptrs, 
                      float scale, void* stream);
 int emip_shard_sum(const void* in, void* out, int world, long chunk, int is_bf16, void* stream);
 
+/* The Mlp half of a PVTv2 stage-3 block per band of an image (round 4; bf16 inference, 22 x 22 tokens, C = 320, N = 1280):
+ * Out = X + fc2(GELU(dwconv3x3(LN(X) W1^T + b1) + bd)) + b2 (lib/pvt_v2.py:45-54,165-169,316-327), out_stats = (sum, sum of
+ * squares) of the rows of Out (may be NULL; stored by fixed-order reductions: reproducible bit for bit).  A workgroup owns a
+ * quarter of an image's tokens (+ 23 halo tokens on either side) for all hidden channels, which never leave the CU; fc1,
+ * depthwise + GELU and fc2 of three consecutive 32-channel chunks run as a software pipeline with one barrier per chunk.
+ * X, Out: bf16 [B, 22, 22, 320] (row strides ldx, ldo), Out must NOT overlap X.  Wst: emip_mlp_band_stage_bytes() bytes, the 42
+ * pipeline stages [W1 chunk t in MFMA-fragment order, LayerNorm scale folded in | W2 chunk t - 2 in fragment order | fc1 bias
+ * (+ W1 beta) and row sums of the packed W1 of chunk t, f32] (emip_amd/ops.py: mlp_band_packs); taps: f32 [40][10][32], the 9
+ * depthwise taps and the depthwise bias per hidden channel, chunk-major; b2: f32 [320]; ln_stats: f32 [B 484][2] (sum, sum of
+ * squares) of the rows of X. */
+int emip_mlp_band_eligible(int B, int H, int W, int C, int N);
+int emip_mlp_band_stage_bytes(void);
+int emip_mlp_band(const void* X, long ldx, const void* Wst, const float* taps, const float* b2, const float* ln_stats,
+                  float eps, void* Out, long ldo, float* out_stats, int B, int H, int W, int C, int N, void* stream);
+
 /* ---- calibration switches: libemip_hip_tuning.so ONLY (make -C emip_amd/csrc tuning, -DEMIP_TUNING) ----------------------
  * Tile / ring-depth overrides and work-skipping ablations (no stores / no MFMA / no loads) for tools/.  The product
  * library libemip_hip.so does not contain them (bench.py checks), so nothing a benchmark runs can skip work. */
