@@ -57,6 +57,9 @@ struct G8Args {
     const float* lne_colsum;   // [N] column sums of W
     float lne_eps;
     float* out_stats;          // [M, 2]: accumulates (sum, sum of squares) of the stored rows
+    int stats_lds;             // > 0: byte offset of [BM][WGN][2] f32 in LDS through which the WGN waves of a tile row combine
+                               // their partial sums in FIXED order (one writer per row and column tile); 0: one atomic pair per
+                               // wave and row -- order-independent only while a row receives at most two contributions
     const float* rowscale;     // [M / rs_rows] or null: act(...) of row m is multiplied by rowscale[m / rs_rows] BEFORE the
     int rs_rows;               // residual is added (stochastic depth: residual + scale[sample] * branch)
     const float* lno_gamma;    // LNO instances: C = R + LayerNorm_over_N(A W^T + bias) * gamma + beta, one output tile per row
@@ -528,6 +531,13 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
             }
         }
         if (p.out_stats) {      // the 4 lanes fr, fr+16, fr+32, fr+48 hold the same row
+            // Reproducibility (round 4): f32 atomics from the WGN waves (and the column tiles) of a row arrive in any order, the
+            // sums differ in the last bit from run to run, and a bf16 rounding of a normalised value flips now and then
+            // (round 3: two runs of the same batch 0.3 apart on logits spanning 8).  With stats_lds the waves of a tile row
+            // meet through LDS and ONE lane adds their partial sums in wave order; a single column tile stores the result, two
+            // column tiles add theirs atomically (two addends commute).  The launcher sends rows of more than two column
+            // tiles through a separate statistics pass (emip_internal::row_stats).
+            float* red = reinterpret_cast<float*>(smem + p.stats_lds);      // [BM][WGN][2]
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 const int m = m0 + wm * WTM + 16 * a + fr;
@@ -536,9 +546,37 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                 s2 += __shfl_xor(s2, 16);
                 s1 += __shfl_xor(s1, 32);
                 s2 += __shfl_xor(s2, 32);
-                if (fq == 0 && m < p.M) {
+                if (p.stats_lds) {
+                    if (fq == 0) *reinterpret_cast<float2*>(red + ((wm * WTM + 16 * a + fr) * WGN + wn) * 2) = make_float2(s1, s2);
+                } else if (fq == 0 && m < p.M) {
                     atomicAdd(p.out_stats + 2 * (long)m, s1);
                     atomicAdd(p.out_stats + 2 * (long)m + 1, s2);
+                }
+            }
+            if (p.stats_lds) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (wn == 0 && fq == 0) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const int m = m0 + wm * WTM + 16 * a + fr;
+                        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WGN; ++w) {
+                            const float2 t = *reinterpret_cast<const float2*>(red + ((wm * WTM + 16 * a + fr) * WGN + w) * 2);
+                            t1 += t.x;
+                            t2 += t.y;
+                        }
+                        if (m < p.M) {
+                            if (p.tiles_n == 1) {
+                                *reinterpret_cast<float2*>(p.out_stats + 2 * (long)m) = make_float2(t1, t2);
+                            } else {
+                                atomicAdd(p.out_stats + 2 * (long)m, t1);
+                                atomicAdd(p.out_stats + 2 * (long)m + 1, t2);
+                            }
+                        }
+                    }
                 }
             }
         }
@@ -547,6 +585,38 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
 #pragma unroll
             for (int b = 0; b < TN; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
     }   // steps
+}
+
+// see emip_internal::row_stats below: row r = 32 blockIdx + tid / 8, lane j of its eight takes the 8-element chunks j, j + 8, ..
+__global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict__ C, long ldc, float* __restrict__ out, int M, int N) {
+    const int row = blockIdx.x * 32 + (threadIdx.x >> 3), gl = threadIdx.x & 7;
+    const bf16_t* cp = C + (long)min(row, M - 1) * ldc;
+    const bool vec = ((ldc & 7) == 0) && ((reinterpret_cast<uintptr_t>(C) & 15u) == 0);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c0 = 8 * gl; c0 < N; c0 += 64) {
+        if (vec && c0 + 8 <= N) {
+            const uint4 v = *reinterpret_cast<const uint4*>(cp + c0);
+            const unsigned vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = __uint_as_float(vw[j] << 16), b = __uint_as_float(vw[j] & 0xFFFF0000u);
+                s1 += a + b;
+                s2 = fmaf(a, a, fmaf(b, b, s2));
+            }
+        } else {
+            for (int j = 0; j < 8 && c0 + j < N; ++j) {
+                const float a = (float)cp[c0 + j];
+                s1 += a;
+                s2 = fmaf(a, a, s2);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (gl == 0 && row < M) *reinterpret_cast<float2*>(out + 2 * (long)row) = make_float2(s1, s2);
 }
 
 struct Cfg {
@@ -626,6 +696,21 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     const bool lno = a.lno_gamma != nullptr;
     if (lno && (rs || lnt || conv || !g.lno || a.tiles_n != 1 || a.act != EMIP_ACT_NONE)) return EMIP_E_INVALID;
     if (lno) lds += (size_t)g.bm * 8 * 4;                      // [BM][WGN <= 4][2] f32 behind the ring
+    // row statistics in a reproducible order (see the epilogue).  WGN = 2 tiles with one column tile: two addends per row,
+    // the atomics commute.  More than two column tiles: the GEMM without statistics, then a statistics pass over its output.
+    float* late_stats = nullptr;
+    if (a.out_stats) {
+        const int wgn = (g.bm == 256 && g.bn <= 128) || (g.bm == 128 && g.bn == 64) ? 2 : 4;       // configurations 1, 6, 8: 4 x 2 waves
+        if (a.tiles_n > 2) {
+            late_stats = a.out_stats;
+            a.out_stats = nullptr;
+        } else if (wgn * a.tiles_n > 2) {
+            if (lno) return EMIP_E_INVALID;
+            a.stats_lds = (int)lds;
+            lds += (size_t)g.bm * wgn * 8;
+            if (lds > 160 * 1024) return EMIP_E_INVALID;
+        }
+    }
     auto fn = lno ? g.lno : (rs ? g.rs : (lnt ? g.lnt : (conv ? g.conv : g.dense)));
     const int which = lno ? 4 : (rs ? 3 : (lnt ? 2 : (conv ? 1 : 0)));
     static size_t attr_done[NCFG][5];
@@ -640,10 +725,22 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
     if (lnt && grid != tiles) return EMIP_E_INVALID;          // the tapsum slice in LDS belongs to ONE tile
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a);
+    if (late_stats) hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((a.M + 31) / 32)), dim3(256), 0, s, a.C, a.ldc, late_stats, a.M, a.N);
     return emip_launch_status();
 }
 
 }  // namespace
+
+// (sum, sum of squares) of the N stored values of every row of a bf16 matrix, eight lanes per row, fixed order: the reproducible
+// stand-in for epilogue statistics where a row is spread over more column tiles than atomics can add in a fixed order
+namespace emip_internal {
+int row_stats(const void* C, long ldc, float* out_stats, int M, int N, void* stream) {
+    EMIP_REQUIRE(C && out_stats && M > 0 && N > 0 && ldc >= N);
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)((M + 31) / 32)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)C, ldc,
+                       out_stats, M, N);
+    return emip_launch_status();
+}
+}  // namespace emip_internal
 
 extern "C" int emip_gemm8_auto_cfg(int M, int N, int K) { return pick_cfg(M, N, K); }
 #ifdef EMIP_TUNING

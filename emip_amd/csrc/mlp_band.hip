@@ -34,6 +34,8 @@
 //     squares by fixed-order lane reductions (no atomics: two runs give the same bits).
 // The halo rows are recomputed by the neighbouring band (fc1 work x 1.38 for the inner bands), the price of no exchange
 // between workgroups inside the launch.
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
@@ -54,6 +56,20 @@ __device__ __forceinline__ void md_dma16(unsigned lds_dst, unsigned voff, i32x4 
         : "s"(lds_dst), "v"(voff), "s"(rs)
         : "memory");
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// gelu_poly (common.h) on two values at once: the same operations in the same order, as packed instructions
+__device__ __forceinline__ f32x2 gelu_poly2(f32x2 x) {
+    const f32x2 t = {__builtin_amdgcn_fmed3f(x[0], -4.0f, 4.0f), __builtin_amdgcn_fmed3f(x[1], -4.0f, 4.0f)};
+    const f32x2 u = t * t;
+    f32x2 p = __builtin_elementwise_fma(f32x2{2.258824939e-08f, 2.258824939e-08f}, u, f32x2{-1.588829207e-06f, -1.588829207e-06f});
+    p = __builtin_elementwise_fma(p, u, f32x2{4.776392641e-05f, 4.776392641e-05f});
+    p = __builtin_elementwise_fma(p, u, f32x2{-8.121878305e-04f, -8.121878305e-04f});
+    p = __builtin_elementwise_fma(p, u, f32x2{8.763692481e-03f, 8.763692481e-03f});
+    p = __builtin_elementwise_fma(p, u, f32x2{-6.455441459e-02f, -6.455441459e-02f});
+    p = __builtin_elementwise_fma(p, u, f32x2{3.978702669e-01f, 3.978702669e-01f});
+    return x * __builtin_elementwise_fma(t, p, f32x2{0.5f, 0.5f});
+}
 template <int N>
 __device__ __forceinline__ void md_wait() {
     // ... and every LDS write of this wave (H, G) has landed before the barrier that follows: a raw s_barrier waits for no counter
@@ -72,17 +88,152 @@ struct MdArgs {
     int B, xcd_map;
     float eps;
     unsigned wst_bytes;
+#ifdef EMIP_TUNING
+    unsigned long long* prof;   // calibration build only: per (workgroup, wave) cycles in [barrier wait, DMA issue, fc1, fc2, depthwise, total]
+    int skip;               // calibration build only: 1 no fc1 MFMAs, 2 no depthwise pass, 4 no fc2 MFMAs, 8 no weight DMA, 16 no H stores, 32 constant taps, 64 no G stores
+#endif
 };
+#ifdef EMIP_TUNING
+#define MD_SKIP(bit) (p.skip & (bit))
+#define MD_SKIPV p.skip
+#define MD_STAMP(i) do { if (p.prof) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_readcyclecounter(); pacc[i] += now_ - last_; last_ = now_; } } while (0)
+#else
+#define MD_SKIP(bit) false
+#define MD_SKIPV 0
+#define MD_STAMP(i) do {} while (0)
+#endif
 
 constexpr int MD_C = 320, MD_N = 1280, MD_CH = 32, MD_NCH = MD_N / MD_CH, MD_NST = MD_NCH + 2;
 constexpr int MD_HW = 22, MD_TOK = MD_HW * MD_HW, MD_NB = 4, MD_BAND = MD_TOK / MD_NB, MD_HALO = MD_HW + 1, MD_HROWS = MD_BAND + 2 * MD_HALO;
 constexpr int MD_STAGE = 41 * 1024, MD_W2OFF = 20 * 1024, MD_COFF = 40 * 1024;
 constexpr int MD_HB = 64 + MD_HROWS * 64, MD_GB = MD_BAND * 64;                 // H buffer: zero row + 167 rows; G buffer: 121 rows
+constexpr int OFF_DUMP = 160 * 1024 - 64;                                       // 64 bytes nobody reads: where masked-out lanes store
 constexpr int OFF_H = 3 * MD_STAGE, OFF_G = OFF_H + 2 * MD_HB, MD_LDS = 160 * 1024;
 constexpr int MD_OROW = 2 * MD_C + 16;                                          // bytes of a row of the epilogue's output image
 static_assert(OFF_G + 2 * MD_GB + 7 * 64 <= MD_LDS, "fc2 reads token slots 121..127 of the second G buffer");
 static_assert(MD_BAND * MD_OROW <= 3 * MD_STAGE, "the output image lies in the ring");
 static_assert(MD_BAND * MD_NB == MD_TOK && MD_HROWS <= 6 * 32 && MD_BAND <= 4 * 32, "tile counts");
+
+// One pipeline iteration of one wave, HAND-SCHEDULED: the three chains of an iteration are independent --
+//   chain A: W1 fragments of the stage -> 20 MFMAs -> output-side LayerNorm + bias -> H (bf16 [row][32 ch], 64-byte rows, 16-byte
+//            chunk c of row r at c ^ ((r >> 2) & 3))
+//   chain B: nine rows of the previous chunk's H -> 3 x 3 taps (wave-uniform scalars) + bias -> GELU -> G (same layout)
+//   chain C: G of the chunk before that x W2 fragments of the stage -> accumulators
+// -- and what makes the launch fast is B's ~190 vector instructions sitting in the shadow of A's and C's matrix instructions
+// (an MFMA occupies the matrix pipe for 32 cycles and the wave's issue port for 8).  hipcc does not produce that order: left
+// alone it emits the chains one after the other, and sched_group_barrier patterns did not survive its other passes here.  So
+// the order is written down: behind every MFMA one SLICE of chain B (a tap = 4 dwords: 8 unpack + 4 v_pk_fma_f32; later the
+// GELU of one channel pair), the A-operand fragment reads three MFMAs ahead in a rotating register set, and a
+// sched_barrier(0) behind every step, which nothing crosses.  The LDS regions arrive as __restrict__ pointers (through one char
+// array the compiler must assume that H written and H read alias, and orders every load behind every store).
+template <bool FC1, bool F1, bool DW, bool F2, int NACC>
+__device__ __forceinline__ void md_body(const char* __restrict__ st, char* __restrict__ hw, const char* __restrict__ hr,
+                                        char* __restrict__ gw, const char* __restrict__ gr, char* __restrict__ dump,
+                                        const float* __restrict__ tpn, float (&tap)[80], const u32x4 (&xf)[FC1 ? 20 : 1], f32x16 (&oacc)[NACC],
+                                        const unsigned (&hoff)[9], float rs, float mrs, int hw_off, int hw_sw, int gw_off, int cg, int h,
+                                        int gr_off, int gr_sw, int d0, int lane) {
+    constexpr int N1 = (FC1 && F1) ? 20 : 0, N2 = F2 ? 2 * NACC : 0, NM = N1 + N2;      // matrix instructions of this iteration
+    // ---- loads first: the nine H rows of this lane's token (taps outside the image: the zero row at offset 0), its G column
+    uint4 hraw[9];
+    if (DW)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) hraw[k] = *reinterpret_cast<const uint4*>(hr + hoff[k]);
+    uint4 g0 = make_uint4(0u, 0u, 0u, 0u), g1 = g0;
+    if (F2) {
+        g0 = *reinterpret_cast<const uint4*>(gr + gr_off + ((h ^ gr_sw) * 16));
+        g1 = *reinterpret_cast<const uint4*>(gr + gr_off + (((2 + h) ^ gr_sw) * 16));
+    }
+    // A-operand fragment m of the iteration: W1 piece m (m < N1), then W2 piece (d0 + d) * 2 + sp with m - N1 = 2 d + sp
+    const char* w1b = st + lane * 16;
+    const char* w2b = st + MD_W2OFF + d0 * 2048 + lane * 16;
+    auto frag = [&](int m) -> uint4 {
+        return *reinterpret_cast<const uint4*>(m < N1 ? w1b + m * 1024 : w2b + (m - N1) * 1024);
+    };
+    constexpr int AHEAD = 3;
+    uint4 wf[AHEAD + 1];
+#pragma unroll
+    for (int m = 0; m < AHEAD && m < NM; ++m) wf[m] = frag(m);
+    __builtin_amdgcn_sched_barrier(0);
+
+    f32x16 hacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
+    f32x2 o[4];                                            // chain B: four channel pairs of this lane's token
+    uint4 ov = make_uint4(0u, 0u, 0u, 0u);
+    // slice s of chain B: 0..8 = tap s, 9..12 = GELU + rounding of channel pair s - 9, 13 = the store
+    auto slice = [&](int sl) {
+        if (!DW) return;
+        if (sl == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f32x2{tap[72 + 2 * j], tap[72 + 2 * j + 1]};
+        }
+        if (sl < 9) {
+            const unsigned rw[4] = {hraw[sl].x, hraw[sl].y, hraw[sl].z, hraw[sl].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x2 v = {__uint_as_float(rw[j] << 16), __uint_as_float(rw[j] & 0xFFFF0000u)};
+                const f32x2 w = {tap[8 * sl + 2 * j], tap[8 * sl + 2 * j + 1]};
+                o[j] = __builtin_elementwise_fma(v, w, o[j]);
+            }
+        } else if (sl < 13) {
+            const int j = sl - 9;
+            const f32x2 g = gelu_poly2(o[j]);
+            bf16x2 b2_;
+            b2_[0] = (bf16_t)g[0];
+            b2_[1] = (bf16_t)g[1];
+            reinterpret_cast<unsigned*>(&ov)[j] = __builtin_bit_cast(unsigned, b2_);
+        } else if (sl == 13) {
+            // (lanes without a token store to the dump row: no branch)
+            *reinterpret_cast<uint4*>(gw_off >= 0 ? gw + gw_off : dump + 16 * cg) = ov;
+        }
+    };
+    constexpr int NSL = 14;
+    // chain A's tail in four slices (one per 8 hidden channels), placed behind the LAST four matrix instructions of the iteration
+    auto tail = [&](int g) {
+        if (!(FC1 && F1)) return;
+        const float* cs = reinterpret_cast<const float*>(st + MD_COFF);       // [b1 (32) | column sums of W1 (32)]
+        char* hb = hw_off >= 0 ? hw + hw_off : dump + 8 * h;
+        const float4 b4 = *reinterpret_cast<const float4*>(cs + 8 * g + 4 * h);
+        const float4 c4 = *reinterpret_cast<const float4*>(cs + 32 + 8 * g + 4 * h);
+        bf16x4 hv;
+        hv[0] = (bf16_t)fmaf(hacc[4 * g + 0], rs, fmaf(-mrs, c4.x, b4.x));
+        hv[1] = (bf16_t)fmaf(hacc[4 * g + 1], rs, fmaf(-mrs, c4.y, b4.y));
+        hv[2] = (bf16_t)fmaf(hacc[4 * g + 2], rs, fmaf(-mrs, c4.z, b4.z));
+        hv[3] = (bf16_t)fmaf(hacc[4 * g + 3], rs, fmaf(-mrs, c4.w, b4.w));
+        *reinterpret_cast<bf16x4*>(hb + ((g ^ hw_sw) * 16)) = hv;
+    };
+
+    // ---- the schedule: step m = matrix instruction m, the fragment read of m + AHEAD, one slice of chain B (steps without an
+    // MFMA -- iterations 0, 1 and the tile-less rows of an outer band -- still run their slices)
+    constexpr int NSTEP = NM > NSL ? NM : NSL;
+#pragma unroll
+    for (int m = 0; m < NSTEP; ++m) {
+        if (m < NM) {
+            const bf16x8 a = __builtin_bit_cast(bf16x8, wf[m % (AHEAD + 1)]);
+            if (m < N1) {
+                hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, xf[m < 20 ? m : 0]), hacc, 0, 0, 0);
+            } else {
+                const int k = m - N1;
+                oacc[k >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, (k & 1) ? g1 : g0), oacc[k >> 1], 0, 0, 0);
+            }
+            if (m + AHEAD < NM) wf[(m + AHEAD) % (AHEAD + 1)] = frag(m + AHEAD);
+        }
+        if (m < NSL) slice(m);
+        // chain A's tail needs all of fc1's MFMAs: behind the last four matrix instructions when those are fc2's
+        if (N2 >= 4 && m >= NSTEP - 4) tail(m - (NSTEP - 4));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (N2 < 4)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) tail(g);
+    // ---- the NEXT iteration's taps + bias (8 channels x 10, wave-uniform: scalar loads), issued behind this iteration's last LDS
+    // read: a scalar load in flight turns every LDS wait of the block into lgkmcnt(0) (scalar loads return out of order).
+    // (the last iterations load chunk 0's again: no branch)
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tap[8 * k + j] = tpn[k * MD_CH + j];
+}
 
 // one wave's share of the launch.  FC1: the wave holds a token tile of the band + halo (waves 0..5); DW_FIRST: the wave runs the
 // depthwise pass ahead of its MFMA phases (waves 4..7).  Three instantiations, entered through wave-uniform branches: every wave
@@ -101,6 +252,7 @@ __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict_
     auto issue = [&](int s) {
         const unsigned base = lds0 + (unsigned)((s % 3) * MD_STAGE);
         const unsigned src = (unsigned)(s * MD_STAGE + lane * 16);
+        if (MD_SKIP(8)) return;
 #pragma unroll
         for (int j = 0; j < 5; ++j) md_dma16(base + (5 * wave + j) * 1024, src + (5 * wave + j) * 1024, rsW);
         if (wave == 0) md_dma16(base + 40 * 1024, src + 40 * 1024, rsW);
@@ -159,7 +311,9 @@ __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict_
     const int w3 = FC1 ? wave % 3 : 0;
     const int tw = FC1 ? 2 + wave / 3 : wave - 6;
     const int d0 = FC1 ? 3 * w3 : 0;
-    const bool four = !FC1 || w3 == 2;                               // (waves 0..5) a fourth channel tile
+    // (waves 0..5 with three own tiles run a fourth -- their neighbour's first -- and drop it: a branch in the loop body would cut
+    // the basic block the scheduler interleaves, and two MFMAs per iteration are cheaper than that)
+    const bool four = !FC1 || w3 == 2;
     const int n2 = 32 * tw + lq;                                     // own-token index of this lane's fc2 column
     f32x16 oacc[NACC];
 #pragma unroll
@@ -167,71 +321,17 @@ __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
 
-    // the three phases of an iteration ------------------------------------------------------------------------------------------
-    auto fc1 = [&](int t, const char* st) {                          // chunk t: W1 fragments of stage t -> H[t & 1]
-        f32x16 hacc;
+#ifdef EMIP_TUNING
+    unsigned long long pacc[5] = {0, 0, 0, 0, 0}, last_ = __builtin_readcyclecounter();
+    const unsigned long long start_ = last_;
+#endif
+    float tap[80];                                                   // the depthwise taps + bias of the NEXT depthwise pass (scalars)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) hacc[r] = 0.f;
-#pragma unroll
-        for (int i = 0; i < (FC1 ? 20 : 0); ++i) {
-            const uint4 wf = *reinterpret_cast<const uint4*>(st + i * 1024 + lane * 16);
-            hacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf[i]), hacc, 0, 0, 0);
-        }
-        // register 4 g + j = hidden channel 8 g + 4 h + j of the chunk, for this lane's token: output-side LayerNorm + bias
-        const float* cs = reinterpret_cast<const float*>(st + MD_COFF);       // [b1 (32) | column sums of W1 (32)]
-        char* hb = smem + OFF_H + (t & 1) * MD_HB + 64 + fr * 64 + 8 * h;
-        const int sw = (fr >> 2) & 3;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 b4 = *reinterpret_cast<const float4*>(cs + 8 * g + 4 * h);
-            const float4 c4 = *reinterpret_cast<const float4*>(cs + 32 + 8 * g + 4 * h);
-            bf16x4 hv;
-            hv[0] = (bf16_t)fmaf(hacc[4 * g + 0], rs, fmaf(-mrs, c4.x, b4.x));
-            hv[1] = (bf16_t)fmaf(hacc[4 * g + 1], rs, fmaf(-mrs, c4.y, b4.y));
-            hv[2] = (bf16_t)fmaf(hacc[4 * g + 2], rs, fmaf(-mrs, c4.z, b4.z));
-            hv[3] = (bf16_t)fmaf(hacc[4 * g + 3], rs, fmaf(-mrs, c4.w, b4.w));
-            if (fr < nh) *reinterpret_cast<bf16x4*>(hb + ((g ^ sw) * 16)) = hv;
-        }
-    };
-    auto dwp = [&](int t) {                                          // chunk t: H[t & 1] -> depthwise 3 x 3 + bias + GELU -> G[t & 1]
-        const float* tp = taps + (long)t * (10 * MD_CH) + 8 * cg;    // wave-uniform: scalar loads
-        const char* hb = smem + OFF_H + (t & 1) * MD_HB;
-        float o[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = tp[9 * MD_CH + j];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) {
-            const uint4 raw = *reinterpret_cast<const uint4*>(hb + hoff[k]);
-            const unsigned rw[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[2 * j] = fmaf(__uint_as_float(rw[j] << 16), tp[k * MD_CH + 2 * j], o[2 * j]);
-                o[2 * j + 1] = fmaf(__uint_as_float(rw[j] & 0xFFFF0000u), tp[k * MD_CH + 2 * j + 1], o[2 * j + 1]);
-            }
-        }
-        bf16x8 ov;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ov[j] = (bf16_t)gelu_poly(o[j]);
-        if (q_ok) *reinterpret_cast<bf16x8*>(smem + OFF_G + (t & 1) * MD_GB + goff) = ov;
-    };
-    auto fc2 = [&](int t, const char* st) {                          // chunk t: G[t & 1] x W2 fragments (stage t + 2) -> accumulators
-        const char* gb = smem + OFF_G + (t & 1) * MD_GB + n2 * 64;
-        const int sw = (n2 >> 2) & 3;
-        const bf16x8 g0 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gb + ((h ^ sw) * 16)));
-        const bf16x8 g1 = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(gb + (((2 + h) ^ sw) * 16)));
-        const char* wb = st + MD_W2OFF + d0 * 2048 + lane * 16;
-#pragma unroll
-        for (int d = 0; d < NACC; ++d) {
-            if (FC1 && d == 3 && !four) break;
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb + d * 2048)), g0,
-                                                              oacc[d], 0, 0, 0);
-            oacc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(wb + d * 2048 + 1024)),
-                                                              g1, oacc[d], 0, 0, 0);
-        }
-    };
-
-#pragma unroll 1
-    for (int t = 0; t < MD_NST; ++t) {
+    for (int k = 0; k < 80; ++k) tap[k] = 0.f;
+    // one iteration (md_body below); which of the three phases exist is a compile-time matter -- the first two and the last two
+    // iterations lack some -- so that the steady state, iterations 2 .. 39, is ONE basic block
+    auto iteration = [&](int t, auto f1_, auto dw_, auto f2_) {
+        constexpr bool F1 = decltype(f1_)::value, DW = decltype(dw_)::value, F2 = decltype(f2_)::value;
         // stage t has landed once all but this wave's pieces of stage t + 1 (issued one iteration ago) are done
         if (t + 1 < MD_NST) {
             if (wave == 0) md_wait<6>();
@@ -241,13 +341,33 @@ __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict_
         }
         __builtin_amdgcn_s_barrier();                      // ... for every wave; H / G of the previous iteration are complete, and
         __builtin_amdgcn_sched_barrier(0);                 // everyone has left stage t - 1's slot and the buffers written next
+        MD_STAMP(0);
         if (t + 2 < MD_NST) issue(t + 2);
-        const char* st = smem + (t % 3) * MD_STAGE;
-        if (DW_FIRST && t >= 1 && t <= MD_NCH) dwp(t - 1);
-        if (FC1 && t < MD_NCH) fc1(t, st);
-        if (t >= 2) fc2(t - 2, st);
-        if (!DW_FIRST && t >= 1 && t <= MD_NCH) dwp(t - 1);
+        MD_STAMP(1);
+        const int b1_ = t & 1, b0_ = b1_ ^ 1;               // H[t & 1] is written, H[(t - 1) & 1] read; G[(t - 1) & 1] written, G[t & 1] read
+        md_body<FC1, F1, DW, F2, NACC>(
+            smem + (t % 3) * MD_STAGE, smem + OFF_H + b1_ * MD_HB, smem + OFF_H + b0_ * MD_HB, smem + OFF_G + b0_ * MD_GB,
+            smem + OFF_G + b1_ * MD_GB, smem + OFF_DUMP, taps + (long)((MD_SKIP(32) || t >= MD_NCH) ? 0 : t) * (10 * MD_CH) + 8 * cg,
+            tap, xf, oacc, hoff,
+            rs, mrs, fr < nh ? 64 + fr * 64 + 8 * h : -1, fr < nh ? (fr >> 2) & 3 : 0, q_ok ? (int)goff : -1, cg, h,
+            n2 * 64, (n2 >> 2) & 3, d0, lane);
+        MD_STAMP(2);
+    };
+    typedef std::true_type Y_;
+    typedef std::false_type N_;
+    iteration(0, Y_{}, N_{}, N_{});
+    iteration(1, Y_{}, Y_{}, N_{});
+#pragma unroll 1
+    for (int t = 2; t < MD_NCH; ++t) iteration(t, Y_{}, Y_{}, Y_{});
+    iteration(MD_NCH, N_{}, Y_{}, Y_{});
+    iteration(MD_NCH + 1, N_{}, N_{}, Y_{});
+#ifdef EMIP_TUNING
+    if (p.prof && lane == 0) {
+        unsigned long long* pr = p.prof + ((long)blockIdx.x * 8 + wave) * 6;
+        for (int i = 0; i < 5; ++i) pr[i] = pacc[i];
+        pr[5] = __builtin_readcyclecounter() - start_;
     }
+#endif
 
     // ---- epilogue: + b2 + x in the accumulator layout, one rounding, -> an LDS image of the band (in the idle ring).
     // register 4 g + j of accumulator tile d = output channel 32 (d0 + d) + 8 g + 4 h + j of token n2
@@ -331,6 +451,13 @@ __global__ __launch_bounds__(512) void mlp_band_kernel(const MdArgs p, const flo
 
 }  // namespace
 
+#ifdef EMIP_TUNING
+static int g_md_skip = 0;
+static unsigned long long* g_md_prof = nullptr;
+extern "C" int emip_debug_set_md(int flags) { g_md_skip = flags; return 0; }
+extern "C" int emip_debug_set_md_prof(void* buf) { g_md_prof = (unsigned long long*)buf; return 0; }   // [B * 4 * 8][6] u64 or NULL
+#endif
+
 extern "C" int emip_mlp_band_eligible(int B, int H, int W, int C, int N) {
     return B > 0 && H == MD_HW && W == MD_HW && C == MD_C && N == MD_N;
 }
@@ -358,6 +485,10 @@ extern "C" int emip_mlp_band(const void* X, long ldx, const void* Wst, const flo
     a.ln_stats = ln_stats; a.out_stats = out_stats; a.ldx = ldx; a.ldo = ldo; a.B = B; a.eps = eps;
     a.xcd_map = (B % 8) == 0;
     a.wst_bytes = (unsigned)(MD_NST * MD_STAGE);
+#ifdef EMIP_TUNING
+    a.skip = g_md_skip;
+    a.prof = g_md_prof;
+#endif
     static bool attr = false;
     if (!attr) {
         attr = true;

@@ -805,6 +805,11 @@ __global__ __launch_bounds__(256) void dwconv3x3_rows_kernel(const T* __restrict
 // Per-(group, channel) sum and sum of squares over `rows` rows: InstanceNorm2d statistics
 // (group = image) and train-mode BatchNorm statistics (one group).  f64 atomics combine the
 // block partials so that E[x^2]-E[x]^2 is evaluated without cancellation trouble.
+// Round 4: every block partial is rounded to a multiple of 2^-24 before it is added.  Sums of such
+// multiples below 2^29 are EXACT in f64, exact additions commute and associate, so the totals no
+// longer depend on the order in which the blocks arrive (reproducible bit for bit); the rounding
+// moves a partial by at most 3e-8, eleven orders below the sums it joins.
+__device__ __forceinline__ double chan_q24(float t) { return rint((double)t * 16777216.0) * (1.0 / 16777216.0); }
 template <typename T>
 __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ X, long ldx, double* __restrict__ sums,
                                                          long rows, int C, int rows_per_block) {
@@ -842,8 +847,8 @@ __global__ __launch_bounds__(256) void chan_stats_kernel(const T* __restrict__ X
         double* dst = sums + (g * C + threadIdx.x * 4) * 2;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            atomicAdd(dst + j * 2, (double)ts[j]);
-            atomicAdd(dst + j * 2 + 1, (double)ts[4 + j]);
+            atomicAdd(dst + j * 2, chan_q24(ts[j]));
+            atomicAdd(dst + j * 2 + 1, chan_q24(ts[4 + j]));
         }
     }
 }
@@ -907,7 +912,7 @@ __global__ __launch_bounds__(256) void chan_stats_wide_kernel(const bf16_t* __re
         const int slot = (c >> 3) * 16 + which * 8 + (c & 7);
         float t = 0.f;
         for (int l = 0; l < plan; ++l) t += red[l * nv * 16 + slot];
-        atomicAdd(sums + (g * C + c) * 2 + which, (double)t);
+        atomicAdd(sums + (g * C + c) * 2 + which, chan_q24(t));
     }
 }
 

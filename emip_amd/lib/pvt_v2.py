@@ -30,7 +30,7 @@ FUSED_LN = True
 # GEMM) and takes it from SRA_BLOCK_WIDE_ROWS token rows on: at the 32 images of a whole 16-pair step it is
 # ahead (1587 against 1580 pairs/s in-process, tools/flag_ab.py) and 40 launches fewer
 SRA_BLOCK_MAXC = 128
-SRA_BLOCK_WIDE_ROWS = 12000
+SRA_BLOCK_WIDE_ROWS = 0        # round 4: always (12 000 before: 2334 / 2328 pairs/s either way at 16 images, and this form owns its rows: reproducible statistics without a second pass)
 # q projection inside the attention launch (emip_sra_block / emip_sra_qattn).  False = q GEMM + emip_sra_attention, the form
 # stage 4 (sr_ratio 1) always takes; tests/test_sra_block_gpu.py runs a block both ways and compares
 SRA_FUSED = True

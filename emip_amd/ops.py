@@ -791,7 +791,7 @@ def sra_qattn(x, stats, eps, wq, bq, colsum_q, kv, heads, scale):
 def mdta_attn(q, kv_k, temperature, B, heads, P):
     """q [B,P,ldq] view, kv_k [B,P,ldk] view (the k half) -> attn [B,heads,64,64]."""
     _dev(q)
-    ws = torch.empty(B * heads * (4096 + 128), dtype=torch.float32, device=q.device)
+    ws = torch.empty(_lib.load().emip_mdta_ws_floats(B, heads), dtype=torch.float32, device=q.device)
     attn = torch.empty((B, heads, 64, 64), dtype=q.dtype, device=q.device)
     _lib.call("emip_mdta_attn", _p(q), q.stride(-2), q.stride(0), _p(kv_k), kv_k.stride(-2), kv_k.stride(0),
               _p(temperature), _p(ws), _p(attn), B, heads, P, dt_code(q.dtype), _stream())
@@ -1318,11 +1318,11 @@ def colscale_add(a, b, s, lds, rows_per_group, out):
 def mdta_attn_ws(q, kv_k, temperature, B, heads, P):
     """like mdta_attn, also returning the f32 workspace [G | nq^2 | nk^2] the backward needs"""
     _dev(q)
-    ws = torch.empty(B * heads * (4096 + 128), dtype=torch.float32, device=q.device)
+    ws = torch.empty(_lib.load().emip_mdta_ws_floats(B, heads), dtype=torch.float32, device=q.device)
     attn = torch.empty((B, heads, 64, 64), dtype=q.dtype, device=q.device)
     _lib.call("emip_mdta_attn", _p(q), q.stride(-2), q.stride(0), _p(kv_k), kv_k.stride(-2), kv_k.stride(0),
               _p(temperature), _p(ws), _p(attn), B, heads, P, dt_code(q.dtype), _stream())
-    return ws, attn
+    return ws[:B * heads * (4096 + 128)], attn
 
 
 def mdta_bwd_small(ws, temperature, attn, dA, B, heads):

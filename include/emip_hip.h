@@ -303,7 +303,10 @@ int emip_ffn_block(const void* X1, long ld1, const void* X2, long ld2, const voi
                    const float* beta, float eps, const void* Res, long ldr, void* Out, long ldo, long M, void* stream);
 
 /* MDTA channel attention matrix: L2-normalise q,k over pixels, 64x64 Gram per head, * temperature, softmax.
- * PromptInteract.py:423-428.  ws: f32 [B*heads*(4096+128)] scratch; attn out: T [B][heads][64][64]. */
+ * PromptInteract.py:423-428.  ws: f32 scratch of emip_mdta_ws_floats(B, heads) floats -- the complete sums [G | nq | nk] per
+ * (image, head) first (B*heads*(4096+128) floats, what the backward reads), then the per-workgroup partial sums the softmax
+ * kernel adds in slot order (no atomics: reproducible bit for bit); attn out: T [B][heads][64][64]. */
+int emip_mdta_ws_floats(int B, int heads);
 int emip_mdta_attn(const void* Q, long ldq, long q_bs, const void* K, long ldk, long k_bs, const float* temperature,
                    float* ws, void* attn, int B, int heads, int P, int dtype, void* stream);
 
@@ -746,6 +749,8 @@ int emip_debug_set_lnb(int wide);               /* 0 = the narrow LayerNorm-back
 int emip_debug_set_dww(int chunks);             /* row chunks per image of the depthwise weight gradient (0 = auto) */
 int emip_debug_set_tn8(int ring_depth, int target_workgroups);   /* emip_gemm_tn8: 2..4 stages; 0 = heuristic split count */
 int emip_debug_set_wa(int flags);              /* emip_window_attention ablations: 1 no S MFMAs, 2 no softmax, 4 no PV, 8 no DMA */
+int emip_debug_set_md(int flags);              /* emip_mlp_band ablations: 1 no fc1 MFMAs, 2 no depthwise pass, 4 no fc2 MFMAs, 8 no weight DMA, 16 no H / G stores, 32 constant taps */
+int emip_debug_set_md_prof(void* buf);         /* emip_mlp_band: u64 [workgroups * 8 waves][6] cycle counters (barrier wait, DMA issue, fc1, fc2, depthwise, total) or NULL */
 int emip_debug_set_mb(int flags);              /* emip_mlp_block ablations: 1 no fc1 MFMAs, 2 no depthwise pass, 4 no fc2 MFMAs, 8 no weight DMA, 16 no H store */
 int emip_tuning_gemm8_dbg(int flags);           /* gemm8 ablations: 1 no epilogue stores, 2 no MFMA, 4 no operand loads, 8 bare launch */
 #endif

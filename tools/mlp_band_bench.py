@@ -27,8 +27,15 @@ def timed(fn, reps=20):
     return best, g
 
 
+_STREAMS = []
+
+
 def concurrent(graphs, reps=5):
-    streams = [torch.cuda.Stream() for _ in graphs]
+    # one fixed set of streams, created back to back: streams map onto the runtime's 4 hardware queues round-robin, and a fresh
+    # set per call can put two of them on one queue (observed: "2 at once" twice as long as "1", "4 at once" no longer than "2")
+    while len(_STREAMS) < len(graphs):
+        _STREAMS.append(torch.cuda.Stream())
+    streams = _STREAMS[:len(graphs)]
     torch.cuda.synchronize()
     best = 1e9
     for _ in range(reps):
