@@ -778,6 +778,7 @@ extern "C" int emip_conv8(const void*, const void*, void*, const float*, const v
 namespace emip_internal {
 int gemm8_choice(int M, int N, long K, long lda, long ldw, int K1, bool has_a2, long lda2);
 int conv8_choice(int M, int Cout, int Cin, int KH, int KW, long a_elems);
+int row_stats(const void* C, long ldc, float* out_stats, int M, int N, void* stream);   // gemm8.hip: fixed-order row sums of a bf16 matrix
 }
 
 // head strides handed from emip_gemm_heads to the shared entry body below (host-side, set and cleared around the call)
@@ -877,6 +878,13 @@ extern "C" int emip_gemm_ln(const void* A, const void* A2, const void* W, void* 
         if (check_ln(a, batch, fast) != EMIP_OK) return EMIP_E_INVALID;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EMIP_BF16 && a.out_stats && batch == 1) {
+        // round 4: the 4-wave body adds a row's statistics with one f32 atomic pair per wave and column tile, in arrival order;
+        // in the bf16 mode they come from a fixed-order pass over the stored rows instead (reproducible bit for bit)
+        a.out_stats = nullptr;
+        const int rc = dispatch<bf16_t, false>(a, batch, s);
+        return rc != EMIP_OK ? rc : emip_internal::row_stats(C, ldc, out_stats, M, N, stream);
+    }
     return dtype == EMIP_F32 ? dispatch<float, false>(a, batch, s) : dispatch<bf16_t, false>(a, batch, s);
 }
 
@@ -944,6 +952,11 @@ extern "C" int emip_conv2d_splitk(const void* X, const void* W, void* Y, const f
         if (check_ln(a, 1, fast) != EMIP_OK) return EMIP_E_INVALID;
     }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (dtype == EMIP_BF16 && a.out_stats) {      // as in emip_gemm_ln: the statistics by a fixed-order pass over the stored rows
+        a.out_stats = nullptr;
+        const int rc = dispatch<bf16_t, true>(a, 1, s);
+        return rc != EMIP_OK ? rc : emip_internal::row_stats(Y, ldy, out_stats, a.M, a.N, stream);
+    }
     return dtype == EMIP_F32 ? dispatch<float, true>(a, 1, s) : dispatch<bf16_t, true>(a, 1, s);
 }
 
