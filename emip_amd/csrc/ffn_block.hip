@@ -21,6 +21,7 @@ namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ff_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ i32x4 ff_rsrc(const void* ptr, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
@@ -68,12 +69,17 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void f
     const long tok = (long)blockIdx.x * 256 + wave * 32 + lq;
     const bool ok = tok < p.M;
     const long tc = ok ? tok : p.M - 1;
-    uint4 xf[16];
+    ff_u32x4 xf[16];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        xf[i] = *reinterpret_cast<const uint4*>(p.X1 + tc * p.ld1 + (2 * i + h) * 8);
-        xf[8 + i] = *reinterpret_cast<const uint4*>(p.X2 + tc * p.ld2 + (2 * i + h) * 8);
+        xf[i] = *reinterpret_cast<const ff_u32x4*>(p.X1 + tc * p.ld1 + (2 * i + h) * 8);
+        xf[8 + i] = *reinterpret_cast<const ff_u32x4*>(p.X2 + tc * p.ld2 + (2 * i + h) * 8);
     }
+    // round 4: the compiler's wait for these loads belongs HERE.  Left to the first use it sat inside the chunk loop -- vmcnt(15) ..
+    // vmcnt(0) between the MFMAs of EVERY iteration -- where it drained the weight ring the compiler cannot see (the LDS-DMAs are
+    // inline asm)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) asm volatile("" : "+v"(xf[i]));
 
     // ---- a chunk = 24 contiguous 1-KB pieces (16 of W0, 8 of W2); wave w moves pieces 3 w .. 3 w + 2
     auto issue = [&](int c) {

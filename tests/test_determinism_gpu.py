@@ -69,14 +69,21 @@ def test_steps_in_flight_reproduce_the_eager_bits(model_args, short_sd):
         im1, im2 = synthetic_pair(16, seed=77)
         im1, im2 = im1.cuda(), im2.cuda()
         with torch.no_grad():
-            ref = net(im1, im2)[0].clone()
+            o = net(im1, im2)
+            ref, ref_fw, ref_bw = o[0].clone(), o[1][0].clone(), o[2][0].clone()
         runner = PipelinedShort(net, 16, inflight=4)
         runner.load(im1, im2)
         torch.cuda.synchronize()
-        for _ in range(11):
-            runner.replay_free()
-        torch.cuda.synchronize()
-        for slot in range(4):
-            assert torch.equal(runner.outputs(slot)[0], ref), slot
+        # 30 rounds x 4 slots: round 3's build failed ~4 % of such samples (one wrong channel for 16 tokens out of emip_ffn_block's
+        # packed-f32 LayerNorm epilogue, only with other steps' kernels on the chip: emip_amd/csrc/Makefile) -- inside the
+        # run-to-run band its tests allowed; a bit-exact comparison sees it
+        for rnd in range(30):
+            for _ in range(11):
+                runner.replay_free()
+            torch.cuda.synchronize()
+            for slot in range(4):
+                m, fw, bw = runner.outputs(slot)
+                assert torch.equal(m, ref), (rnd, slot, (m.float() - ref.float()).abs().max().item())
+                assert torch.equal(fw[0], ref_fw) and torch.equal(bw[0], ref_bw), (rnd, slot)
     finally:
         nn_base.set_default_dtype(torch.float32)

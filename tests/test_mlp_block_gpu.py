@@ -74,6 +74,7 @@ def test_block_run_fused_with_and_without_the_one_launch_mlp():
         B, H, W, C = 8, 22, 22, 320
         x0 = (torch.randn(B, H, W, C, device="cuda") * 1.2).to(torch.bfloat16)
         outs = []
+        keep_band, pvt_v2.MLP_BAND = pvt_v2.MLP_BAND, False      # (round 4's emip_mlp_band would take the launch: tests/test_mlp_band_gpu.py)
         for flag in (True, False):
             pvt_v2.MLP_BLOCK = flag
             try:
@@ -92,6 +93,7 @@ def test_block_run_fused_with_and_without_the_one_launch_mlp():
             finally:
                 pvt_v2.MLP_BLOCK = False
                 _lib.profile(None)
+        pvt_v2.MLP_BAND = keep_band
         (a, sa), (b, sb) = outs
         top = max(1.0, b.abs().max().item())
         assert (a - b).abs().max().item() < 2e-2 * top and (a - b).abs().mean().item() < 1e-3 * top

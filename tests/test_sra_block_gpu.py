@@ -132,6 +132,7 @@ def test_pvt_block_fused_path_uses_it_and_matches_the_unfused_launches():
     B, H, W, C = 4, 22, 22, 320
     x0 = (torch.randn(B, H, W, C, device="cuda") * 1.2).to(torch.bfloat16)
     outs = []
+    wide, pvt_v2.SRA_BLOCK_WIDE_ROWS = pvt_v2.SRA_BLOCK_WIDE_ROWS, 10 ** 9      # the q + attention launch form (round 4's default is emip_sra_block)
     for flag in (True, False):
         pvt_v2.SRA_FUSED = flag
         try:
@@ -150,6 +151,7 @@ def test_pvt_block_fused_path_uses_it_and_matches_the_unfused_launches():
         finally:
             pvt_v2.SRA_FUSED = True
             _lib.profile(None)
+    pvt_v2.SRA_BLOCK_WIDE_ROWS = wide
     nn_base.set_default_dtype(prev)
     (a, sa), (b, sb) = outs
     top = max(1.0, b.abs().max().item())

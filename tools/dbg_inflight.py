@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""stress the steps-in-flight arrangement for bit-exactness against the eager forward; on a mismatch say where (which images,
+how many elements, how large)"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from emip_amd import nn_base
+from emip_amd.filler import state_dict_from_manifest, synthetic_pair
+from emip_amd.graph import PipelinedShort
+from emip_amd.model.EMIP_short.model import CoUpdater
+from emip_amd.lib import pvt_v2
+import importlib
+for kv in os.environ.get("EMIP_DBG", "").split(","):      # e.g. EMIP_DBG="emip_amd.lib.pvt_v2:MLP_BAND=False,...:FFN_BLOCK=False"
+    if "=" in kv:
+        k, v = kv.split("=")
+        mn, k = k.split(":")
+        mod = importlib.import_module(mn)
+        assert hasattr(mod, k), (mn, k)
+        setattr(mod, k, eval(v))
+        print("set", mod.__name__, k, eval(v))
+inflight = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+g = os.path.join(ROOT, "tests", "golden")
+margs = json.load(open(os.path.join(g, "model_args.json")))
+sd = state_dict_from_manifest(json.load(open(os.path.join(g, "short_state_manifest.json"))), 0)
+nn_base.set_default_dtype(torch.bfloat16)
+net = CoUpdater(margs); net.load_state_dict(sd); net = net.to("cuda:0").eval()
+im1, im2 = synthetic_pair(16, seed=77)
+im1, im2 = im1.cuda(), im2.cuda()
+def flat(d, prefix=""):
+    out = {}
+    for k, v in (d.items() if isinstance(d, dict) else enumerate(d)):
+        if torch.is_tensor(v): out[f"{prefix}{k}"] = v
+        elif isinstance(v, (dict, list, tuple)): out.update(flat(v, f"{prefix}{k}."))
+    return out
+from emip_amd.model.EMIP_short.motion.gmflow import transformer as TR
+TAPS = os.environ.get("EMIP_TAPS") == "1"
+if TAPS:
+    TR.DEBUG_TAPS = []
+with torch.no_grad():
+    ref = [t.clone() for t in (lambda o: (o[0], o[1][0], o[2][0]))(net(im1, im2))]
+    ref_taps = list(TR.DEBUG_TAPS) if TAPS else []
+    ref_last = {k: v.clone() for k, v in flat(net.last).items()}
+    ref_gm = {k: v.clone() for k, v in flat(net.GMFlow.last).items()} if hasattr(net.GMFlow, "last") else {}
+r = PipelinedShort(net, 16, inflight=inflight); r.load(im1, im2)
+ntap = len(ref_taps)
+# every part ran two warm-up forwards and the captured one: its taps are the last ntap of its 3 ntap entries
+part_taps = [TR.DEBUG_TAPS[ntap + (3 * i + 2) * ntap: ntap + (3 * i + 3) * ntap] for i in range(inflight)] if TAPS else []
+torch.cuda.synchronize()
+bad = 0
+for rnd in range(rounds):
+    for _ in range(2 * inflight + 3):
+        r.replay_free()
+    torch.cuda.synchronize()
+    for slot in range(inflight):
+        m, fw, bw = r.outputs(slot)
+        for name, a, b in (("mask", m, ref[0]), ("fw", fw[0], ref[1]), ("bw", bw[0], ref[2])):
+            if not torch.equal(a, b):
+                d = (a.float() - b.float()).abs()
+                imgs = [i for i in range(d.shape[0]) if d[i].max() > 0]
+                print("round %d slot %d %s: %d elements differ, max %.4f, images %s" % (rnd, slot, name, int((d > 0).sum()), d.max().item(), imgs), flush=True)
+                bad += 1
+                if name == "mask" and TAPS:
+                    for (tn, tv), (rn, rv) in zip(part_taps[slot], ref_taps):
+                        if not torch.equal(tv, rv):
+                            dd = (tv.float() - rv.float()).abs()
+                            bi = [i for i in range(dd.shape[0]) if dd[i].max() > 0]
+                            nz = (dd[bi[0]] > 0).nonzero()
+                            print("      tap %-10s differs: max %.4f, batch entries %s; entry %d: %d elements, token range %d..%d, channel range %d..%d" % (
+                                tn, dd.max().item(), bi[:8], bi[0], nz.shape[0], nz[:, 0].min().item(), nz[:, 0].max().item(),
+                                nz[:, 1].min().item(), nz[:, 1].max().item()), flush=True)
+                            idx = part_taps[slot].index((tn, tv))
+                            for (t_, c_) in nz[:3].tolist():
+                                b_ = bi[0]
+                                prev = [(part_taps[slot][k][0], part_taps[slot][k][1][b_, t_, c_ if part_taps[slot][k][1].shape[-1] == 128 else 0].item(),
+                                         ref_taps[k][1][b_, t_, c_ if ref_taps[k][1].shape[-1] == 128 else 0].item()) for k in range(max(0, idx - 3), idx + 1)]
+                                print("         (image %d, token %d, channel %d): (tap, got, ref) %s; neighbours got %s ref %s" % (
+                                    b_, t_, c_, prev, tv[b_, t_, max(0, c_ - 2):c_ + 3].tolist(), rv[b_, t_, max(0, c_ - 2):c_ + 3].tolist()), flush=True)
+                            break
+                if name == "mask":
+                    for k, v in flat(r.parts[slot].last).items():
+                        if k in ref_last and ref_last[k].shape == v.shape and not torch.equal(v, ref_last[k]):
+                            dd = (v.float() - ref_last[k].float()).abs()
+                            bi = [i for i in range(dd.shape[0]) if dd[i].max() > 0]
+                            print("      intermediate %-12s differs: max %.4f, batch entries %s" % (k, dd.max().item(), bi[:8]), flush=True)
+print("mismatching (round, slot, tensor) triples: %d of %d" % (bad, rounds * inflight * 3))
