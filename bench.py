@@ -81,6 +81,12 @@ def _launch_info(lib, name, a):
         # fc1 as a GEMM + 9 taps per hidden element; tokens in, weights once, activated hidden tensor out (the fc1 output
         # itself never leaves the CU, so it is not algorithmic traffic of this kernel)
         return 2.0 * M * N * K + 18.0 * M * N, "mlp_fc1dw_kernel", 2.0 * (M * K + N * K + M * N) + 8.0 * M + 44.0 * N
+    if name == "emip_mlp_band":           # (X, ldx, Wst, taps, b2, ln_stats, eps, Out, ldo, out_stats, B, H, W, C, N, stream)
+        Bm, H, W, K, N = a[10], a[11], a[12], a[13], a[14]
+        M = Bm * H * W
+        # the whole Mlp half: fc1 + 9 taps per hidden element + fc2 (the halo rows a band recomputes are NOT algorithmic work);
+        # tokens in and out, both weight matrices once, the hidden tensor never leaves the CU
+        return 4.0 * M * N * K + 18.0 * M * N, "mlp_band_kernel", 2.0 * (2 * M * K + 2 * N * K) + 16.0 * M + 48.0 * N
     if name == "emip_window_attention":   # (Q, K, V, O, B, nwin, L, ldq, ldk, ldv, ldo, q_bs, k_bs, v_bs, o_bs, rows, gid, tokens, rot, scale, stream)
         Bf, nwin, L = a[4], a[5], a[6]
         return 4.0 * Bf * nwin * L * L * 128, "wattn_kernel", 2.0 * Bf * nwin * L * 128 * 4
@@ -965,6 +971,10 @@ def main():
                                                "GMFlow split-window attention, 2 x 2 windows of 484 tokens, D = 128, with the "
                                                "layer's merge Linear + norm1 + residual in the epilogue, "
                                                "gmflow/transformer.py:46-105,330-338 (emip_window_attention_merge)"),
+            "mlp_band": named_roofline(agg, "mlp_band_kernel",
+                                       "the Mlp half of a 22x22-stage PVTv2 block per quarter image in one launch: fc1 (norm2 on the "
+                                       "output side) + depthwise 3x3 + GELU + fc2 + residual + row statistics, hidden tensor on the CU "
+                                       "only, lib/pvt_v2.py:45-54,165-169 (emip_mlp_band; algorithmic FLOPs: halo rows not counted)"),
             "ffn": named_roofline(agg, "ffn_block_kernel",
                                   "GMFlow FFN: mlp[0] + GELU + mlp[2] + norm2 + residual in one launch, hidden tensor on the CU "
                                   "only, gmflow/transformer.py:316-345 (emip_ffn_block)"),

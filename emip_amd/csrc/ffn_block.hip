@@ -14,7 +14,7 @@
 //     the key order the accumulator registers have), so a chunk is 24 contiguous KB: LDS-DMA into a 4-slot ring (3 chunks in
 //     flight, one s_barrier + one counted vmcnt per chunk), fragment reads are conflict-free ds_read_b128 at lane * 16;
 //   * epilogue: the lane pair (lq, lq + 32) holds the 128 outputs of a token: LayerNorm statistics by one shuffle, gamma / beta
-//     from LDS, residual added, 8-byte stores.
+//     from LDS, residual added, the pair trades halves (v_permlane32_swap): 16-byte stores.
 #include "common.h"
 
 namespace {
@@ -22,6 +22,7 @@ namespace {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned ff_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ff_u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ i32x4 ff_rsrc(const void* ptr, unsigned bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
@@ -150,26 +151,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void f
     s2 += __shfl_xor(s2, 32);
     const float mean = s1 * (1.0f / FF_C);
     const float rstd = rsqrtf(fmaxf(s2 * (1.0f / FF_C) - mean * mean, 0.f) + p.eps);
-    if (ok) {
-        const bf16_t* rp = p.Res ? p.Res + tok * p.ldr : nullptr;
-        bf16_t* op = p.Out + tok * p.ldo;
+    // Round 4: 16-byte stores.  A lane holds 4 channels (8 bytes) of every 8-channel group and its partner (lane ^ 32) the other 4;
+    // stored as they were, every 128-byte line of the output took sixteen 8-byte partial writes (PMC WRITE_SIZE 50.9 MB for 15.9 MB
+    // of output).  Now the pair trades halves (v_permlane32_swap, as match.hip does for the correlation rows): lane half 0 stores the
+    // 8 channels of group g, lane half 1 those of group g + 1.  Every lane of the wave takes part in the swap (clamped rows of the
+    // last workgroup compute and drop).
+    {
+        const bf16_t* rp = p.Res ? p.Res + tc * p.ldr : nullptr;
+        bf16_t* op = p.Out + tc * p.ldo;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ch = 32 * d + 8 * g + 4 * h;
-                const float4 gm = *reinterpret_cast<const float4*>(tg + ch), bt = *reinterpret_cast<const float4*>(tg + FF_C + ch);
-                const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
-                float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (rp) {
-                    const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp + ch);
+            for (int g = 0; g < 4; g += 2) {
+                bf16x4 o2[2];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) rv[j] = (float)r4[j];
+                for (int e = 0; e < 2; ++e) {
+                    const int ch = 32 * d + 8 * (g + e) + 4 * h;
+                    const float4 gm = *reinterpret_cast<const float4*>(tg + ch), bt = *reinterpret_cast<const float4*>(tg + FF_C + ch);
+                    const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (rp) {
+                        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp + ch);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) rv[j] = (float)r4[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o2[e][j] = (bf16_t)(fmaf((oacc[d][4 * (g + e) + j] - mean) * rstd, gv[j], bv[j]) + rv[j]);
                 }
-                bf16x4 ov;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ov[j] = (bf16_t)(fmaf((oacc[d][4 * g + j] - mean) * rstd, gv[j], bv[j]) + rv[j]);
-                *reinterpret_cast<bf16x4*>(op + ch) = ov;
+                const ff_u32x2 a2 = __builtin_bit_cast(ff_u32x2, o2[0]), b2 = __builtin_bit_cast(ff_u32x2, o2[1]);
+                const auto r0 = __builtin_amdgcn_permlane32_swap(a2.x, b2.x, false, false);
+                const auto r1 = __builtin_amdgcn_permlane32_swap(a2.y, b2.y, false, false);
+                // lanes 0..31: group g = [own half | partner's half]; lanes 32..63: group g + 1 likewise
+                const ff_u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+                if (ok) *reinterpret_cast<ff_u32x4*>(op + 32 * d + 8 * (g + h)) = v;
             }
     }
 }
@@ -182,9 +196,9 @@ extern "C" int emip_ffn_block(const void* X1, long ld1, const void* X2, long ld2
                               const float* gamma, const float* beta, float eps, const void* Res, long ldr, void* Out, long ldo,
                               long M, void* stream) {
     EMIP_REQUIRE(X1 && X2 && W0p && W2p && gamma && beta && Out && M > 0 && M < 2147483647L && eps > 0.f);
-    EMIP_REQUIRE(ld1 >= FF_C && ld2 >= FF_C && ldo >= FF_C && ((ld1 | ld2) & 7) == 0 && (ldo & 3) == 0 && (!Res || (ldr >= FF_C && (ldr & 3) == 0)));
+    EMIP_REQUIRE(ld1 >= FF_C && ld2 >= FF_C && ldo >= FF_C && ((ld1 | ld2 | ldo) & 7) == 0 && (!Res || (ldr >= FF_C && (ldr & 3) == 0)));
     EMIP_REQUIRE(aligned16(X1) && aligned16(X2) && aligned16(W0p) && aligned16(W2p) && aligned16(gamma) && aligned16(beta) &&
-                 (reinterpret_cast<uintptr_t>(Out) & 7u) == 0 && (!Res || (reinterpret_cast<uintptr_t>(Res) & 7u) == 0));
+                 aligned16(Out) && (!Res || (reinterpret_cast<uintptr_t>(Res) & 7u) == 0));
     FfArgs a{};
     a.X1 = (const bf16_t*)X1; a.X2 = (const bf16_t*)X2; a.W0p = (const bf16_t*)W0p; a.W2p = (const bf16_t*)W2p;
     a.gamma = gamma; a.beta = beta; a.Res = (const bf16_t*)Res; a.Out = (bf16_t*)Out;
