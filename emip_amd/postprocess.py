@@ -26,6 +26,20 @@ def mask_to_uint8(mask_logits, shape):
     return out
 
 
+def mask_to_float(mask_logits, shape):
+    """the same resize + sigmoid + per-image min-max as the f32 map in [0, 1] (train.py:125-127: what the validation metrics
+    read); planar f32 [B,1,H,W] on the device -> f32 [B,Ho,Wo] on the device, bit for bit the reference's CPU arithmetic"""
+    assert mask_logits.is_cuda and mask_logits.dtype == torch.float32 and mask_logits.dim() == 4 and mask_logits.shape[1] == 1
+    x = mask_logits.contiguous()
+    B, _, H, W = x.shape
+    Ho, Wo = int(shape[0]), int(shape[1])
+    out = torch.empty((B, Ho, Wo), dtype=torch.float32, device=x.device)
+    ws = torch.empty(2 * B, dtype=torch.int32, device=x.device)
+    _lib.call("emip_postprocess_mask_f32", x.data_ptr(), out.data_ptr(), ws.data_ptr(), B, H, W, Ho, Wo,
+              torch.cuda.current_stream().cuda_stream)
+    return out
+
+
 def mask_to_uint8_host(mask_logits, shape, pinned=None):
     """same, plus an asynchronous copy into (reusable) pinned host memory; returns (host tensor, event to wait on)"""
     dev = mask_to_uint8(mask_logits, shape)

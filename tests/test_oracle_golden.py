@@ -259,3 +259,21 @@ def test_the_long_step_reads_only_stage_two_of_the_first_frame(long_sd, monkeypa
     assert len(calls) == 2
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+def test_postprocess_oracle_equals_the_bytes_the_reference_statements_wrote():
+    """tests/golden/postprocess.npz = the PNG bytes test.py:29-31,35-36 wrote for six predictions (oracle/make_golden_postprocess.py
+    executes those lines); the oracle's restatement, on one thread like the generator, must produce the same bytes"""
+    import os
+    import numpy as np
+    from oracle.make_golden_postprocess import mask_logits
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "postprocess.npz"))
+    kinds = ["field", "constant", "lowcontrast"]
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for i, (seed, h, w, kind) in enumerate(g["cases"].tolist()):
+            out = O.postprocess_mask(torch.from_numpy(mask_logits(seed, kinds[kind])), (h, w))
+            assert out.dtype == np.uint8 and np.array_equal(out, g["u8_%d" % i]), i
+    finally:
+        torch.set_num_threads(nt)
