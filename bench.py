@@ -81,7 +81,7 @@ def _launch_info(lib, name, a):
         # fc1 as a GEMM + 9 taps per hidden element; tokens in, weights once, activated hidden tensor out (the fc1 output
         # itself never leaves the CU, so it is not algorithmic traffic of this kernel)
         return 2.0 * M * N * K + 18.0 * M * N, "mlp_fc1dw_kernel", 2.0 * (M * K + N * K + M * N) + 8.0 * M + 44.0 * N
-    if name == "emip_mlp_band":           # (X, ldx, Wst, taps, b2, ln_stats, eps, Out, ldo, out_stats, B, H, W, C, N, stream)
+    if name == "emip_mlp_band":           # (X, ldx, Wst, taps, b2, ln_stats, eps, Out, ldo, out_stats, B, H, W, C, N, bands, stream)
         Bm, H, W, K, N = a[10], a[11], a[12], a[13], a[14]
         M = Bm * H * W
         # the whole Mlp half: fc1 + 9 taps per hidden element + fc2 (the halo rows a band recomputes are NOT algorithmic work);

@@ -104,7 +104,7 @@ struct MdArgs {
 #endif
 
 constexpr int MD_C = 320, MD_N = 1280, MD_CH = 32, MD_NCH = MD_N / MD_CH, MD_NST = MD_NCH + 2;
-constexpr int MD_HW = 22, MD_TOK = MD_HW * MD_HW, MD_NB = 4, MD_BAND = MD_TOK / MD_NB, MD_HALO = MD_HW + 1, MD_HROWS = MD_BAND + 2 * MD_HALO;
+constexpr int MD_HW = 22, MD_TOK = MD_HW * MD_HW, MD_BAND = MD_TOK / 4, MD_HALO = MD_HW + 1, MD_HROWS = MD_BAND + 2 * MD_HALO;   // sizes of the 4-band form (the 8-band form needs less)
 constexpr int MD_STAGE = 41 * 1024, MD_W2OFF = 20 * 1024, MD_COFF = 40 * 1024;
 constexpr int MD_HB = 64 + MD_HROWS * 64, MD_GB = MD_BAND * 64;                 // H buffer: zero row + 167 rows; G buffer: 121 rows
 constexpr int OFF_DUMP = 160 * 1024 - 64;                                       // 64 bytes nobody reads: where masked-out lanes store
@@ -112,7 +112,7 @@ constexpr int OFF_H = 3 * MD_STAGE, OFF_G = OFF_H + 2 * MD_HB, MD_LDS = 160 * 10
 constexpr int MD_OROW = 2 * MD_C + 16;                                          // bytes of a row of the epilogue's output image
 static_assert(OFF_G + 2 * MD_GB + 7 * 64 <= MD_LDS, "fc2 reads token slots 121..127 of the second G buffer");
 static_assert(MD_BAND * MD_OROW <= 3 * MD_STAGE, "the output image lies in the ring");
-static_assert(MD_BAND * MD_NB == MD_TOK && MD_HROWS <= 6 * 32 && MD_BAND <= 4 * 32, "tile counts");
+static_assert(MD_BAND * 4 == MD_TOK && MD_HROWS <= 6 * 32 && MD_BAND <= 4 * 32 && (MD_TOK + 7) / 8 <= 2 * 32 && (MD_TOK + 7) / 8 + 2 * MD_HALO <= 4 * 32, "tile counts");
 
 // One pipeline iteration of one wave, HAND-SCHEDULED: the three chains of an iteration are independent --
 //   chain A: W1 fragments of the stage -> 20 MFMAs -> output-side LayerNorm + bias -> H (bf16 [row][32 ch], 64-byte rows, 16-byte
@@ -126,7 +126,7 @@ static_assert(MD_BAND * MD_NB == MD_TOK && MD_HROWS <= 6 * 32 && MD_BAND <= 4 * 
 // GELU of one channel pair), the A-operand fragment reads three MFMAs ahead in a rotating register set, and a
 // sched_barrier(0) behind every step, which nothing crosses.  The LDS regions arrive as __restrict__ pointers (through one char
 // array the compiler must assume that H written and H read alias, and orders every load behind every store).
-template <bool FC1, bool F1, bool DW, bool F2, int NACC>
+template <bool FC1, bool F1, bool DW, bool F2, int NACC, bool PRE>
 __device__ __forceinline__ void md_body(const char* __restrict__ st, char* __restrict__ hw, const char* __restrict__ hr,
                                         char* __restrict__ gw, const char* __restrict__ gr, char* __restrict__ dump,
                                         const float* __restrict__ tpn, float (&tap)[80], const u32x4 (&xf)[FC1 ? 20 : 1], f32x16 (&oacc)[NACC],
@@ -228,22 +228,28 @@ __device__ __forceinline__ void md_body(const char* __restrict__ st, char* __res
         for (int g = 0; g < 4; ++g) tail(g);
     // ---- the NEXT iteration's taps + bias (8 channels x 10, wave-uniform: scalar loads), issued behind this iteration's last LDS
     // read: a scalar load in flight turns every LDS wait of the block into lgkmcnt(0) (scalar loads return out of order).
-    // (the last iterations load chunk 0's again: no branch)
+    // (the last iterations load chunk 0's again: no branch; waves without a share of the depthwise pass load nothing)
+    if (PRE)
 #pragma unroll
-    for (int k = 0; k < 10; ++k)
+        for (int k = 0; k < 10; ++k)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) tap[8 * k + j] = tpn[k * MD_CH + j];
+            for (int j = 0; j < 8; ++j) tap[8 * k + j] = tpn[k * MD_CH + j];
 }
 
-// one wave's share of the launch.  FC1: the wave holds a token tile of the band + halo (waves 0..5); DW_FIRST: the wave runs the
-// depthwise pass ahead of its MFMA phases (waves 4..7).  Three instantiations, entered through wave-uniform branches: every wave
+// one wave's share of the launch.  NB: bands per image (4: 121 tokens per workgroup; 8: 60 / 61, for launches that would leave
+// most of the chip idle with four); FC1: the wave holds a 32-row tile of the band + halo; DWA: it has a share of the depthwise
+// pass; NACC: its fc2 accumulator tiles (0: none).  Each instantiation is entered through a wave-uniform branch: every wave
 // executes the same sequence of s_barriers, and each role gets a register allocation of its own.
-template <bool FC1, bool DW_FIRST>
+//   NB = 4: waves 0..5 <FC1, DWA, 4> (fc2: token tile 2 + w / 3, channel tiles 3 (w % 3) .. + 3), waves 6, 7 <-, DWA, 10> (token
+//           tile w - 6, all ten channel tiles);
+//   NB = 8: waves 0..3 <FC1, -, 0> (the four fc1 tiles), waves 4..7 <-, DWA, 5> (the depthwise pass, one token per lane, and fc2:
+//           token tile (w - 4) >> 1, channel tiles 5 ((w - 4) & 1) .. + 4)
+template <int NB, bool FC1, bool DWA, int NACC>
 __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict__ taps, char* smem, int wave, int lane, int img, int band) {
     const int lq = lane & 31, h = lane >> 5;
-    const int t0 = band * MD_BAND;                                   // first own token (inside the image)
-    const int h0 = max(t0 - MD_HALO, 0), h1 = min(t0 + MD_BAND + MD_HALO, MD_TOK);
-    const int nh = h1 - h0;                                          // fc1 rows: 144 (outer bands) or 167
+    const int t0 = MD_TOK * band / NB, nb = MD_TOK * (band + 1) / NB - t0;      // first own token (inside the image), own tokens
+    const int h0 = max(t0 - MD_HALO, 0), h1 = min(t0 + nb + MD_HALO, MD_TOK);
+    const int nh = h1 - h0;                                          // fc1 rows: own + one or two halos
     const long rowbase = (long)img * MD_TOK;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
     const i32x4 rsW = md_rsrc(p.Wst, p.wst_bytes);
@@ -284,13 +290,14 @@ __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict_
         reinterpret_cast<unsigned*>(smem + OFF_H + MD_HB)[lane & 15] = 0u;
     }
 
-    // ---- depthwise pass geometry: wave w = channel group cg = w & 3 (8 channels) x token half w >> 2, one own token per lane
+    // ---- depthwise pass geometry: channel group cg = w & 3 (8 channels), one own token per lane: NB = 4: token half w >> 2 of the
+    // band on every wave; NB = 8: the band's 60 / 61 tokens on each of the waves 4..7
     const int cg = wave & 3;
-    const int q = 64 * (wave >> 2) + lane;                           // own-token index of this lane
-    const bool q_ok = q < MD_BAND;
+    const int q = (NB == 4 ? 64 * (wave >> 2) : 0) + lane;           // own-token index of this lane
+    const bool q_ok = DWA && q < nb;
     unsigned hoff[9];                                                // byte offsets into an H buffer of the nine taps' rows
     {
-        const int pq = t0 + min(q, MD_BAND - 1);                     // token inside the image
+        const int pq = t0 + min(q, nb - 1);                          // token inside the image
         const int py = pq / MD_HW, px = pq - py * MD_HW;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky)
@@ -302,22 +309,21 @@ __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict_
                 hoff[3 * ky + kx] = in ? (unsigned)(64 + r * 64 + ((cg ^ ((r >> 2) & 3)) * 16)) : 0u;
             }
     }
-    const int qs = min(q, MD_BAND - 1);
+    const int qs = min(q, nb - 1);
     const unsigned goff = (unsigned)(qs * 64 + ((cg ^ ((qs >> 2) & 3)) * 16));
 
-    // ---- fc2: waves 6, 7: token tile w - 6, channel tiles 0..9; waves 0..5: token tile 2 + w / 3, channel tiles d0 .. d0 + nd - 1
-    // with (d0, nd) = (0, 3), (3, 3), (6, 4) for w % 3 = 0, 1, 2
-    constexpr int NACC = FC1 ? 4 : 10;
-    const int w3 = FC1 ? wave % 3 : 0;
-    const int tw = FC1 ? 2 + wave / 3 : wave - 6;
-    const int d0 = FC1 ? 3 * w3 : 0;
-    // (waves 0..5 with three own tiles run a fourth -- their neighbour's first -- and drop it: a branch in the loop body would cut
-    // the basic block the scheduler interleaves, and two MFMAs per iteration are cheaper than that)
-    const bool four = !FC1 || w3 == 2;
+    // ---- fc2 geometry (see the table above)
+    constexpr int NA = NACC > 0 ? NACC : 1;
+    const int w3 = (NB == 4 && FC1) ? wave % 3 : 0;
+    const int tw = NB == 4 ? (FC1 ? 2 + wave / 3 : wave - 6) : ((wave - 4) >> 1);
+    const int d0 = NB == 4 ? (FC1 ? 3 * w3 : 0) : 5 * ((wave - 4) & 1);
+    // (NB = 4: waves 0..5 with three own tiles run a fourth -- their neighbour's first -- and drop it: a branch in the loop body
+    // would cut the block the schedule is written for, and two MFMAs per iteration are cheaper than that)
+    const bool four = !(NB == 4 && FC1) || w3 == 2;
     const int n2 = 32 * tw + lq;                                     // own-token index of this lane's fc2 column
-    f32x16 oacc[NACC];
+    f32x16 oacc[NA];
 #pragma unroll
-    for (int d = 0; d < NACC; ++d)
+    for (int d = 0; d < NA; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[d][r] = 0.f;
 
@@ -345,11 +351,11 @@ __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict_
         if (t + 2 < MD_NST) issue(t + 2);
         MD_STAMP(1);
         const int b1_ = t & 1, b0_ = b1_ ^ 1;               // H[t & 1] is written, H[(t - 1) & 1] read; G[(t - 1) & 1] written, G[t & 1] read
-        md_body<FC1, F1, DW, F2, NACC>(
+        md_body<FC1, F1, DW && DWA, F2 && (NACC > 0), NA, DWA>(
             smem + (t % 3) * MD_STAGE, smem + OFF_H + b1_ * MD_HB, smem + OFF_H + b0_ * MD_HB, smem + OFF_G + b0_ * MD_GB,
             smem + OFF_G + b1_ * MD_GB, smem + OFF_DUMP, taps + (long)((MD_SKIP(32) || t >= MD_NCH) ? 0 : t) * (10 * MD_CH) + 8 * cg,
             tap, xf, oacc, hoff,
-            rs, mrs, fr < nh ? 64 + fr * 64 + 8 * h : -1, fr < nh ? (fr >> 2) & 3 : 0, q_ok ? (int)goff : -1, cg, h,
+            rs, mrs, (FC1 && fr < nh) ? 64 + fr * 64 + 8 * h : -1, (FC1 && fr < nh) ? (fr >> 2) & 3 : 0, q_ok ? (int)goff : -1, cg, h,
             n2 * 64, (n2 >> 2) & 3, d0, lane);
         MD_STAMP(2);
     };
@@ -374,14 +380,14 @@ __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    {
-        const bool ok = n2 < MD_BAND;
-        const long tr = rowbase + t0 + min(n2, MD_BAND - 1);
+    if (NACC > 0) {
+        const bool ok = n2 < nb;
+        const long tr = rowbase + t0 + min(n2, nb - 1);
         const bf16_t* xr = p.X + tr * p.ldx;
-        char* ob = smem + min(n2, MD_BAND - 1) * MD_OROW;
+        char* ob = smem + min(n2, nb - 1) * MD_OROW;
 #pragma unroll
         for (int d = 0; d < NACC; ++d) {
-            if (FC1 && d == 3 && !four) break;
+            if (d == 3 && !four) break;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int ch = 32 * (d0 + d) + 8 * g + 4 * h;
@@ -398,6 +404,7 @@ __device__ __forceinline__ void md_run(const MdArgs& p, const float* __restrict_
     }
 }
 
+template <int NB>
 __global__ __launch_bounds__(512) void mlp_band_kernel(const MdArgs p, const float* __restrict__ taps) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -405,28 +412,32 @@ __global__ __launch_bounds__(512) void mlp_band_kernel(const MdArgs p, const flo
     int img, band;
     if (p.xcd_map) {       // the bands of an image on one XCD: they share its token rows in that L2
         const int j = blockIdx.x >> 3;
-        band = j % MD_NB;
-        img = (blockIdx.x & 7) + 8 * (j / MD_NB);
+        band = j % NB;
+        img = (blockIdx.x & 7) + 8 * (j / NB);
     } else {
-        band = blockIdx.x % MD_NB;
-        img = blockIdx.x / MD_NB;
+        band = blockIdx.x % NB;
+        img = blockIdx.x / NB;
     }
-    if (wave < 4) md_run<true, false>(p, taps, smem, wave, lane, img, band);
-    else if (wave < 6) md_run<true, true>(p, taps, smem, wave, lane, img, band);
-    else md_run<false, true>(p, taps, smem, wave, lane, img, band);
+    if (NB == 4) {
+        if (wave < 6) md_run<4, true, true, 4>(p, taps, smem, wave, lane, img, band);
+        else md_run<4, false, true, 10>(p, taps, smem, wave, lane, img, band);
+    } else {
+        if (wave < 4) md_run<8, true, false, 0>(p, taps, smem, wave, lane, img, band);
+        else md_run<8, false, true, 5>(p, taps, smem, wave, lane, img, band);
+    }
 
     // ---- the band's rows out of the LDS image, whole 128-byte segments, and their statistics
     __syncthreads();
-    const int t0 = band * MD_BAND;
+    const int t0 = MD_TOK * band / NB, nb = MD_TOK * (band + 1) / NB - t0;
     const long rowbase = (long)img * MD_TOK;
     // 8 lanes per row: lane j of the group moves the 16-byte chunks j, j + 8, .. j + 32 (128-byte segments per group and step)
     const int grp = tid >> 3, gl = tid & 7;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
+    for (int pass = 0; pass < (NB == 4 ? 2 : 1); ++pass) {
         const int row = grp + 64 * pass;
-        const bool ok = row < MD_BAND;
-        const char* ob = smem + min(row, MD_BAND - 1) * MD_OROW;
-        bf16_t* op = p.Out + (rowbase + t0 + min(row, MD_BAND - 1)) * p.ldo;
+        const bool ok = row < nb;
+        const char* ob = smem + min(row, nb - 1) * MD_OROW;
+        bf16_t* op = p.Out + (rowbase + t0 + min(row, nb - 1)) * p.ldo;
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
@@ -467,10 +478,14 @@ extern "C" int emip_mlp_band_stage_bytes(void) { return MD_NST * MD_STAGE; }
 // be NULL).  X, Out: bf16 [B, 22, 22, 320] with row strides ldx / ldo, Out must not overlap X.  Wst: the 42 pipeline stages of
 // ops.mlp_band_packs (fragment-order W1 with the LayerNorm scale folded in, fragment-order W2, fc1 bias + W1 beta, row sums of the
 // packed W1), taps: f32 [40][10][32] (9 depthwise taps + bias per hidden channel, chunk-major), b2: f32 [320], ln_stats: f32
-// [B 484][2] (sum, sum of squares) of the rows of X.
+// [B 484][2] (sum, sum of squares) of the rows of X.  bands: workgroups per image, 4 or 8 (0: 8 while four would leave CUs
+// idle, else 4; the result does not depend on it: every output element is one accumulator chain over the same 40 chunks).
 extern "C" int emip_mlp_band(const void* X, long ldx, const void* Wst, const float* taps, const float* b2, const float* ln_stats,
-                             float eps, void* Out, long ldo, float* out_stats, int B, int H, int W, int C, int N, void* stream) {
+                             float eps, void* Out, long ldo, float* out_stats, int B, int H, int W, int C, int N, int bands,
+                             void* stream) {
     EMIP_REQUIRE(X && Wst && taps && b2 && ln_stats && Out && emip_mlp_band_eligible(B, H, W, C, N));
+    EMIP_REQUIRE(bands == 0 || bands == 4 || bands == 8);
+    if (bands == 0) bands = B * 4 < 256 ? 8 : 4;
     EMIP_REQUIRE(ldx >= C && (ldx & 7) == 0 && ldo >= C && (ldo & 7) == 0);
     EMIP_REQUIRE(aligned16(X) && aligned16(Wst) && aligned16(taps) && aligned16(b2) && aligned16(Out) &&
                  (reinterpret_cast<uintptr_t>(ln_stats) & 7u) == 0 && (reinterpret_cast<uintptr_t>(out_stats) & 7u) == 0);
@@ -492,9 +507,11 @@ extern "C" int emip_mlp_band(const void* X, long ldx, const void* Wst, const flo
     static bool attr = false;
     if (!attr) {
         attr = true;
-        if (hipFuncSetAttribute((const void*)mlp_band_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, MD_LDS) != hipSuccess)
+        if (hipFuncSetAttribute((const void*)mlp_band_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, MD_LDS) != hipSuccess ||
+            hipFuncSetAttribute((const void*)mlp_band_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, MD_LDS) != hipSuccess)
             return EMIP_E_LAUNCH;
     }
-    hipLaunchKernelGGL(mlp_band_kernel, dim3((unsigned)(B * MD_NB)), dim3(512), MD_LDS, (hipStream_t)stream, a, taps);
+    if (bands == 4) hipLaunchKernelGGL(mlp_band_kernel<4>, dim3((unsigned)(B * 4)), dim3(512), MD_LDS, (hipStream_t)stream, a, taps);
+    else hipLaunchKernelGGL(mlp_band_kernel<8>, dim3((unsigned)(B * 8)), dim3(512), MD_LDS, (hipStream_t)stream, a, taps);
     return emip_launch_status();
 }

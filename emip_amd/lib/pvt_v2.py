@@ -44,9 +44,13 @@ SR_WIDE_TILE = True         # the spatial-reduction conv of the 22 x 22 stage on
 FC1DW_BAND_MIN_ROWS = 3     # banded fc1 + depthwise launch for maps of > 512 tokens when a band has at least this many output rows (0: off;
                             # in-call at 16 pairs: off 1592, the 44 x 44 stage only 1618, the 88 x 88 stage too 1628 pairs/s)
 MLP_BLOCK = False
-# the Mlp half of a 22 x 22-stage block as ONE launch of quarter-image workgroups (emip_mlp_band, round 4): fc1, depthwise + GELU
-# and fc2 as a three-stage software pipeline over 32-channel chunks, one barrier per chunk, the hidden tensor on the CU only
-MLP_BAND = True
+# the Mlp half of a 22 x 22-stage block as ONE launch of quarter- or eighth-image workgroups (emip_mlp_band, round 4): fc1,
+# depthwise + GELU and fc2 as a three-stage software pipeline over 32-channel chunks, one barrier per chunk, the hidden tensor on
+# the CU only; bit-identical to emip_mlp_fc1dw + the fc2 GEMM (tests/test_mlp_band_gpu.py).  OFF by measurement (MI355X, 16 pairs,
+# tools/flag_ab.py, pairs/s with 4 steps in flight | ms one step at a time): two launches 2371 | 12.19; 4 bands 2348-2377 | 14.07;
+# 8 bands 2296 | 13.00.  Inside a step a launch takes 99 us (4 bands) / 76 us (8 bands; 56 us with its weights already in L2)
+# against 41 + 21 us: 80 launches per step fewer, no gain in either figure
+MLP_BAND = False
 # the spatial-reduction convs with few output tiles and a long K walk (stages 1-2: 61 tiles x 64 / 32 K tiles at 32 images)
 # with K split inside the launch (emip_conv2d_ksplit, the normalising loader) instead of the per-tap ring body.  OFF: shorter
 # alone, but with three steps in flight 1554 against 1587 pairs/s (tools/flag_ab.py) -- the third time a split-K form loses

@@ -117,8 +117,6 @@ def _window_attention(q, k, v, B2, h, w, C, ldq, ldk, ldv, shift, splits, kv_rot
 
 WATTN_QPROJ = True      # ... and the q projection in its prologue (the fused input GEMM then makes k | v | k' | v' only)
 WATTN_MERGE = True      # emip_window_attention_merge: attention + merge + norm1 (+ residual) in one launch (bf16 inference)
-DEBUG_TAPS = None       # tools/dbg_inflight.py: a list that receives (name, clone) of the token tensor behind every launch group
-FFN_OUT_OF_PLACE = False
 FFN_BLOCK = True        # emip_ffn_block: mlp[0] + GELU + mlp[2] + norm2 + residual in one launch (bf16 inference)
 
 
@@ -179,31 +177,17 @@ class FeatureTransformer(EmipModule):
                 big = ops.gemm(c0, blk.fused_in4())                              # [2B, n, 4C]
                 rows_t, gid_t = window_tables(h, w, attn_num_splits, shift, c0.device)
                 gm = gid_t if shift else None
-                if DEBUG_TAPS is not None:
-                    DEBUG_TAPS.append(("big%d" % len(DEBUG_TAPS), big.clone()))
                 ops.window_attention_merge(c0, big[..., :C], big[..., C:2 * C], c0, rows_t, gm, n, C ** -0.5, ws["mfrag"],
                                            ws["n1"][0], ws["n1"][1], blk.self_attn.norm1.eps, res=c0, wq_pack=ws["qfrag"])
-                if DEBUG_TAPS is not None:
-                    DEBUG_TAPS.append(("self%d" % len(DEBUG_TAPS), c0.clone()))
                 msg = torch.empty((B2, n, C), dtype=dt, device=c0.device)
                 ops.window_attention_merge(c0, big[..., 2 * C:3 * C], big[..., 3 * C:], msg, rows_t, gm, n, C ** -0.5, wc["mfrag"],
                                            wc["n1"][0], wc["n1"][1], blk.cross_attn_ffn.norm1.eps, kv_rot=B, wq_pack=wc["qfrag"])
-                if DEBUG_TAPS is not None:
-                    DEBUG_TAPS.append(("cross%d" % len(DEBUG_TAPS), msg.clone()))
                 if FFN_BLOCK and wc.get("ffn") is not None:
-                    if FFN_OUT_OF_PLACE:
-                        alt = torch.empty_like(c0)
-                        ops.ffn_block(c0, msg, wc["ffn"][0], wc["ffn"][1], wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps,
-                                      res=c0, out=alt)
-                        c0 = alt
-                    else:
-                        ops.ffn_block(c0, msg, wc["ffn"][0], wc["ffn"][1], wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps,
-                                      res=c0, out=c0)
+                    ops.ffn_block(c0, msg, wc["ffn"][0], wc["ffn"][1], wc["n2"][0], wc["n2"][1], blk.cross_attn_ffn.norm2.eps,
+                                  res=c0, out=c0)
                 else:
                     ops.gemm_ln_out(ops.gemm(c0, wc["m0"], a2=msg, act=ops.ACT_GELU), wc["m2"], wc["n2"][0], wc["n2"][1],
                                     blk.cross_attn_ffn.norm2.eps, res=c0, out=c0)
-                if DEBUG_TAPS is not None:
-                    DEBUG_TAPS.append(("ffn%d" % len(DEBUG_TAPS), c0.clone()))
                 continue
             big = ops.gemm(c0, blk.fused_in())                                   # [2B, n, 5C]
             ck, cv, ldc5, rot = big[..., 3 * C:], big[..., 4 * C:], 5 * C, B

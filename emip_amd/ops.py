@@ -886,9 +886,12 @@ def mlp_band_packs(w1, b1, colsum, w2, wd, bd):
     return st, taps
 
 
-def mlp_band(x, stages, taps, b2, ln_stats, eps, out, out_stats=None):
-    """out = x + fc2(GELU(dwconv3x3(LN(x) w1^T + b1) + bd)) + b2, one launch, a quarter image per workgroup (bf16, 22 x 22
-    tokens, C = 320, N = 1280); out must not alias x"""
+MLP_BAND_BANDS = 0      # workgroups per image of emip_mlp_band: 4, 8, or 0 = by batch (the output bits do not depend on it)
+
+
+def mlp_band(x, stages, taps, b2, ln_stats, eps, out, out_stats=None, bands=None):
+    """out = x + fc2(GELU(dwconv3x3(LN(x) w1^T + b1) + bd)) + b2, one launch, a quarter or an eighth of an image per workgroup
+    (bf16, 22 x 22 tokens, C = 320, N = 1280); out must not alias x"""
     B, H, W, C = x.shape
     M, _, ldx = rows(x)
     _, _, ldo = rows(out)
@@ -896,7 +899,7 @@ def mlp_band(x, stages, taps, b2, ln_stats, eps, out, out_stats=None):
     assert taps.shape == (40, 10, 32) and taps.is_contiguous() and taps.dtype == torch.float32
     assert out.shape == x.shape and out.data_ptr() != x.data_ptr()
     _lib.call("emip_mlp_band", _p(x), ldx, _p(stages), _p(taps), _p(b2), _p(ln_stats), float(eps), _p(out), ldo,
-              _p(out_stats), B, H, W, C, 1280, _stream())
+              _p(out_stats), B, H, W, C, 1280, MLP_BAND_BANDS if bands is None else bands, _stream())
     return out
 
 

@@ -733,11 +733,12 @@ int emip_shard_sum(const void* in, void* out, int world, long chunk, int is_bf16
  * pipeline stages [W1 chunk t in MFMA-fragment order, LayerNorm scale folded in | W2 chunk t - 2 in fragment order | fc1 bias
  * (+ W1 beta) and row sums of the packed W1 of chunk t, f32] (emip_amd/ops.py: mlp_band_packs); taps: f32 [40][10][32], the 9
  * depthwise taps and the depthwise bias per hidden channel, chunk-major; b2: f32 [320]; ln_stats: f32 [B 484][2] (sum, sum of
- * squares) of the rows of X. */
+ * squares) of the rows of X.  bands: workgroups per image, 4 (121 tokens each) or 8 (60 / 61 tokens: half the launch duration
+ * while 4 B workgroups would leave CUs idle), 0 = chosen by B; the result does not depend on it. */
 int emip_mlp_band_eligible(int B, int H, int W, int C, int N);
 int emip_mlp_band_stage_bytes(void);
 int emip_mlp_band(const void* X, long ldx, const void* Wst, const float* taps, const float* b2, const float* ln_stats,
-                  float eps, void* Out, long ldo, float* out_stats, int B, int H, int W, int C, int N, void* stream);
+                  float eps, void* Out, long ldo, float* out_stats, int B, int H, int W, int C, int N, int bands, void* stream);
 
 /* ---- calibration switches: libemip_hip_tuning.so ONLY (make -C emip_amd/csrc tuning, -DEMIP_TUNING) ----------------------
  * Tile / ring-depth overrides and work-skipping ablations (no stores / no MFMA / no loads) for tools/.  The product

@@ -9,8 +9,9 @@ from test_mlp_block_gpu import _reference, _setup
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("bands", [4, 8])
 @pytest.mark.parametrize("B", [8, 3, 1, 16])
-def test_against_pytorch_and_the_two_launch_path(B):
+def test_against_pytorch_and_the_two_launch_path(B, bands):
     from emip_amd import ops
     H = W = 22
     assert ops.mlp_band_eligible(B, H, W, 320, 1280) and not ops.mlp_band_eligible(B, 22, 14, 320, 1280)
@@ -21,11 +22,15 @@ def test_against_pytorch_and_the_two_launch_path(B):
     for _ in range(2):
         out = torch.full_like(x, 7.0)
         ost = torch.full((B * H * W, 2), -1.0, device="cuda")
-        ops.mlp_band(x, stg, taps, b2, stats.view(-1), eps, out, out_stats=ost)
+        ops.mlp_band(x, stg, taps, b2, stats.view(-1), eps, out, out_stats=ost, bands=bands)
         outs.append((out, ost))
+    other = torch.empty_like(x)
+    ost_o = torch.empty_like(ost)
+    ops.mlp_band(x, stg, taps, b2, stats.view(-1), eps, other, out_stats=ost_o, bands=12 - bands)
     torch.cuda.synchronize()
     (out, ost), (out_b, ost_b) = outs
     assert torch.equal(out, out_b) and torch.equal(ost, ost_b)          # fixed-order reductions only: reproducible bit for bit
+    assert torch.equal(out, other) and torch.equal(ost, ost_o)          # ... and the same bits from quarter- and eighth-image workgroups
     ref = _reference(x, w1, w2, b1, b2, bd, wd, eps)
     top = ref.abs().max().item()
     d = (out.float() - ref).abs()
@@ -43,7 +48,8 @@ def test_against_pytorch_and_the_two_launch_path(B):
     assert err < 1.5e-2 * top, (err, top)                 # bf16 output rounding (2^-8 relative) + the polynomial GELU
 
 
-def test_strided_rows_and_missing_statistics_output():
+@pytest.mark.parametrize("bands", [4, 8])
+def test_strided_rows_and_missing_statistics_output(bands):
     """token rows embedded in a wider buffer (row stride > 320) on both sides; out_stats NULL"""
     from emip_amd import ops
     B, H, W = 2, 22, 22
@@ -54,9 +60,9 @@ def test_strided_rows_and_missing_statistics_output():
     xs = wide[..., 32:352]
     owide = torch.full((B, H, W, 336), 3.0, dtype=torch.bfloat16, device="cuda")
     os_ = owide[..., 8:328]
-    ops.mlp_band(xs, stg, taps, b2, stats.view(-1), 1e-6, os_, out_stats=None)
+    ops.mlp_band(xs, stg, taps, b2, stats.view(-1), 1e-6, os_, out_stats=None, bands=bands)
     out = torch.empty_like(x)
-    ops.mlp_band(x, stg, taps, b2, stats.view(-1), 1e-6, out, out_stats=None)
+    ops.mlp_band(x, stg, taps, b2, stats.view(-1), 1e-6, out, out_stats=None, bands=bands)
     torch.cuda.synchronize()
     assert torch.equal(os_, out)
     assert (owide[..., :8] == 3.0).all() and (owide[..., 328:] == 3.0).all()      # nothing written outside the 320 channels

@@ -87,11 +87,14 @@ def test_bf16_mode_stage_bounds(model_args, short_sd, golden):
         with torch.no_grad():
             mask, fw, bw = net(im1.cuda(), im2.cuda())
         L = net.last
-        assert _rel(_planar(L["fea"][1][:1]), g["pvt1_s3"]) < 0.08
-        assert _rel(_planar(L["gm"][:1])[:, :, ::2, ::2], g["gm1"]) < 0.05
-        assert _rel(_planar(L["inj1"])[:, :, ::2, ::2], g["inj1"]) < 0.08
+        # round 4: the bf16 forward is reproducible bit for bit (tests/test_determinism_gpu.py), so these are bounds on the bf16
+        # error itself against the f32 reference -- 1.5 x the measured values (profiles/r04_bf16_stage_errors.json: 0.035, 0.017,
+        # 0.016, 0.030), no run-to-run band on top
+        e = (_rel(_planar(L["fea"][1][:1]), g["pvt1_s3"]), _rel(_planar(L["gm"][:1])[:, :, ::2, ::2], g["gm1"]),
+             _rel(_planar(L["inj1"])[:, :, ::2, ::2], g["inj1"]), _rel(mask, torch.from_numpy(g["mask"])))
+        print("  bf16 vs the f32 reference: pvt stage 3 %.4f, gmflow cnn %.4f, injector1 %.4f, mask %.4f" % e)
+        assert e[0] < 0.052 and e[1] < 0.026 and e[2] < 0.024 and e[3] < 0.045, e
         ref = torch.from_numpy(g["mask"])
-        assert _rel(mask, ref) < 0.08
         a, b = mask.cpu() >= 0, ref >= 0
         assert (a & b).sum().item() / max((a | b).sum().item(), 1) > 0.97
     finally:
@@ -232,6 +235,7 @@ def test_bf16_inference_beyond_the_single_launch_batch(model_args, short_sd):
             again = torch.cat([net(im1[:12], im2[:12])[0], net(im1[12:], im2[12:])[0]], 0).float()
         d, jit = (whole - halves).abs().max().item(), (again - halves).abs().max().item()
         print(f"  24 pairs at once vs 2 x 12: max |dlogit| {d:.4f} (two runs of the halves: {jit:.4f})")
-        assert torch.isfinite(whole).all() and d <= 2.0 * jit + 0.1
+        # round 4: no run-to-run band any more (fixed-order reductions); the batch size still selects tiles, hence summation orders
+        assert torch.isfinite(whole).all() and jit == 0.0 and d <= 0.1
     finally:
         nn_base.set_default_dtype(torch.float32)

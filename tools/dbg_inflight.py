@@ -34,19 +34,16 @@ def flat(d, prefix=""):
         if torch.is_tensor(v): out[f"{prefix}{k}"] = v
         elif isinstance(v, (dict, list, tuple)): out.update(flat(v, f"{prefix}{k}."))
     return out
-from emip_amd.model.EMIP_short.motion.gmflow import transformer as TR
-TAPS = os.environ.get("EMIP_TAPS") == "1"
-if TAPS:
-    TR.DEBUG_TAPS = []
+TAPS = False      # (the per-launch-group taps that located the ffn_block fault lived in transformer.py for that hunt only)
 with torch.no_grad():
     ref = [t.clone() for t in (lambda o: (o[0], o[1][0], o[2][0]))(net(im1, im2))]
-    ref_taps = list(TR.DEBUG_TAPS) if TAPS else []
+    ref_taps = []
     ref_last = {k: v.clone() for k, v in flat(net.last).items()}
     ref_gm = {k: v.clone() for k, v in flat(net.GMFlow.last).items()} if hasattr(net.GMFlow, "last") else {}
 r = PipelinedShort(net, 16, inflight=inflight); r.load(im1, im2)
 ntap = len(ref_taps)
 # every part ran two warm-up forwards and the captured one: its taps are the last ntap of its 3 ntap entries
-part_taps = [TR.DEBUG_TAPS[ntap + (3 * i + 2) * ntap: ntap + (3 * i + 3) * ntap] for i in range(inflight)] if TAPS else []
+part_taps = []
 torch.cuda.synchronize()
 bad = 0
 for rnd in range(rounds):

@@ -9,6 +9,14 @@ from emip_amd import nn_base
 from emip_amd.filler import state_dict_from_manifest, synthetic_pair
 from emip_amd.graph import PipelinedShort
 from emip_amd.model.EMIP_short.model import CoUpdater
+import importlib
+for kv in os.environ.get("EMIP_DBG", "").split(","):      # e.g. EMIP_DBG="emip_amd.lib.pvt_v2:MLP_BAND=False,emip_amd.ops:MLP_BAND_BANDS=8"
+    if "=" in kv:
+        k, v = kv.split("=")
+        mn, k = k.split(":")
+        mod = importlib.import_module(mn)
+        assert hasattr(mod, k), (mn, k)
+        setattr(mod, k, eval(v))
 inflight = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 g = os.path.join(ROOT, "tests", "golden")
 margs = json.load(open(os.path.join(g, "model_args.json")))
