@@ -76,7 +76,39 @@ def measure(inflight, steps):
     return sorted(out)[1]
 
 
+from emip_amd import ops as OPS
+_real = {n: getattr(OPS, n) for n in ("mlp_fc1dw", "gemm", "sra_block", "conv8")}
+S3 = {
+    # launches of the 22 x 22 stage's blocks (C = 320) replaced by nothing (outputs: uninitialised or unchanged tensors)
+    "s3 fc1 + depthwise (emip_mlp_fc1dw)": ("mlp_fc1dw", lambda f: (lambda x, w1, *a, **k: torch.empty(x.shape[:3] + (w1.shape[0],), dtype=x.dtype, device=x.device)
+                                                              if x.shape[1] == 22 and x.shape[-1] == 320 else f(x, w1, *a, **k))),
+    "s3 fc2 GEMM + its row statistics": ("gemm", lambda f: (lambda a, w, *r, **k: k["out"] if (a.shape[-1] == 1280 and w.shape[0] == 320 and k.get("out") is not None)
+                                                          else f(a, w, *r, **k))),
+    "s3 kv GEMM": ("gemm", lambda f: (lambda a, w, *r, **k: torch.empty(a.shape[:-1] + (640,), dtype=a.dtype, device=a.device)
+                                      if (a.shape[-1] == 320 and w.shape[0] == 640) else f(a, w, *r, **k))),
+    "s3 q + attention + proj (emip_sra_block)": ("sra_block", lambda f: (lambda x, *a, **k: None if x.shape[-1] == 320 else f(x, *a, **k))),
+    "s3 spatial-reduction conv": ("conv8", lambda f: (lambda x, w, kh, kw, stride=1, pad=0, **k:
+                                                      torch.empty((x.shape[0], x.shape[1] // stride, x.shape[2] // stride, w.shape[0]), dtype=x.dtype, device=x.device)
+                                                      if k.get("cfg") == 10 else f(x, w, kh, kw, stride, pad, **k))),
+}
+_set_part = set_part
+
+
+def set_part(key, on):
+    if key in S3:
+        name, mk = S3[key]
+        setattr(OPS, name, mk(_real[name]) if on else _real[name])
+        return
+    _set_part(key, on)
+
+
+if "--s3" in sys.argv:
+    keys_override = ["(nothing)"] + list(S3)
+else:
+    keys_override = None
 keys = ["(nothing)"] + (list(parts) if "--all" in sys.argv else []) + ["pvt stage %d blocks" % i for i in (1, 2, 3, 4)]
+if keys_override:
+    keys = keys_override
 base = None
 for k in keys:
     if k != "(nothing)":
