@@ -118,6 +118,8 @@ def _launch_info(lib, name, a):
         if a[4]:                                            # raw scores (the correlation volume) written out
             byt += 2.0 * z * Lq * Lk
         return 2.0 * z * Lq * Lk * (D + dv), "attn_kernel<bf16,%d,%d,64>%s" % (D, DV, "+scores" if a[4] else ""), byt
+    if name == "emip_gemm_ln_ws":         # emip_gemm_ln's arguments + (stats_ws, stats_ws_bytes) in front of the stream
+        name, a = "emip_gemm_ln", tuple(a[:-3]) + (a[-1],)
     if name in ("emip_gemm", "emip_gemm_ln", "emip_gemm_lne"):
         if name == "emip_gemm_lne":      # (A, W, C, bias, R, M, N, K, lda, ldw, ...)
             M, N, K, lda, ldw, K1, batch, a2, res, ln = a[5], a[6], a[7], a[8], a[9], a[7], 1, None, a[4], None

@@ -492,23 +492,16 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& p, const int bx, const
         if (!p.ticket) return;
         // Order this workgroup's accumulator adds before its ticket: no-return atomics are only known to have landed
         // once the issuing wave has waited for vmcnt(0) -- a workgroup barrier alone emits no such wait on gfx950 -- so
-        // every wave drains, the workgroup meets, and one lane publishes with an agent-scope release in front of the
-        // ticket increment (the explicit wait after the fence stays: hipcc can drop the fence's own).
+        // every wave drains, the workgroup meets, and one lane draws the ticket.  Every access to the accumulator and the
+        // ticket, here and in the read-back below, is a device-scope atomic performed at the memory side: no fence is needed,
+        // and an agent-scope fence is NOT free on this part -- release writes back, acquire invalidates the XCD's whole L2
+        // (round 4: the same pair of fences in gemm8's statistics combine took the step from 2230 to 1310 pairs/s).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(smem);
-        if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            *flag = __hip_atomic_fetch_add(p.ticket + swz, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        if (tid == 0) *flag = __hip_atomic_fetch_add(p.ticket + swz, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         if (*flag != (unsigned)p.ksplit - 1u) return;
-        if (tid == 0) {        // last arrival: acquire before the read-back (the exchanges below are memory-side atomics)
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();
         if (tid == 0) atomicExch(p.ticket + swz, 0u);
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
@@ -886,6 +879,30 @@ extern "C" int emip_gemm_ln(const void* A, const void* A2, const void* W, void* 
         return rc != EMIP_OK ? rc : emip_internal::row_stats(C, ldc, out_stats, M, N, stream);
     }
     return dtype == EMIP_F32 ? dispatch<float, false>(a, batch, s) : dispatch<bf16_t, false>(a, batch, s);
+}
+
+namespace emip_internal {
+extern thread_local void* t_stats_ws;
+extern thread_local long t_stats_ws_bytes;
+}  // namespace emip_internal
+
+// emip_gemm_ln with a caller-owned workspace (emip_gemm_stats_ws_bytes(M, N) bytes, its ticket block zero before the first
+// use) through which a bf16 launch whose rows span more than two column tiles combines its row statistics in a fixed order
+// INSIDE the launch (the last column tile of a row tile to finish adds the partials) instead of a row_stats pass behind it.
+// Launches that do not need it ignore it.
+extern "C" int emip_gemm_ln_ws(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R,
+                               int M, int N, int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act,
+                               int batch, long bsA, long bsW, long bsC, long bsR, const float* ln_stats, int ln_C,
+                               float ln_eps, float* out_stats, void* zero_ptr, long zero_bytes, int dtype, void* stats_ws,
+                               long stats_ws_bytes, void* stream) {
+    EMIP_REQUIRE(!stats_ws || (stats_ws_bytes > 0 && (reinterpret_cast<uintptr_t>(stats_ws) & 63u) == 0));
+    emip_internal::t_stats_ws = stats_ws;
+    emip_internal::t_stats_ws_bytes = stats_ws ? stats_ws_bytes : 0;
+    const int rc = emip_gemm_ln(A, A2, W, C, bias, R, M, N, K, K1, lda, lda2, ldw, ldc, ldr, act, batch, bsA, bsW, bsC, bsR,
+                                ln_stats, ln_C, ln_eps, out_stats, zero_ptr, zero_bytes, dtype, stream);
+    emip_internal::t_stats_ws = nullptr;
+    emip_internal::t_stats_ws_bytes = 0;
+    return rc;
 }
 
 extern "C" int emip_conv2d(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H,

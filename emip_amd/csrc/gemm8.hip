@@ -60,6 +60,9 @@ struct G8Args {
     int stats_lds;             // > 0: byte offset of [BM][WGN][2] f32 in LDS through which the WGN waves of a tile row combine
                                // their partial sums in FIXED order (one writer per row and column tile); 0: one atomic pair per
                                // wave and row -- order-independent only while a row receives at most two contributions
+    float* stats_part;         // with stats_cnt: [tiles_m][tiles_n][BM][2] f32 row partials of the column tiles and
+    unsigned* stats_cnt;       // [tiles_m] tickets (zero at launch, zero again at exit): the LAST column tile of a row tile to
+                               // arrive adds the partials in column order and stores out_stats (rows of more than two tiles)
     const float* rowscale;     // [M / rs_rows] or null: act(...) of row m is multiplied by rowscale[m / rs_rows] BEFORE the
     int rs_rows;               // residual is added (stochastic depth: residual + scale[sample] * branch)
     const float* lno_gamma;    // LNO instances: C = R + LayerNorm_over_N(A W^T + bias) * gamma + beta, one output tile per row
@@ -553,7 +556,55 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                     atomicAdd(p.out_stats + 2 * (long)m + 1, s2);
                 }
             }
-            if (p.stats_lds) {
+            if (p.stats_lds && p.stats_cnt) {
+                // rows of more than two column tiles: no atomics on the sums (three addends do not commute).  Every column
+                // tile leaves its row partials in memory and draws a ticket; the tile that draws the last one adds the
+                // partials in column order.  No waiting on other workgroups anywhere: whoever comes last does the work.
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                const int tm = t / p.tiles_n;
+                if (wn == 0 && fq == 0) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) {
+                        const int r = wm * WTM + 16 * a + fr;
+                        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                        for (int w = 0; w < WGN; ++w) {
+                            const float2 v = *reinterpret_cast<const float2*>(red + (r * WGN + w) * 2);
+                            t1 += v.x;
+                            t2 += v.y;
+                        }
+                        // device-scope relaxed atomics, NOT plain stores behind a __threadfence(): on this multi-XCD part an
+                        // agent-scope fence writes back and invalidates the whole L2 of the XCD (measured: the step went from
+                        // 2230 to 1310 pairs/s with four steps in flight); a device-scope access goes past the L2 by itself
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.stats_part + ((long)t * BM + r) * 2),
+                                           ((unsigned long long)__float_as_uint(t2) << 32) | __float_as_uint(t1), __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the partials have been performed ...
+                __syncthreads();                                   // ... for every row of the tile, and red is free
+                unsigned* tick = reinterpret_cast<unsigned*>(red);
+                if (tid == 0) *tick = atomicAdd(p.stats_cnt + tm, 1u);
+                __syncthreads();
+                if (*tick == (unsigned)(p.tiles_n - 1)) {
+                    if (tid < BM && m0 + tid < p.M) {
+                        float t1 = 0.f, t2 = 0.f;
+                        for (int c = 0; c < p.tiles_n; ++c) {
+                            const unsigned long long v = __hip_atomic_load(
+                                reinterpret_cast<const unsigned long long*>(p.stats_part + (((long)tm * p.tiles_n + c) * BM + tid) * 2),
+                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            t1 += __uint_as_float((unsigned)v);
+                            t2 += __uint_as_float((unsigned)(v >> 32));
+                        }
+                        *reinterpret_cast<float2*>(p.out_stats + 2 * (long)(m0 + tid)) = make_float2(t1, t2);
+                    }
+                    // the next launch finds the ticket at zero again
+                    if (tid == 0) __hip_atomic_store(p.stats_cnt + tm, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            } else if (p.stats_lds) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
@@ -618,6 +669,14 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const bf16_t* __restrict
     }
     if (gl == 0 && row < M) *reinterpret_cast<float2*>(out + 2 * (long)row) = make_float2(s1, s2);
 }
+
+}  // namespace
+namespace emip_internal {
+// set by emip_gemm_ln_ws (gemm.hip) around ITS launch: a caller-owned workspace for the in-launch combine of row statistics
+thread_local void* t_stats_ws = nullptr;
+thread_local long t_stats_ws_bytes = 0;
+}  // namespace emip_internal
+namespace {
 
 struct Cfg {
     int bm, bn, nst, nst_lnt;
@@ -701,7 +760,19 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     float* late_stats = nullptr;
     if (a.out_stats) {
         const int wgn = (g.bm == 256 && g.bn <= 128) || (g.bm == 128 && g.bn == 64) ? 2 : 4;       // configurations 1, 6, 8: 4 x 2 waves
-        if (a.tiles_n > 2) {
+        // workspace for the in-launch combine: tickets (64-byte aligned block) then the partials
+        // (the ticket block has ONE size per M, whatever the tile: launches with different tiles may share a workspace)
+        const size_t cnt_bytes = ((size_t)((a.M + 63) / 64) * 4 + 63) & ~(size_t)63;
+        const size_t ws_need = cnt_bytes + (size_t)a.tiles_m * a.tiles_n * g.bm * 8;
+        void* ws = emip_internal::t_stats_ws;
+        const bool ws_ok = ws && (size_t)emip_internal::t_stats_ws_bytes >= ws_need && !lno &&
+                           lds + (size_t)g.bm * wgn * 8 <= 160 * 1024;
+        if (a.tiles_n > 2 && ws_ok) {
+            a.stats_cnt = (unsigned*)ws;
+            a.stats_part = (float*)((char*)ws + cnt_bytes);
+            a.stats_lds = (int)lds;
+            lds += (size_t)g.bm * wgn * 8;
+        } else if (a.tiles_n > 2) {
             late_stats = a.out_stats;
             a.out_stats = nullptr;
         } else if (wgn * a.tiles_n > 2) {
@@ -743,6 +814,12 @@ int row_stats(const void* C, long ldc, float* out_stats, int M, int N, void* str
 }  // namespace emip_internal
 
 extern "C" int emip_gemm8_auto_cfg(int M, int N, int K) { return pick_cfg(M, N, K); }
+// bytes of the workspace emip_gemm_ln_ws wants for an M x N output, whatever tile it picks (tickets + row partials of every
+// column tile); the first 4 * ceil(M / 64) bytes must be ZERO at the first launch (launches leave them zero)
+extern "C" long emip_gemm_stats_ws_bytes(int M, int N) {
+    const long tm = (M + 63) / 64, tn = (N + 63) / 64;
+    return ((tm * 4 + 63) & ~63L) + ((long)M + 256) * tn * 8;
+}
 #ifdef EMIP_TUNING
 extern "C" int emip_tuning_gemm8_dbg(int v) { g8_dbg = v; return 0; }
 #endif

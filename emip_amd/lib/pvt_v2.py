@@ -30,7 +30,7 @@ FUSED_LN = True
 # GEMM) and takes it from SRA_BLOCK_WIDE_ROWS token rows on: at the 32 images of a whole 16-pair step it is
 # ahead (1587 against 1580 pairs/s in-process, tools/flag_ab.py) and 40 launches fewer
 SRA_BLOCK_MAXC = 128
-SRA_BLOCK_WIDE_ROWS = 0        # round 4: always (12 000 before: 2334 / 2328 pairs/s either way at 16 images, and this form owns its rows: reproducible statistics without a second pass)
+SRA_BLOCK_WIDE_ROWS = 12000    # round 4: with the proj GEMM's row statistics combined inside its launch (STATS_IN_LAUNCH) the two-launch form is reproducible too: at 16 images 11.88 against 12.54 ms one step at a time, 2243 pairs/s either way in flight
 # q projection inside the attention launch (emip_sra_block / emip_sra_qattn).  False = q GEMM + emip_sra_attention, the form
 # stage 4 (sr_ratio 1) always takes; tests/test_sra_block_gpu.py runs a block both ways and compares
 SRA_FUSED = True
@@ -40,6 +40,9 @@ SRA_FUSED = True
 # other on 10 waves per CU (phase ablation: depthwise + GELU 43 us, fc2 26, fc1 18, H stores 8, 60 barriers + prologue 24) --
 # and with three steps in flight the throughput follows the SUM of the kernels' isolated times, not the CUs a launch leaves
 # free: 1401 against 1536 pairs/s (tools/flag_ab.py).  What it would take: DESIGN.md section 7d.
+# row statistics of the proj / fc2 GEMMs whose rows span more than two column tiles (N = 320 on 128-wide tiles) combined inside
+# the launch by the last column tile to finish (emip_gemm_ln_ws) instead of a row_stats launch behind it
+STATS_IN_LAUNCH = True
 SR_WIDE_TILE = True         # the spatial-reduction conv of the 22 x 22 stage on ONE 64 x 320 tile per 64 rows (gemm8 configuration 10)
 FC1DW_BAND_MIN_ROWS = 3     # banded fc1 + depthwise launch for maps of > 512 tokens when a band has at least this many output rows (0: off;
                             # in-call at 16 pairs: off 1592, the 44 x 44 stage only 1618, the 88 x 88 stage too 1628 pairs/s)
@@ -253,10 +256,12 @@ class Block(EmipModule):
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
         return 2 * (Ms + 2 * M)
 
-    def run_fused(self, x, stats, buf, alt=None):
+    def run_fused(self, x, stats, buf, alt=None, ws=None):
         """Inference block without LayerNorm launches.  x [B,H,W,C] (updated in place), stats f32 [B*H*W, 2] = (sum, sum of
         squares) of its rows, buf: this block's slice of the stage's ZEROED scratch, alt: a second token buffer of x's shape
-        (the one-launch Mlp half writes out of place) -> (new x, stats of its rows, the token buffer that is free now)."""
+        (the one-launch Mlp half writes out of place), ws: the stage's workspace for row statistics combined inside a GEMM
+        launch (ops.gemm stats_ws; its ticket block lies in the zeroed scratch) -> (new x, stats of its rows, the token buffer
+        that is free now)."""
         a = self.attn
         dt, C, heads, sr = self.cdtype, a.dim, a.num_heads, a.sr_ratio
         B, H, W, _ = x.shape
@@ -316,7 +321,7 @@ class Block(EmipModule):
                     ops.attention(q, kv, kv[..., C:], att, batch=B, heads=heads, nwin=1, Lq=N, Lk=Lk, D=64, DV=64, q_bs=N * C,
                                   k_bs=Lk * 2 * C, v_bs=Lk * 2 * C, o_bs=N * C, ldq=C, ldk=2 * C, ldv=2 * C, ldo=C, q_hs=64,
                                   k_hs=64, v_hs=64, o_hs=64, scale=a.scale)
-            ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1)
+            ops.gemm(att, w["p"], bias=w["bp"], res=x, out=x, out_stats=st1, stats_ws=ws if STATS_IN_LAUNCH else None)
         # ---- Mlp half: x += fc2(GELU(dwconv(fc1(LN(x)))))
         hid = w["w1"].shape[0]
         if MLP_BAND and alt is not None and "mband" in w and ops.mlp_band_eligible(B, H, W, C, hid):
@@ -333,7 +338,7 @@ class Block(EmipModule):
         else:
             t = ops.gemm(x, w["w1"], bias=w["b1"], ln_stats=st1, ln_eps=self.norm2.eps, colsum=cs("w1"))
             t = ops.dwconv3x3(t, w["wd"], w["bd"], act=ops.ACT_GELU)
-        ops.gemm(t, w["w2"], bias=w["b2"], res=x, out=x, out_stats=st2)
+        ops.gemm(t, w["w2"], bias=w["b2"], res=x, out=x, out_stats=st2, stats_ws=ws if STATS_IN_LAUNCH else None)
         return x, st2, alt
 
     def run(self, x):
@@ -455,11 +460,15 @@ class PyramidVisionTransformerV2(EmipModule):
                 # statistics scratch of the whole stage: one allocation, cleared by the patch-embed conv's workgroups
                 a0 = blocks[0].attn
                 per = Block.scratch_floats(x.shape[0], Ho, Wo, a0.dim, a0.sr_ratio)
-                scratch = torch.empty(len(blocks) * per, dtype=torch.float32, device=x.device)
+                # + the stage's workspace for row statistics combined inside a launch (tickets first: they must be zero)
+                wsb = ops.gemm_stats_ws_bytes(x.shape[0] * Ho * Wo, a0.dim) if x.dtype == torch.bfloat16 else 0
+                off = (len(blocks) * per + 15) // 16 * 16
+                scratch = torch.empty(off + (wsb + 3) // 4, dtype=torch.float32, device=x.device)
+                ws = scratch[off:].view(torch.uint8) if wsb else None
                 x = pe.run(x, out_stats=stats, zero=scratch)
                 alt = torch.empty_like(x)
                 for j, blk in enumerate(blocks):
-                    x, stats, alt = blk.run_fused(x, stats, scratch[j * per:(j + 1) * per], alt)
+                    x, stats, alt = blk.run_fused(x, stats, scratch[j * per:(j + 1) * per], alt, ws)
             else:
                 x = pe.run(x)
                 if self.training:

@@ -231,12 +231,17 @@ def _nbytes(t):
     return t.numel() * t.element_size() if t is not None else 0
 
 
+def gemm_stats_ws_bytes(M, N):
+    return int(_lib.load().emip_gemm_stats_ws_bytes(int(M), int(N)))
+
+
 def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=None, ln_eps=0.0, out_stats=None,
-         zero=None, colsum=None):
+         zero=None, colsum=None, stats_ws=None):
     """out[m, n] = act(a[m, :] . w[n, :] (+ a2 . w[n, K1:]) + bias[n]) + res[m, n]
     ln_stats f32 [M,2]: normalise the rows of a on the fly ((x - mean) * rstd; gamma / beta folded into w / bias);
     colsum f32 [N] (= w.float().sum(1)) with ln_stats: the same LayerNorm applied on the output side (emip_gemm_lne);
-    out_stats f32 [M,2]: accumulate (sum, sum of squares) of the stored rows; zero: scratch tensor this launch clears."""
+    out_stats f32 [M,2]: accumulate (sum, sum of squares) of the stored rows; zero: scratch tensor this launch clears;
+    stats_ws: workspace of emip_gemm_ln_ws (out_stats of rows spanning more than two column tiles without a second pass)."""
     M, K1, lda = rows(a)
     N, K = w.shape
     lda2 = 0
@@ -265,6 +270,13 @@ def gemm(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=No
         assert a2 is None and colsum.dtype == torch.float32 and colsum.numel() == N and colsum.is_contiguous()
         _lib.call("emip_gemm_lne", _p(a), _p(w), _p(out), _p(bias), _p(res), M, N, K, lda, K, ldc, ldr, act, _p(ln_stats),
                   _p(colsum), float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), dt_code(a.dtype), _stream())
+        return out
+    if stats_ws is not None and out_stats is not None:
+        # uint8 workspace (gemm_stats_ws_bytes, ticket block zero): row statistics combined inside the launch
+        assert stats_ws.dtype == torch.uint8 and stats_ws.is_contiguous()
+        _lib.call("emip_gemm_ln_ws", _p(a), _p(a2), _p(w), _p(out), _p(bias), _p(res), M, N, K, K1, lda, lda2, K, ldc, ldr, act,
+                  1, 0, 0, 0, 0, _p(ln_stats), K, float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), dt_code(a.dtype),
+                  _p(stats_ws), stats_ws.numel(), _stream())
         return out
     _lib.call("emip_gemm_ln", _p(a), _p(a2), _p(w), _p(out), _p(bias), _p(res), M, N, K, K1, lda, lda2, K, ldc, ldr, act,
               1, 0, 0, 0, 0, _p(ln_stats), K, float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), dt_code(a.dtype),
@@ -392,13 +404,16 @@ def conv2d_splitk(x, w, kh, kw, stride, pad, bias, acc, ksplit, ln_stats=None, l
     return acc
 
 
+KSPLIT_MAX = 2       # two partial tiles per output tile: their f32 atomic adds commute (reproducible); 16 before round 4
+
+
 def ksplit_for(M, Cout, K, dtype):
     """split count of emip_conv2d_ksplit for an [M, Cout] output over K: 0 = enough tiles / too short a walk to split"""
     tiles = ((M + 63) // 64) * ((Cout + 63) // 64)
     nk = K // (64 if dtype == torch.bfloat16 else 32)
     if tiles >= 192 or nk < 16:
         return 0
-    return max(2, min(nk // 4, (256 + tiles - 1) // tiles, 16))
+    return max(2, min(nk // 4, (256 + tiles - 1) // tiles, KSPLIT_MAX))
 
 
 def conv2d_ksplit(x, w, kh, kw, stride, pad, ksplit, bias=None, act=ACT_NONE, ln_stats=None, ln_eps=0.0, out_stats=None, out=None):

@@ -64,6 +64,20 @@ int emip_gemm_ln(const void* A, const void* A2, const void* W, void* C, const fl
                  long bsC, long bsR, const float* ln_stats, int ln_C, float ln_eps, float* out_stats, void* zero_ptr,
                  long zero_bytes, int dtype, void* stream);
 
+/* emip_gemm_ln with a caller-owned workspace for reproducible row statistics without a second pass (round 4).  A bf16 launch
+ * whose output rows span more than two column tiles cannot add the tiles' (sum, sum of squares) with atomics in a fixed order;
+ * without a workspace the launch is followed by a statistics pass over its output (row_stats_kernel).  With one, every column
+ * tile leaves its row partials there and draws a ticket, and the tile that draws the last ticket of its row tile adds the
+ * partials in column order and stores out_stats -- one launch, same bits as the pass.  stats_ws: emip_gemm_stats_ws_bytes(M, N)
+ * bytes, 64-byte aligned, the first 4 ceil(M / 64) bytes ZERO before the first use (every launch leaves them zero); it must
+ * not be shared by launches that may run at the same time.  NULL or too small: emip_gemm_ln's behaviour.
+ * (lib/pvt_v2.py:126,165-169: proj / fc2 + the statistics of the next LayerNorm) */
+long emip_gemm_stats_ws_bytes(int M, int N);
+int emip_gemm_ln_ws(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M, int N,
+                    int K, int K1, long lda, long lda2, long ldw, long ldc, long ldr, int act, int batch, long bsA, long bsW,
+                    long bsC, long bsR, const float* ln_stats, int ln_C, float ln_eps, float* out_stats, void* zero_ptr,
+                    long zero_bytes, int dtype, void* stats_ws, long stats_ws_bytes, void* stream);
+
 /* emip_gemm_ln with the LayerNorm applied on the OUTPUT side of the product (lib/pvt_v2.py:139-142 norm2 -> fc1,
  * :107-110 norm -> kv):  LN(x) W^T = rstd (x W^T) - rstd mean colsum(W) (+ the folded bias), so the main loop stages the raw
  * rows (LDS-DMA path) and the normalisation costs two FMAs per output element instead of one per staged operand element

