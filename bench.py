@@ -75,6 +75,11 @@ def _launch_info(lib, name, a):
         M = Bm * N
         # q projection + attention + proj + residual: tokens in and out, both weight matrices and the k / v rows once
         return 4.0 * M * C * C + 4.0 * M * Lk * C, "sra_block_kernel", 2.0 * (2 * M * C + 2 * C * C + Bm * Lk * 2 * C) + 16.0 * M
+    if name == "emip_conv3x3_halo":       # (X, ldx, Wp, Y, ldy, B, H, W, Cin, Cout, in_sums, in_eps, out_sums, ws, ws_bytes, stream)
+        Bm, H, W, Ci, Co = a[5], a[6], a[7], a[8], a[9]
+        M = Bm * H * W
+        # direct 3 x 3 convolution: input and output once, the weights once
+        return 2.0 * M * Co * 9 * Ci, "conv_halo_kernel", 2.0 * (M * Ci + M * Co + 9 * Ci * Co)
     if name == "emip_mlp_fc1dw":          # (X, ldx, W1, b1, colsum, ln_stats, eps, Wdw, bd, G, ldg, B, H, W, K, N, stream)
         Bm, H, W, K, N = a[11], a[12], a[13], a[14], a[15]
         M = Bm * H * W

@@ -1,0 +1,306 @@
+// 3 x 3 convolution (stride 1, zero padding 1, 64 -> 64 channels, bf16) of the GMFlow CNN encoder's first level as a DIRECT
+// convolution on an LDS-resident halo tile, with the InstanceNorm + ReLU of the producing layer applied while the tile is
+// staged and the statistics of the result taken in the epilogue (/root/reference/model/EMIP_short/motion/gmflow/backbone.py:
+// 39-69 ResidualBlock: conv1 -> norm1 -> relu -> conv2 -> norm2 -> relu, :154-192 CNNEncoder).
+//
+// The implicit-GEMM form (gemm8.hip, CONV) moves the input tile of every tap L2 -> LDS: nine passes over the same pixels
+// (360 KB per 256 output pixels), and InstanceNorm, which needs the whole image's statistics, costs a statistics pass and a
+// normalise pass over the tensor between any two convolutions (profiles/pmc_traffic.json: 3.2 GB of a 21-GB step).  Here:
+//   * persistent workgroups (one per CU, 8 waves); all nine taps' weights stay in LDS for the whole launch in MFMA A-fragment
+//     order (72 pieces of 1 KB: conflict-free ds_read_b128 at lane * 16);
+//   * an output tile is 16 x 16 pixels; its 18 x 18 x 64 input halo (41.5 KB) arrives by LDS-DMA (buffer_load ... lds) into one
+//     of two buffers while the previous tile is computed; pixels outside the image come back as zeros from the buffer
+//     descriptor's range check; the 16-byte chunk c of halo pixel P lies at chunk c ^ ((P >> 1) & 7) of its 128-byte row, so
+//     that the 16 lanes of a b128 read (16 neighbouring pixels, same channel chunk) cover all 64 banks;
+//   * NORM: before the tile is used every thread normalises 5 chunks of it in place -- relu((x - mean) * rstd) with the
+//     per-(image, channel) mean / rstd from the producer's sums -- except the chunks of pixels outside the image, which stay
+//     zero (the reference pads the NORMALISED tensor);
+//   * a wave owns 2 rows x 16 pixels x 64 output channels: per tap 4 B fragments (its pixels shifted by the tap, 16 input
+//     channels each) and 8 weight fragments feed 8 MFMAs 32x32x16; 72 MFMAs per tile and wave;
+//   * epilogue: accumulators -> bf16 -> an LDS image of the tile in the halo buffer just read: whole 128-byte lines leave for
+//     memory; STATS: per-channel (sum, sum of squares) of the ROUNDED values from columns of that image (thread = channel x
+//     eighth of the tile, fixed order), carried in registers over the workgroup's CONTIGUOUS tiles of an image -> one partial
+//     per (image, workgroup) in memory (device-scope store) + a ticket per image; the workgroup that draws an image's last
+//     ticket adds the partials in workgroup order in f64 and stores the sums the normalising consumers read.  No
+//     atomics on the sums, no waiting on other workgroups, no fences (gemm8.hip's statistics combine has the measurements).
+#include "common.h"
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ch_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 ch_bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ i32x4 ch_rsrc(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    return i32x4{(int)(unsigned)a, (int)((a >> 32) & 0xFFFFu), (int)bytes, 0x00020000};
+}
+__device__ __forceinline__ void ch_dma16(unsigned lds_dst, unsigned voff, i32x4 rs) {
+    unsigned keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, 0 offen lds\n\ts_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(lds_dst), "v"(voff), "s"(rs)
+        : "memory");
+}
+
+constexpr unsigned CH_OOB = 0x80000000u;
+constexpr int CH_C = 64, CH_T = 16, CH_HS = CH_T + 2, CH_HPX = CH_HS * CH_HS;          // 18 x 18 = 324 halo pixels
+constexpr int CH_HINS = (CH_HPX + 7) / 8;                                              // 41 DMA instructions of 8 pixels
+constexpr int CH_HALO = CH_HINS * 1024;                                                // 41 984 B
+constexpr int CH_W = 9 * 2 * 4 * 1024;                                                 // 73 728 B
+constexpr int CH_OFF_H = CH_W, CH_OFF_S = CH_W + 2 * CH_HALO;                          // statistics scratch behind the halos
+constexpr int CH_LDS = CH_OFF_S + 8 * CH_C * 2 * 4 + 64;                               // + [8 waves][64][2] f32 + the ticket
+static_assert(CH_LDS <= 160 * 1024, "LDS");
+
+struct ChArgs {
+    const bf16_t* X;        // [B, H, W, ldx >= 64]
+    const bf16_t* Wp;       // fragment-order weights (ops.conv3x3_halo_pack): [9 taps][2][4][64 lanes][8]
+    bf16_t* Y;              // [B, H, W, ldy >= 64]
+    long ldx, ldy;
+    int B, H, W, tx, ty;    // tiles per row / column
+    unsigned x_bytes;
+    const double* in_sums;  // NORM: [B][64][2] (sum, sum of squares) of the INPUT tensor's channels per image
+    float in_eps;
+    float* part;            // STATS: [B * ty * tx][64][2] tile partials
+    unsigned* cnt;          // STATS: [B] tickets (zero at launch, zero at exit)
+    double* out_sums;       // STATS: [B][64][2]
+};
+
+template <bool NORM, bool STATS>
+__global__ __launch_bounds__(512) void conv_halo_kernel(const ChArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
+    const i32x4 rsX = ch_rsrc(p.X, p.x_bytes);
+    const i32x4 rsW = ch_rsrc(p.Wp, (unsigned)CH_W);
+    const int per_img = p.tx * p.ty, ntiles = p.B * per_img;
+
+    // ---- halo of tile t -> buffer b: instruction i moves halo pixels 8 i .. 8 i + 7 (one 16-byte chunk per lane)
+    auto issue = [&](int t, int b) {
+        const int img = t / per_img, r = t - img * per_img;
+        const int y0 = (r / p.tx) * CH_T - 1, x0 = (r % p.tx) * CH_T - 1;
+        for (int i = wave; i < CH_HINS; i += 8) {
+            const int P = 8 * i + (lane >> 3);
+            const int hy = P / CH_HS, hx = P - hy * CH_HS;
+            const int gy = y0 + hy, gx = x0 + hx;
+            const bool in = P < CH_HPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned c = (unsigned)((lane & 7) ^ ((P >> 1) & 7));           // the logical chunk this slot holds
+            const unsigned off = in ? (unsigned)((((long)img * p.H + gy) * p.W + gx) * p.ldx * 2) + c * 16u : CH_OOB;
+            ch_dma16((unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + CH_OFF_H + b * CH_HALO + i * 1024)), off, rsX);
+        }
+    };
+    // ---- prologue: the weights (72 pieces of 1 KB, 9 per wave) and the first halo
+    for (int i = wave; i < 72; i += 8)
+        ch_dma16((unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + i * 1024)), (unsigned)(i * 1024 + lane * 16), rsW);
+    // workgroup b walks the CONTIGUOUS tiles [b N / G, (b + 1) N / G): neighbouring halos share rows in L2, and the tiles of a
+    // workgroup lie in one or two images, so the channel sums are carried in registers over tiles and published per image
+    const int G = gridDim.x;
+    const int t_begin = (int)(((long)blockIdx.x * ntiles) / G), t_end = (int)(((long)(blockIdx.x + 1) * ntiles) / G);
+    auto owner = [&](int t) { return (int)((((long)t + 1) * G - 1) / ntiles); };       // the workgroup whose range holds tile t
+    if (t_begin < t_end) issue(t_begin, 0);
+
+    // this lane's output pixel inside a tile and its halo pixel for tap (0, 0)
+    const int oy = 2 * wave + (px >> 4), ox = px & 15;
+    const int P00 = oy * CH_HS + ox;
+    float run1 = 0.f, run2 = 0.f;            // STATS: thread (channel tid & 63, eighth tid >> 6 of every tile) over this image's tiles
+
+    int buf = 0;
+    for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                       // the halo (and the weights) have landed; everyone has left the other buffer
+        if (t + 1 < t_end) issue(t + 1, buf ^ 1);
+        const int img = t / per_img, r = t - img * per_img;
+        const int ty0 = (r / p.tx) * CH_T, tx0 = (r % p.tx) * CH_T;
+        char* hb = smem + CH_OFF_H + buf * CH_HALO;
+
+        float* red = reinterpret_cast<float*>(smem + CH_OFF_S);                      // [8][64][2] f32 scratch
+        if (NORM) {
+            // the image's (mean, rstd) per input channel -> LDS, then in place: relu((x - mean) * rstd) on the 16-byte slots of
+            // pixels inside the image (2 592 slots; pixels outside stay zero: the reference pads the NORMALISED tensor)
+            if (tid < CH_C) {
+                const double* sm = p.in_sums + ((long)img * CH_C + tid) * 2;
+                const double n = (double)p.H * (double)p.W;
+                const float mu = (float)(sm[0] / n);
+                const float var = fmaxf((float)(sm[1] / n) - mu * mu, 0.f);
+                *reinterpret_cast<float2*>(red + 2 * tid) = make_float2(mu, rsqrtf(var + p.in_eps));
+            }
+            __syncthreads();
+            for (int s2 = tid; s2 < CH_HPX * 8; s2 += 512) {
+                const int P = s2 >> 3;
+                const int hy = P / CH_HS, hx = P - hy * CH_HS;
+                const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+                if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;
+                const int c = (s2 & 7) ^ ((P >> 1) & 7);
+                const ch_u32x4 v = *reinterpret_cast<const ch_u32x4*>(hb + s2 * 16);
+                unsigned vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 mr = *reinterpret_cast<const float4*>(red + 2 * (8 * c + 2 * j));      // (mean, rstd) of two channels
+                    const float x0 = fmaxf((__uint_as_float(vw[j] << 16) - mr.x) * mr.y, 0.f);
+                    const float x1 = fmaxf((__uint_as_float(vw[j] & 0xFFFF0000u) - mr.z) * mr.w, 0.f);
+                    ch_bf16x2 o;
+                    o[0] = (bf16_t)x0;
+                    o[1] = (bf16_t)x1;
+                    vw[j] = __builtin_bit_cast(unsigned, o);
+                }
+                *reinterpret_cast<ch_u32x4*>(hb + s2 * 16) = ch_u32x4{vw[0], vw[1], vw[2], vw[3]};
+            }
+            __syncthreads();
+        }
+
+        // ---- 9 taps x (4 B fragments, 8 weight fragments, 8 MFMAs)
+        f32x16 acc[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) acc[d][r2] = 0.f;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int P = P00 + (tap / 3) * CH_HS + (tap % 3);
+            const char* pb = hb + P * 128;
+            const int sw = (P >> 1) & 7;
+            ch_u32x4 bfr[4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) bfr[ks] = *reinterpret_cast<const ch_u32x4*>(pb + (((2 * ks + h) ^ sw) * 16));
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const ch_u32x4 af = *reinterpret_cast<const ch_u32x4*>(smem + ((tap * 2 + d) * 4 + ks) * 1024 + lane * 16);
+                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr[ks]),
+                                                                    acc[d], 0, 0, 0);
+                }
+        }
+
+        // ---- epilogue: register 4 g + j of tile d = output channel 32 d + 8 g + 4 h + j of this lane's pixel.  The tile goes
+        // through an LDS image [256 pixels][64 ch] bf16 in the halo buffer just read (same chunk swizzle): whole 128-byte lines
+        // leave for memory, and the channel sums read columns of it
+        __syncthreads();                                   // every wave is done with this halo buffer
+        {
+            const int q = 32 * wave + px, sw = (q >> 1) & 7;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)acc[d][4 * g + j];
+                    *reinterpret_cast<bf16x4*>(hb + q * 128 + (((4 * d + g) ^ sw) * 16) + 8 * h) = o;
+                }
+        }
+        __syncthreads();
+        {
+            const int c = tid & 7;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int q = 64 * pass + (tid >> 3);
+                const ch_u32x4 v = *reinterpret_cast<const ch_u32x4*>(hb + q * 128 + ((c ^ ((q >> 1) & 7)) * 16));
+                bf16_t* op = p.Y + (((long)img * p.H + ty0 + (q >> 4)) * p.W + tx0 + (q & 15)) * p.ldy;
+                *reinterpret_cast<ch_u32x4*>(op + 8 * c) = v;
+            }
+        }
+        if (STATS) {
+            // thread (channel, eighth of the tile): 32 pixels of its channel in pixel order, carried over the image's tiles
+            const int ch = tid & 63, part = tid >> 6;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const int q = 32 * part + k;
+                const unsigned short u = *reinterpret_cast<const unsigned short*>(hb + q * 128 + (((ch >> 3) ^ ((q >> 1) & 7)) * 16) + 2 * (ch & 7));
+                const float x = __uint_as_float((unsigned)u << 16);
+                run1 += x;
+                run2 = fmaf(x, x, run2);
+            }
+            if (t + 1 == t_end || (t + 1) / per_img != img) {
+                // this workgroup's last tile of the image: eighths in order -> ONE partial per (image, workgroup) in memory
+                // (device-scope store) + a ticket; the workgroup that draws the image's last ticket adds the partials in
+                // workgroup order, in f64.  How many workgroups touch an image follows from the partition: no communication
+                const int lo = img * per_img, b0 = owner(lo), nb = owner(lo + per_img - 1) - b0 + 1;
+                *reinterpret_cast<float2*>(red + (part * CH_C + ch) * 2) = make_float2(run1, run2);
+                run1 = run2 = 0.f;
+                __syncthreads();
+                float* pp = p.part + ((long)img * per_img) * CH_C * 2;                 // [<= per_img contributions][64][2]
+                if (tid < 2 * CH_C) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) s += red[w * CH_C * 2 + tid];
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(pp + (long)((int)blockIdx.x - b0) * CH_C * 2 + tid), __float_as_uint(s),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                unsigned* tick = reinterpret_cast<unsigned*>(smem + CH_OFF_S + 8 * CH_C * 2 * 4);
+                if (tid == 0) *tick = atomicAdd(p.cnt + img, 1u);
+                __syncthreads();
+                if (*tick == (unsigned)(nb - 1)) {
+                    if (tid < 2 * CH_C) {
+                        double s = 0.0;
+                        for (int k = 0; k < nb; k += 8) {          // device-scope loads, eight in flight (a chain of them waits a
+                            float v[8];                            // memory round trip EACH)
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float* a = pp + (long)min(k + e, nb - 1) * CH_C * 2 + tid;
+                                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[e]) : "v"(a) : "memory");
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (k + e < nb) s += (double)v[e];
+                        }
+                        p.out_sums[(long)img * CH_C * 2 + tid] = s;
+                    }
+                    if (tid == 0) __hip_atomic_store(p.cnt + img, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int emip_conv3x3_halo_eligible(int B, int H, int W, int Cin, int Cout) {
+    return B > 0 && Cin == CH_C && Cout == CH_C && H >= CH_T && W >= CH_T && (H % CH_T) == 0 && (W % CH_T) == 0;
+}
+extern "C" int emip_conv3x3_halo_pack_bytes(void) { return CH_W; }
+/* bytes of the statistics workspace: [B] tickets (64-byte block, ZERO before the first use) then the tile partials */
+extern "C" long emip_conv3x3_halo_ws_bytes(int B, int H, int W) {
+    return (((long)B * 4 + 63) & ~63L) + (long)B * (H / CH_T) * (W / CH_T) * CH_C * 2 * 4;
+}
+
+// Y = conv3x3(f(X)), stride 1, zero padding 1, no bias, 64 -> 64 channels, bf16 channels-last (row strides ldx / ldy in
+// elements); f = identity (in_sums NULL) or relu(InstanceNorm(X)) from in_sums f64 [B][64][2] = (sum, sum of squares) of X per
+// image and channel (biased variance, eps); out_sums (may be NULL): the same sums of the stored Y, through ws
+// (emip_conv3x3_halo_ws_bytes, ticket block zero).  Wp: ops.conv3x3_halo_pack.
+extern "C" int emip_conv3x3_halo(const void* X, long ldx, const void* Wp, void* Y, long ldy, int B, int H, int W, int Cin, int Cout,
+                                 const double* in_sums, float in_eps, double* out_sums, void* ws, long ws_bytes, void* stream) {
+    EMIP_REQUIRE(X && Wp && Y && emip_conv3x3_halo_eligible(B, H, W, Cin, Cout));
+    EMIP_REQUIRE(ldx >= CH_C && (ldx & 7) == 0 && ldy >= CH_C && (ldy & 7) == 0 && aligned16(X) && aligned16(Wp) && aligned16(Y));
+    const long xb = (((long)B * H * W - 1) * ldx + CH_C) * 2;
+    EMIP_REQUIRE(xb < (1L << 31));
+    EMIP_REQUIRE(!out_sums || (ws && ws_bytes >= emip_conv3x3_halo_ws_bytes(B, H, W) && (reinterpret_cast<uintptr_t>(ws) & 63u) == 0));
+    EMIP_REQUIRE(!in_sums || in_eps > 0.f);
+    ChArgs a{};
+    a.X = (const bf16_t*)X; a.Wp = (const bf16_t*)Wp; a.Y = (bf16_t*)Y; a.ldx = ldx; a.ldy = ldy; a.B = B; a.H = H; a.W = W;
+    a.tx = W / CH_T; a.ty = H / CH_T; a.x_bytes = (unsigned)xb; a.in_sums = in_sums; a.in_eps = in_eps; a.out_sums = out_sums;
+    if (out_sums) {
+        a.cnt = (unsigned*)ws;
+        a.part = (float*)((char*)ws + (((long)B * 4 + 63) & ~63L));
+    }
+    const int ntiles = B * a.tx * a.ty;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    void (*fn)(const ChArgs) = in_sums ? (out_sums ? conv_halo_kernel<true, true> : conv_halo_kernel<true, false>)
+                                       : (out_sums ? conv_halo_kernel<false, true> : conv_halo_kernel<false, false>);
+    static bool attr[4] = {false, false, false, false};
+    const int which = (in_sums ? 2 : 0) + (out_sums ? 1 : 0);
+    if (!attr[which]) {
+        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, CH_LDS) != hipSuccess) return EMIP_E_LAUNCH;
+        attr[which] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), CH_LDS, (hipStream_t)stream, a);
+    return emip_launch_status();
+}

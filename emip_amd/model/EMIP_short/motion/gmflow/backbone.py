@@ -22,6 +22,23 @@ def _conv_inorm(x, w, k, stride, pad, relu, bias=None, res=None, relu_outer=Fals
     return ops.chan_norm_apply(y, sums, B, 1e-5, relu_inner=relu, relu_outer=relu_outer, res=res, out=y)
 
 
+# the 64 -> 64 stride-1 convolutions (layer1 at half resolution: 4 of the encoder's 15 convolutions and the largest tensors) as
+# direct convolutions on an LDS halo tile with norm1 + ReLU applied while conv2 stages its input and the InstanceNorm sums taken
+# in the conv epilogues (emip_conv3x3_halo, conv_halo.hip): per block 3 launches instead of 6 and 4 tensor passes instead of 9.
+# bf16, H and W multiples of 16; anything else takes the conv + statistics + normalise launches
+CNN_HALO = True
+
+
+def _halo_block(x, w1p, w2p, ws):
+    """backbone.py:39-69 for in_planes == planes == 64, stride 1: relu(x + norm2(conv2(relu(norm1(conv1(x))))))"""
+    B = x.shape[0]
+    s1 = torch.empty((B, 64, 2), dtype=torch.float64, device=x.device)
+    s2 = torch.empty((B, 64, 2), dtype=torch.float64, device=x.device)
+    y1 = ops.conv3x3_halo(x, w1p, out_sums=s1, ws=ws)
+    y2 = ops.conv3x3_halo(y1, w2p, in_sums=s1, in_eps=1e-5, out_sums=s2, ws=ws, out=torch.empty_like(y1))
+    return ops.chan_norm_apply(y2, s2, B, 1e-5, relu_inner=True, relu_outer=True, res=x, out=y2)
+
+
 class ResidualBlock(EmipModule):
     """backbone.py:39-69"""
 
@@ -37,8 +54,12 @@ class ResidualBlock(EmipModule):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride),
                                             norm_layer(planes))
 
-    def run(self, x):
+    def run(self, x, halo_ws=None):
         dt = self.cdtype
+        if halo_ws is not None and self.downsample is None and self.stride == 1:
+            w1p, w2p = self.packed("wh", (self.conv1.weight, self.conv2.weight),
+                                   lambda a, b: (ops.conv3x3_halo_pack(pack_conv(a, dt)), ops.conv3x3_halo_pack(pack_conv(b, dt))))
+            return _halo_block(x, w1p, w2p, halo_ws)
         w1, w2 = self.packed("w", (self.conv1.weight, self.conv2.weight),
                              lambda a, b: (pack_conv(a, dt), pack_conv(b, dt)))
         y = _conv_inorm(x, w1, 3, self.stride, 1, relu=True)
@@ -81,8 +102,22 @@ class CNNEncoder(EmipModule):
         w1, w2, b2 = self.packed("w", (self.conv1.weight, self.conv2.weight, self.conv2.bias),
                                  lambda a, b, c: (pack_conv(a, dt, cin_pad=cin), pack_linear(b.reshape(b.shape[0], -1), dt),
                                                   f32(c)))
-        x = _conv_inorm(img_cl, w1, 7, 2, 3, relu=True)
-        for layer in (self.layer1, self.layer2, self.layer3):
+        B, H, W = img_cl.shape[0], (img_cl.shape[1] + 1) // 2, (img_cl.shape[2] + 1) // 2
+        if CNN_HALO and dt == torch.bfloat16 and ops.conv3x3_halo_eligible(B, H, W, 64, 64):
+            # the stem as before; its statistics scratch and the ticket block of layer1's workspace are one allocation, cleared by
+            # the stem conv's first workgroup (the halo launches leave the tickets at zero, a graph replay starts from zero again)
+            nb = B * 64 * 2 * 8
+            wsb = ops.conv3x3_halo_ws_bytes(B, H, W)
+            buf = torch.empty(nb + wsb, dtype=torch.uint8, device=img_cl.device)
+            sums, ws = buf[:nb].view(torch.float64).view(B, 64, 2), buf[nb:]
+            y = ops.conv2d(img_cl, w1, 7, 7, 2, 3, zero=buf[:nb + (4 * B + 63) // 64 * 64])
+            ops.chan_stats(y, B, sums=sums)
+            x = ops.chan_norm_apply(y, sums, B, 1e-5, relu_inner=True, out=y)
+            x = self.layer1[1].run(self.layer1[0].run(x, ws), ws)
+        else:
+            x = _conv_inorm(img_cl, w1, 7, 2, 3, relu=True)
+            x = self.layer1[1].run(self.layer1[0].run(x))
+        for layer in (self.layer2, self.layer3):
             x = layer[1].run(layer[0].run(x))
         return ops.gemm(x, w2, bias=b2)
 
