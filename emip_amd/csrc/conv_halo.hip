@@ -261,36 +261,298 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ChArgs p) {
     }
 }
 
+
+// ---- the wider levels (96 and 128 channels: 88 x 88 and 44 x 44 maps): nine taps of weights no longer fit beside the halo, so
+// they STREAM: one tap (C x C, 18 / 32 KB in fragment order) per ring slot, two slots, tap k + 1 in flight while tap k is
+// used, one s_barrier per tap; with 96 channels the NEXT tile's halo rides along in eight pieces (one DMA instruction per
+// wave and tap) into the second halo buffer; with 128 channels one halo buffer is all that fits (at 32 images a CU has one
+// tile).  Tiles are 11 x 22 pixels (242 of the 256 pixel lanes): 176, 88 and 44 are multiples of both, and 32 images give
+// 4 096 / 1 024 / 256 tiles = 16 / 4 / 1 per CU exactly.  Chunk swizzles per pixel pitch: 128 B: c ^ ((P >> 1) & 7),
+// 192 B: c ^ ((P >> 2) & 3), 256 B: c ^ (P & 15) -- each makes the 16 lanes of a b128 read cover the 64 banks.
+constexpr int CS_TH = 11, CS_TW = 22, CS_TPX = CS_TH * CS_TW, CS_HY = CS_TH + 2, CS_HX = CS_TW + 2, CS_HPX = CS_HY * CS_HX;   // 242, 13 x 24 = 312
+
+template <int C>
+struct CsGeo {
+    static constexpr int NCH = C / 8, CB = 2 * C, NKS = C / 16, NCT = C / 32;
+    static constexpr int TAPW = C * C * 2, NWI = (TAPW / 1024 + 7) / 8;              // weight DMA instructions per wave and tap
+    static constexpr int HINS = (CS_HPX * NCH + 63) / 64, HALO = HINS * 1024;
+    static constexpr bool DBL = C <= 96;                                            // two halo buffers
+    static constexpr int OFF_W = (DBL ? 2 : 1) * HALO, OFF_S = OFF_W + 2 * TAPW;    // scratch: 1 KB table / ticket + 1 KB dump
+    static constexpr int LDS = OFF_S + 2048;
+    static constexpr int NP = 512 / C, PP = (CS_TPX + NP - 1) / NP;                 // statistics: parts of the tile, pixels per part
+    static_assert(LDS <= 160 * 1024 && CS_TPX * CB + NP * C * 8 <= HALO && HINS <= 64 + (DBL ? 0 : 64), "LDS");
+    __device__ static __forceinline__ int swz(int P) { return C == 64 ? (P >> 1) & 7 : (C == 96 ? (P >> 2) & 3 : P & 15); }
+};
+
+template <int C, bool NORM, bool STATS>
+__global__ __launch_bounds__(512) void conv_halo_stream_kernel(const ChArgs p) {
+    typedef CsGeo<C> Gm;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
+    const i32x4 rsX = ch_rsrc(p.X, p.x_bytes);
+    const i32x4 rsW = ch_rsrc(p.Wp, (unsigned)(9 * Gm::TAPW));
+    const int per_img = p.tx * p.ty, ntiles = p.B * per_img;
+    const unsigned dump = lds0 + Gm::OFF_S + 1024;
+
+    // halo instruction i of tile t -> buffer b (slot s = 64 i + lane: pixel s / NCH, physical chunk s % NCH)
+    auto issue_h = [&](int t, int b, int i) {
+        const bool live = t < ntiles && i < Gm::HINS;
+        const int tt = min(t, ntiles - 1);
+        const int img = tt / per_img, r = tt - img * per_img;
+        const int y0 = (r / p.tx) * CS_TH - 1, x0 = (r % p.tx) * CS_TW - 1;
+        const int sl = 64 * i + lane, P = sl / Gm::NCH, cp = sl - P * Gm::NCH;
+        const int hy = P / CS_HX, hx = P - hy * CS_HX;
+        const int gy = y0 + hy, gx = x0 + hx;
+        const bool in = live && P < CS_HPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        const unsigned c = (unsigned)(cp ^ Gm::swz(P));
+        const unsigned off = in ? (unsigned)((((long)img * p.H + gy) * p.W + gx) * p.ldx * 2) + c * 16u : CH_OOB;
+        const unsigned dst = live ? lds0 + b * Gm::HALO + i * 1024 : dump;
+        ch_dma16((unsigned)__builtin_amdgcn_readfirstlane((int)dst), off, rsX);
+    };
+    // the weights of tap k -> ring slot: NWI instructions per wave (pieces beyond the tap go to the dump: the counts the
+    // vmcnt waits rely on are the same for every wave)
+    auto issue_w = [&](int k, int slot) {
+#pragma unroll
+        for (int m = 0; m < Gm::NWI; ++m) {
+            const int j = wave + 8 * m;
+            const bool live = j < Gm::TAPW / 1024;
+            const unsigned dst = live ? lds0 + Gm::OFF_W + slot * Gm::TAPW + j * 1024 : dump;
+            ch_dma16((unsigned)__builtin_amdgcn_readfirstlane((int)dst), live ? (unsigned)(k * Gm::TAPW + j * 1024 + lane * 16) : CH_OOB, rsW);
+        }
+    };
+
+    const int G = gridDim.x;
+    const int t_begin = (int)(((long)blockIdx.x * ntiles) / G), t_end = (int)(((long)(blockIdx.x + 1) * ntiles) / G);
+    auto owner = [&](int t) { return (int)((((long)t + 1) * G - 1) / ntiles); };
+    if (t_begin < t_end) {
+        for (int i = wave; i < Gm::HINS; i += 8) issue_h(t_begin, 0, i);
+        issue_w(0, 0);
+    }
+    // this lane's output pixel (lanes 242 .. 255 of the tile repeat the last pixel and store nothing)
+    const int q = min(32 * wave + px, CS_TPX - 1);
+    const bool q_ok = 32 * wave + px < CS_TPX;
+    const int oy = q / CS_TW, ox = q - oy * CS_TW;
+    const int P00 = oy * CS_HX + ox;
+    float run1 = 0.f, run2 = 0.f;
+    float* tab = reinterpret_cast<float*>(smem + Gm::OFF_S);            // NORM: [C][2] (mean, rstd); publish: the ticket at tab[0]
+
+    int buf = 0;
+    int wslot = 0;                                                      // ring slot of the tap about to be used
+    for (int t = t_begin; t < t_end; ++t, buf ^= (Gm::DBL ? 1 : 0)) {
+        const int img = t / per_img, r = t - img * per_img;
+        const int ty0 = (r / p.tx) * CS_TH, tx0 = (r % p.tx) * CS_TW;
+        char* hb = smem + buf * Gm::HALO;
+        if (!Gm::DBL && t > t_begin) {
+            // one halo buffer: everyone is out of the image of the previous tile -> load this tile's halo now
+            __syncthreads();
+            for (int i = wave; i < Gm::HINS; i += 8) issue_h(t, 0, i);
+        }
+        f32x16 acc[Gm::NCT];
+#pragma unroll
+        for (int d = 0; d < Gm::NCT; ++d)
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) acc[d][r2] = 0.f;
+#pragma unroll 1
+        for (int tap = 0; tap < 9; ++tap) {
+            // tap's weights (issued one tap ago) have landed once everything but the halo piece issued behind them is done
+            if (tap == 0 || !Gm::DBL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            __syncthreads();
+            // next tap's weights (the first tap of the next tile behind the last one) + a piece of the next tile's halo
+            if (tap < 8 || t + 1 < t_end) issue_w(tap < 8 ? tap + 1 : 0, wslot ^ 1);
+            else issue_w(0, wslot ^ 1);                                  // (nothing follows: harmless, keeps the counts)
+            if (Gm::DBL && tap < 8) issue_h(t + 1 < t_end ? t + 1 : ntiles, buf ^ 1, wave + 8 * tap);
+            if (NORM && tap == 0) {
+                if (tid < C) {
+                    const double* sm = p.in_sums + ((long)img * C + tid) * 2;
+                    const double n = (double)p.H * (double)p.W;
+                    const float mu = (float)(sm[0] / n);
+                    const float var = fmaxf((float)(sm[1] / n) - mu * mu, 0.f);
+                    *reinterpret_cast<float2*>(tab + 2 * tid) = make_float2(mu, rsqrtf(var + p.in_eps));
+                }
+                __syncthreads();
+                for (int s2 = tid; s2 < CS_HPX * Gm::NCH; s2 += 512) {
+                    const int P = s2 / Gm::NCH, cp = s2 - P * Gm::NCH;
+                    const int hy = P / CS_HX, hx = P - hy * CS_HX;
+                    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+                    if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;
+                    const int c = cp ^ Gm::swz(P);
+                    const ch_u32x4 v = *reinterpret_cast<const ch_u32x4*>(hb + s2 * 16);
+                    unsigned vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 mr = *reinterpret_cast<const float4*>(tab + 2 * (8 * c + 2 * j));
+                        const float x0 = fmaxf((__uint_as_float(vw[j] << 16) - mr.x) * mr.y, 0.f);
+                        const float x1 = fmaxf((__uint_as_float(vw[j] & 0xFFFF0000u) - mr.z) * mr.w, 0.f);
+                        ch_bf16x2 o;
+                        o[0] = (bf16_t)x0;
+                        o[1] = (bf16_t)x1;
+                        vw[j] = __builtin_bit_cast(unsigned, o);
+                    }
+                    *reinterpret_cast<ch_u32x4*>(hb + s2 * 16) = ch_u32x4{vw[0], vw[1], vw[2], vw[3]};
+                }
+                __syncthreads();
+            }
+            const int P = P00 + (tap / 3) * CS_HX + (tap % 3);
+            const char* pb = hb + P * Gm::CB;
+            const int sw = Gm::swz(P);
+            const char* wb = smem + Gm::OFF_W + wslot * Gm::TAPW + lane * 16;
+            ch_u32x4 bfr[Gm::NKS];
+#pragma unroll
+            for (int ks = 0; ks < Gm::NKS; ++ks) bfr[ks] = *reinterpret_cast<const ch_u32x4*>(pb + (((2 * ks + h) ^ sw) * 16));
+#pragma unroll
+            for (int d = 0; d < Gm::NCT; ++d)
+#pragma unroll
+                for (int ks = 0; ks < Gm::NKS; ++ks) {
+                    const ch_u32x4 af = *reinterpret_cast<const ch_u32x4*>(wb + (d * Gm::NKS + ks) * 1024);
+                    acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bfr[ks]),
+                                                                    acc[d], 0, 0, 0);
+                }
+            wslot ^= 1;
+        }
+
+        // ---- epilogue through an LDS image [242 pixels][C] bf16 in the halo buffer just read (same swizzle)
+        __syncthreads();
+        if (q_ok) {
+            const int sw = Gm::swz(q);
+#pragma unroll
+            for (int d = 0; d < Gm::NCT; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)acc[d][4 * g + j];
+                    *reinterpret_cast<bf16x4*>(hb + q * Gm::CB + (((4 * d + g) ^ sw) * 16) + 8 * h) = o;
+                }
+        }
+        __syncthreads();
+        for (int s2 = tid; s2 < CS_TPX * Gm::NCH; s2 += 512) {
+            const int qq = s2 / Gm::NCH, c = s2 - qq * Gm::NCH;
+            const ch_u32x4 v = *reinterpret_cast<const ch_u32x4*>(hb + qq * Gm::CB + ((c ^ Gm::swz(qq)) * 16));
+            const int yy = qq / CS_TW, xx = qq - yy * CS_TW;
+            bf16_t* op = p.Y + (((long)img * p.H + ty0 + yy) * p.W + tx0 + xx) * p.ldy;
+            *reinterpret_cast<ch_u32x4*>(op + 8 * c) = v;
+        }
+        if (STATS) {
+            const int ch = tid % C, part = tid / C;
+            if (part < Gm::NP) {
+                const int q1 = min(CS_TPX, (part + 1) * Gm::PP);
+                for (int qq = part * Gm::PP; qq < q1; ++qq) {
+                    const unsigned short u = *reinterpret_cast<const unsigned short*>(hb + qq * Gm::CB + (((ch >> 3) ^ Gm::swz(qq)) * 16) + 2 * (ch & 7));
+                    const float x = __uint_as_float((unsigned)u << 16);
+                    run1 += x;
+                    run2 = fmaf(x, x, run2);
+                }
+            }
+            if (t + 1 == t_end || (t + 1) / per_img != img) {
+                const int lo = img * per_img, b0 = owner(lo), nb = owner(lo + per_img - 1) - b0 + 1;
+                __syncthreads();                                           // the column reads of the image are done
+                float* red = reinterpret_cast<float*>(hb + CS_TPX * Gm::CB);   // [NP][C][2] behind the image
+                if (part < Gm::NP) *reinterpret_cast<float2*>(red + (part * C + ch) * 2) = make_float2(run1, run2);
+                run1 = run2 = 0.f;
+                __syncthreads();
+                float* pp = p.part + ((long)img * per_img) * C * 2;
+                if (tid < 2 * C) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int w = 0; w < Gm::NP; ++w) sacc += red[w * C * 2 + tid];
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(pp + (long)((int)blockIdx.x - b0) * C * 2 + tid), __float_as_uint(sacc),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                unsigned* tick = reinterpret_cast<unsigned*>(tab);
+                if (tid == 0) *tick = atomicAdd(p.cnt + img, 1u);
+                __syncthreads();
+                if (*tick == (unsigned)(nb - 1)) {
+                    if (tid < 2 * C) {
+                        double sd = 0.0;
+                        for (int k = 0; k < nb; k += 8) {
+                            float v[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float* a = pp + (long)min(k + e, nb - 1) * C * 2 + tid;
+                                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[e]) : "v"(a) : "memory");
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (k + e < nb) sd += (double)v[e];
+                        }
+                        p.out_sums[(long)img * C * 2 + tid] = sd;
+                    }
+                    if (tid == 0) __hip_atomic_store(p.cnt + img, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+template <int C>
+int launch_stream(const ChArgs& a, bool norm, bool stats, int grid, hipStream_t s) {
+    void (*fn)(const ChArgs) = norm ? (stats ? conv_halo_stream_kernel<C, true, true> : conv_halo_stream_kernel<C, true, false>)
+                                    : (stats ? conv_halo_stream_kernel<C, false, true> : conv_halo_stream_kernel<C, false, false>);
+    static bool attr[4] = {false, false, false, false};
+    const int which = (norm ? 2 : 0) + (stats ? 1 : 0);
+    if (!attr[which]) {
+        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, CsGeo<C>::LDS) != hipSuccess) return EMIP_E_LAUNCH;
+        attr[which] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), CsGeo<C>::LDS, s, a);
+    return emip_launch_status();
+}
+
 }  // namespace
 
+static bool ch_resident(int H, int W, int C) { return C == CH_C && (H % CH_T) == 0 && (W % CH_T) == 0; }
+static bool ch_stream(int H, int W, int C) { return (C == 64 || C == 96 || C == 128) && (H % CS_TH) == 0 && (W % CS_TW) == 0; }
+
 extern "C" int emip_conv3x3_halo_eligible(int B, int H, int W, int Cin, int Cout) {
-    return B > 0 && Cin == CH_C && Cout == CH_C && H >= CH_T && W >= CH_T && (H % CH_T) == 0 && (W % CH_T) == 0;
+    return B > 0 && Cin == Cout && H > 0 && W > 0 && (ch_resident(H, W, Cin) || ch_stream(H, W, Cin));
 }
-extern "C" int emip_conv3x3_halo_pack_bytes(void) { return CH_W; }
-/* bytes of the statistics workspace: [B] tickets (64-byte block, ZERO before the first use) then the tile partials */
-extern "C" long emip_conv3x3_halo_ws_bytes(int B, int H, int W) {
-    return (((long)B * 4 + 63) & ~63L) + (long)B * (H / CH_T) * (W / CH_T) * CH_C * 2 * 4;
+extern "C" int emip_conv3x3_halo_pack_bytes(int C) { return 9 * C * C * 2; }
+/* bytes of the statistics workspace: [B] tickets (64-byte block, ZERO before the first use) then the partials, one per
+ * (image, workgroup that holds tiles of it): never more than the image's tiles */
+extern "C" long emip_conv3x3_halo_ws_bytes(int B, int H, int W, int C) {
+    const long t16 = (long)((H + CH_T - 1) / CH_T) * ((W + CH_T - 1) / CH_T), t11 = (long)((H + CS_TH - 1) / CS_TH) * ((W + CS_TW - 1) / CS_TW);
+    return (((long)B * 4 + 63) & ~63L) + (long)B * (t16 > t11 ? t16 : t11) * C * 2 * 4;
 }
 
-// Y = conv3x3(f(X)), stride 1, zero padding 1, no bias, 64 -> 64 channels, bf16 channels-last (row strides ldx / ldy in
-// elements); f = identity (in_sums NULL) or relu(InstanceNorm(X)) from in_sums f64 [B][64][2] = (sum, sum of squares) of X per
-// image and channel (biased variance, eps); out_sums (may be NULL): the same sums of the stored Y, through ws
-// (emip_conv3x3_halo_ws_bytes, ticket block zero).  Wp: ops.conv3x3_halo_pack.
+// Y = conv3x3(f(X)), stride 1, zero padding 1, no bias, C -> C channels (64: H, W multiples of 16, or 64 / 96 / 128: H a multiple
+// of 11 and W of 22), bf16 channels-last (row strides ldx / ldy in elements); f = identity (in_sums NULL) or
+// relu(InstanceNorm(X)) from in_sums f64 [B][C][2] = (sum, sum of squares) of X per image and channel (biased variance, eps);
+// out_sums (may be NULL): the same sums of the stored Y, through ws (emip_conv3x3_halo_ws_bytes, ticket block zero).
+// Wp: ops.conv3x3_halo_pack.
 extern "C" int emip_conv3x3_halo(const void* X, long ldx, const void* Wp, void* Y, long ldy, int B, int H, int W, int Cin, int Cout,
                                  const double* in_sums, float in_eps, double* out_sums, void* ws, long ws_bytes, void* stream) {
     EMIP_REQUIRE(X && Wp && Y && emip_conv3x3_halo_eligible(B, H, W, Cin, Cout));
-    EMIP_REQUIRE(ldx >= CH_C && (ldx & 7) == 0 && ldy >= CH_C && (ldy & 7) == 0 && aligned16(X) && aligned16(Wp) && aligned16(Y));
-    const long xb = (((long)B * H * W - 1) * ldx + CH_C) * 2;
+    const int C = Cin;
+    EMIP_REQUIRE(ldx >= C && (ldx & 7) == 0 && ldy >= C && (ldy & 7) == 0 && aligned16(X) && aligned16(Wp) && aligned16(Y));
+    const long xb = (((long)B * H * W - 1) * ldx + C) * 2;
     EMIP_REQUIRE(xb < (1L << 31));
-    EMIP_REQUIRE(!out_sums || (ws && ws_bytes >= emip_conv3x3_halo_ws_bytes(B, H, W) && (reinterpret_cast<uintptr_t>(ws) & 63u) == 0));
+    EMIP_REQUIRE(!out_sums || (ws && ws_bytes >= emip_conv3x3_halo_ws_bytes(B, H, W, C) && (reinterpret_cast<uintptr_t>(ws) & 63u) == 0));
     EMIP_REQUIRE(!in_sums || in_eps > 0.f);
     ChArgs a{};
     a.X = (const bf16_t*)X; a.Wp = (const bf16_t*)Wp; a.Y = (bf16_t*)Y; a.ldx = ldx; a.ldy = ldy; a.B = B; a.H = H; a.W = W;
-    a.tx = W / CH_T; a.ty = H / CH_T; a.x_bytes = (unsigned)xb; a.in_sums = in_sums; a.in_eps = in_eps; a.out_sums = out_sums;
+    a.x_bytes = (unsigned)xb; a.in_sums = in_sums; a.in_eps = in_eps; a.out_sums = out_sums;
     if (out_sums) {
         a.cnt = (unsigned*)ws;
         a.part = (float*)((char*)ws + (((long)B * 4 + 63) & ~63L));
     }
+    if (!ch_resident(H, W, C)) {
+        a.tx = W / CS_TW; a.ty = H / CS_TH;
+        const int nt = B * a.tx * a.ty, gr = nt < 256 ? nt : 256;
+        if (C == 64) return launch_stream<64>(a, in_sums != nullptr, out_sums != nullptr, gr, (hipStream_t)stream);
+        if (C == 96) return launch_stream<96>(a, in_sums != nullptr, out_sums != nullptr, gr, (hipStream_t)stream);
+        return launch_stream<128>(a, in_sums != nullptr, out_sums != nullptr, gr, (hipStream_t)stream);
+    }
+    a.tx = W / CH_T; a.ty = H / CH_T;
     const int ntiles = B * a.tx * a.ty;
     const int grid = ntiles < 256 ? ntiles : 256;
     void (*fn)(const ChArgs) = in_sums ? (out_sums ? conv_halo_kernel<true, true> : conv_halo_kernel<true, false>)

@@ -22,18 +22,22 @@ def _conv_inorm(x, w, k, stride, pad, relu, bias=None, res=None, relu_outer=Fals
     return ops.chan_norm_apply(y, sums, B, 1e-5, relu_inner=relu, relu_outer=relu_outer, res=res, out=y)
 
 
-# the 64 -> 64 stride-1 convolutions (layer1 at half resolution: 4 of the encoder's 15 convolutions and the largest tensors) as
-# direct convolutions on an LDS halo tile with norm1 + ReLU applied while conv2 stages its input and the InstanceNorm sums taken
-# in the conv epilogues (emip_conv3x3_halo, conv_halo.hip): per block 3 launches instead of 6 and 4 tensor passes instead of 9.
-# bf16, H and W multiples of 16; anything else takes the conv + statistics + normalise launches
+# the stride-1 3 x 3 convolutions of the residual blocks (10 of the encoder's 15 convolutions) as direct convolutions on an LDS
+# halo tile with norm1 + ReLU applied while conv2 stages its input and the InstanceNorm sums taken in the conv epilogues
+# (emip_conv3x3_halo, conv_halo.hip): a stride-1 block is 3 launches instead of 6 and 4 tensor passes instead of 9.  bf16 and
+# the shapes that kernel takes (352 x 352 inputs: all three levels); anything else takes conv + statistics + normalise launches
 CNN_HALO = True
+# widest block that takes it.  Measured (MI355X, 16 pairs, tools/flag_ab.py; pairs/s with 4 steps in flight | one step at a time):
+# none 2223 | 1344, 64: 2327 | 1400, 96: 2405 | 1432, 128: 2027 | 1440 -- the 128-channel form (one 11 x 22 tile per CU at 32
+# images, one halo buffer, 146 KB of LDS) is the shortest alone and the most expensive beside other steps' kernels
+CNN_HALO_MAXC = 96
 
 
 def _halo_block(x, w1p, w2p, ws):
-    """backbone.py:39-69 for in_planes == planes == 64, stride 1: relu(x + norm2(conv2(relu(norm1(conv1(x))))))"""
-    B = x.shape[0]
-    s1 = torch.empty((B, 64, 2), dtype=torch.float64, device=x.device)
-    s2 = torch.empty((B, 64, 2), dtype=torch.float64, device=x.device)
+    """backbone.py:39-69 for in_planes == planes, stride 1: relu(x + norm2(conv2(relu(norm1(conv1(x))))))"""
+    B, C = x.shape[0], x.shape[-1]
+    s1 = torch.empty((B, C, 2), dtype=torch.float64, device=x.device)
+    s2 = torch.empty((B, C, 2), dtype=torch.float64, device=x.device)
     y1 = ops.conv3x3_halo(x, w1p, out_sums=s1, ws=ws)
     y2 = ops.conv3x3_halo(y1, w2p, in_sums=s1, in_eps=1e-5, out_sums=s2, ws=ws, out=torch.empty_like(y1))
     return ops.chan_norm_apply(y2, s2, B, 1e-5, relu_inner=True, relu_outer=True, res=x, out=y2)
@@ -56,10 +60,27 @@ class ResidualBlock(EmipModule):
 
     def run(self, x, halo_ws=None):
         dt = self.cdtype
+        planes = self.conv2.weight.shape[0]
+        B, Ho, Wo = x.shape[0], (x.shape[1] - 1) // self.stride + 1, (x.shape[2] - 1) // self.stride + 1
+        if halo_ws is not None and not (dt == torch.bfloat16 and planes <= CNN_HALO_MAXC and ops.conv3x3_halo_eligible(B, Ho, Wo, planes, planes)
+                                        and halo_ws.numel() >= ops.conv3x3_halo_ws_bytes(B, Ho, Wo, planes)):
+            halo_ws = None
         if halo_ws is not None and self.downsample is None and self.stride == 1:
             w1p, w2p = self.packed("wh", (self.conv1.weight, self.conv2.weight),
                                    lambda a, b: (ops.conv3x3_halo_pack(pack_conv(a, dt)), ops.conv3x3_halo_pack(pack_conv(b, dt))))
             return _halo_block(x, w1p, w2p, halo_ws)
+        if halo_ws is not None:
+            # the strided first convolution and the 1 x 1 downsample stay implicit GEMMs; conv2 normalises conv1's raw output
+            # while it stages it and takes its own sums
+            w1, w2p, wd, bd = self.packed("wh2", (self.conv1.weight, self.conv2.weight, self.downsample[0].weight, self.downsample[0].bias),
+                                          lambda a, b, c, d: (pack_conv(a, dt), ops.conv3x3_halo_pack(pack_conv(b, dt)), pack_conv(c, dt), f32(d)))
+            s1 = torch.empty((B, planes, 2), dtype=torch.float64, device=x.device)
+            s2 = torch.empty((B, planes, 2), dtype=torch.float64, device=x.device)
+            y1 = ops.conv2d(x, w1, 3, 3, self.stride, 1, zero=s1)
+            ops.chan_stats(y1, B, sums=s1)
+            y2 = ops.conv3x3_halo(y1, w2p, in_sums=s1, in_eps=1e-5, out_sums=s2, ws=halo_ws, out=torch.empty_like(y1))
+            res = _conv_inorm(x, wd, 1, self.stride, 0, relu=False, bias=bd)
+            return ops.chan_norm_apply(y2, s2, B, 1e-5, relu_inner=True, relu_outer=True, res=res, out=y2)
         w1, w2 = self.packed("w", (self.conv1.weight, self.conv2.weight),
                              lambda a, b: (pack_conv(a, dt), pack_conv(b, dt)))
         y = _conv_inorm(x, w1, 3, self.stride, 1, relu=True)
@@ -104,21 +125,21 @@ class CNNEncoder(EmipModule):
                                                   f32(c)))
         B, H, W = img_cl.shape[0], (img_cl.shape[1] + 1) // 2, (img_cl.shape[2] + 1) // 2
         if CNN_HALO and dt == torch.bfloat16 and ops.conv3x3_halo_eligible(B, H, W, 64, 64):
-            # the stem as before; its statistics scratch and the ticket block of layer1's workspace are one allocation, cleared by
-            # the stem conv's first workgroup (the halo launches leave the tickets at zero, a graph replay starts from zero again)
+            # the stem as before; its statistics scratch and the ticket block of the halo launches' workspace are one allocation,
+            # cleared by the stem conv's first workgroup (the halo launches leave the tickets at zero, a graph replay starts from
+            # zero again); the workspace is sized for layer1, which needs the most, and serves all three levels in turn
             nb = B * 64 * 2 * 8
-            wsb = ops.conv3x3_halo_ws_bytes(B, H, W)
+            wsb = ops.conv3x3_halo_ws_bytes(B, H, W, 64)
             buf = torch.empty(nb + wsb, dtype=torch.uint8, device=img_cl.device)
             sums, ws = buf[:nb].view(torch.float64).view(B, 64, 2), buf[nb:]
             y = ops.conv2d(img_cl, w1, 7, 7, 2, 3, zero=buf[:nb + (4 * B + 63) // 64 * 64])
             ops.chan_stats(y, B, sums=sums)
             x = ops.chan_norm_apply(y, sums, B, 1e-5, relu_inner=True, out=y)
-            x = self.layer1[1].run(self.layer1[0].run(x, ws), ws)
         else:
+            ws = None
             x = _conv_inorm(img_cl, w1, 7, 2, 3, relu=True)
-            x = self.layer1[1].run(self.layer1[0].run(x))
-        for layer in (self.layer2, self.layer3):
-            x = layer[1].run(layer[0].run(x))
+        for layer in (self.layer1, self.layer2, self.layer3):
+            x = layer[1].run(layer[0].run(x, ws), ws)
         return ops.gemm(x, w2, bias=b2)
 
     def forward(self, x):

@@ -923,32 +923,33 @@ def conv3x3_halo_eligible(B, H, W, Cin, Cout):
 
 
 def conv3x3_halo_pack(w):
-    """pack_conv's [Cout, 3 * 3 * Cin] bf16 (Cout = Cin = 64) -> the MFMA-fragment order of emip_conv3x3_halo:
+    """pack_conv's [C, 3 * 3 * C] bf16 (C = 64 / 96 / 128) -> the MFMA-fragment order of emip_conv3x3_halo:
     [tap][d][ks][lane][e] = w[32 d + lane % 32][tap][16 ks + 8 (lane // 32) + e]"""
-    assert w.dtype == torch.bfloat16 and w.shape == (64, 576)
-    v = w.view(2, 32, 9, 4, 2, 8)                     # [d][row][tap][ks][half][e]
+    C = w.shape[0]
+    assert w.dtype == torch.bfloat16 and w.shape == (C, 9 * C) and C in (64, 96, 128)
+    v = w.view(C // 32, 32, 9, C // 16, 2, 8)         # [d][row][tap][ks][half][e]
     return v.permute(2, 0, 3, 4, 1, 5).contiguous().view(-1)     # [tap][d][ks][half][row][e]: lane = 32 half + row
 
 
-def conv3x3_halo_ws_bytes(B, H, W):
-    return int(_lib.load().emip_conv3x3_halo_ws_bytes(B, H, W))
+def conv3x3_halo_ws_bytes(B, H, W, C=64):
+    return int(_lib.load().emip_conv3x3_halo_ws_bytes(B, H, W, C))
 
 
-def conv3x3_halo_ws(B, H, W, device):
+def conv3x3_halo_ws(B, H, W, device, C=64):
     """zeroed statistics workspace of emip_conv3x3_halo (allocate OUTSIDE the timed path: launches leave the tickets zero)"""
-    return torch.zeros(int(_lib.load().emip_conv3x3_halo_ws_bytes(B, H, W)), dtype=torch.uint8, device=device)
+    return torch.zeros(conv3x3_halo_ws_bytes(B, H, W, C), dtype=torch.uint8, device=device)
 
 
 def conv3x3_halo(x, wp, out=None, in_sums=None, in_eps=1e-5, out_sums=None, ws=None):
-    """y = conv3x3(relu(instance_norm(x)) if in_sums is given else x), stride 1, pad 1, 64 -> 64, bf16 channels-last;
-    out_sums f64 [B, 64, 2] receives (sum, sum of squares) of y per image and channel (needs ws)"""
+    """y = conv3x3(relu(instance_norm(x)) if in_sums is given else x), stride 1, pad 1, C -> C, bf16 channels-last;
+    out_sums f64 [B, C, 2] receives (sum, sum of squares) of y per image and channel (needs ws)"""
     B, H, W, C = x.shape
     assert x.dtype == torch.bfloat16 and x.stride(-1) == 1 and x.stride(1) == W * x.stride(2) and (B == 1 or x.stride(0) == H * x.stride(1))
     if out is None:
-        out = torch.empty((B, H, W, 64), dtype=x.dtype, device=x.device)
+        out = torch.empty((B, H, W, C), dtype=x.dtype, device=x.device)
     for t in (in_sums, out_sums):
-        assert t is None or (t.dtype == torch.float64 and t.is_contiguous() and t.numel() == B * 64 * 2)
-    _lib.call("emip_conv3x3_halo", _p(x), x.stride(2), _p(wp), _p(out), out.stride(2), B, H, W, C, 64, _p(in_sums), float(in_eps),
+        assert t is None or (t.dtype == torch.float64 and t.is_contiguous() and t.numel() == B * C * 2)
+    _lib.call("emip_conv3x3_halo", _p(x), x.stride(2), _p(wp), _p(out), out.stride(2), B, H, W, C, C, _p(in_sums), float(in_eps),
               _p(out_sums), _p(ws), _nbytes(ws), _stream())
     return out
 

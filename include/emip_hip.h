@@ -754,20 +754,23 @@ int emip_mlp_band_stage_bytes(void);
 int emip_mlp_band(const void* X, long ldx, const void* Wst, const float* taps, const float* b2, const float* ln_stats,
                   float eps, void* Out, long ldo, float* out_stats, int B, int H, int W, int C, int N, int bands, void* stream);
 
-/* 3 x 3 convolution of the GMFlow CNN encoder's first level (stride 1, zero padding 1, no bias, 64 -> 64 channels, bf16
- * channels-last) as a DIRECT convolution on an LDS-resident halo tile, fused with the InstanceNorm2d around it
+/* 3 x 3 convolutions of the GMFlow CNN encoder's residual blocks (stride 1, zero padding 1, no bias, C -> C channels, bf16
+ * channels-last) as DIRECT convolutions on an LDS-resident halo tile, fused with the InstanceNorm2d around them
  * (gmflow/backbone.py:39-69 ResidualBlock: conv1 -> norm1 -> relu -> conv2 -> norm2 -> relu; :154-192 CNNEncoder):
- *   Y = conv3x3(f(X)),  f = identity (in_sums NULL) or relu((X - mean) rstd) per (image, channel) from in_sums f64 [B][64][2] =
+ *   Y = conv3x3(f(X)),  f = identity (in_sums NULL) or relu((X - mean) rstd) per (image, channel) from in_sums f64 [B][C][2] =
  *   (sum, sum of squares) over the image (biased variance, in_eps) -- the reference's norm1 + relu applied while the input tile
  *   is staged, zero padding applied AFTER it as in the reference;
- *   out_sums f64 [B][64][2] (may be NULL): the same sums of the stored (bf16-rounded) Y, taken in the epilogue: tile partials
- *   in ws, combined in tile order by the workgroup that finishes an image's last tile (no atomics on the sums, reproducible).
- * X, Y: [B, H, W, 64] with row strides ldx, ldy (elements); H, W multiples of 16; Wp: emip_conv3x3_halo_pack_bytes() bytes, the
- * weights in MFMA-fragment order [tap][2][4][64 lanes][8] (emip_amd/ops.py: conv3x3_halo_pack); ws: emip_conv3x3_halo_ws_bytes
- * bytes, 64-byte aligned, its first 4 B bytes zero before the first use, not shared by launches that may run at once. */
+ *   out_sums f64 [B][C][2] (may be NULL): the same sums of the stored (bf16-rounded) Y, taken in the epilogue: one partial per
+ *   (image, workgroup) in ws, combined in workgroup order by the workgroup that finishes an image's last tile (no atomics on
+ *   the sums, reproducible).
+ * Shapes: C = 64 with H, W multiples of 16 (all nine taps' weights resident in LDS, 16 x 16 tiles), or C = 64 / 96 / 128 with H
+ * a multiple of 11 and W of 22 (weights streamed per tap, 11 x 22 tiles: 176, 88 and 44 qualify).  X, Y: [B, H, W, C] with row
+ * strides ldx, ldy (elements); Wp: emip_conv3x3_halo_pack_bytes(C) bytes, the weights in MFMA-fragment order
+ * [tap][C / 32][C / 16][64 lanes][8] (emip_amd/ops.py: conv3x3_halo_pack); ws: emip_conv3x3_halo_ws_bytes bytes, 64-byte aligned,
+ * its first 4 B bytes zero before the first use, not shared by launches that may run at once. */
 int emip_conv3x3_halo_eligible(int B, int H, int W, int Cin, int Cout);
-int emip_conv3x3_halo_pack_bytes(void);
-long emip_conv3x3_halo_ws_bytes(int B, int H, int W);
+int emip_conv3x3_halo_pack_bytes(int C);
+long emip_conv3x3_halo_ws_bytes(int B, int H, int W, int C);
 int emip_conv3x3_halo(const void* X, long ldx, const void* Wp, void* Y, long ldy, int B, int H, int W, int Cin, int Cout,
                       const double* in_sums, float in_eps, double* out_sums, void* ws, long ws_bytes, void* stream);
 

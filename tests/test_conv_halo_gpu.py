@@ -7,29 +7,32 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _setup(B, H, W, seed):
+def _setup(B, H, W, seed, C=64):
     g = torch.Generator(device="cuda").manual_seed(seed)
-    x = (torch.randn(B, H, W, 64, device="cuda", generator=g) * 1.5 + 0.3).to(torch.bfloat16)
-    w = (torch.randn(64, 64, 3, 3, device="cuda", generator=g) / 24.0)
-    wp = w.permute(0, 2, 3, 1).reshape(64, -1).to(torch.bfloat16).contiguous()        # pack_conv layout [Cout][kh][kw][Cin]
+    x = (torch.randn(B, H, W, C, device="cuda", generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    w = (torch.randn(C, C, 3, 3, device="cuda", generator=g) / (3.0 * C ** 0.5))
+    wp = w.permute(0, 2, 3, 1).reshape(C, -1).to(torch.bfloat16).contiguous()         # pack_conv layout [Cout][kh][kw][Cin]
     return x, w, wp
 
 
 def _ref_conv(xf, wp):
-    w = wp.float().view(64, 3, 3, 64).permute(0, 3, 1, 2)
+    C = wp.shape[0]
+    w = wp.float().view(C, 3, 3, C).permute(0, 3, 1, 2)
     return torch.nn.functional.conv2d(xf.permute(0, 3, 1, 2), w, padding=1).permute(0, 2, 3, 1)
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 176, 176), (3, 32, 48), (1, 16, 16)])
-def test_plain_conv_and_statistics(B, H, W):
+# (64 channels, multiples of 16: weights resident; multiples of 11 x 22: the streamed form, also for 96 and 128 channels)
+@pytest.mark.parametrize("B,H,W,C", [(2, 176, 176, 64), (3, 32, 48, 64), (1, 16, 16, 64), (2, 33, 44, 64), (2, 88, 88, 96), (3, 22, 44, 96),
+                                     (2, 44, 44, 128), (9, 44, 44, 128), (1, 11, 22, 128)])
+def test_plain_conv_and_statistics(B, H, W, C):
     from emip_amd import ops
-    assert ops.conv3x3_halo_eligible(B, H, W, 64, 64) and not ops.conv3x3_halo_eligible(B, H, W + 8, 64, 64)
-    x, w, wp = _setup(B, H, W, 5 + B)
+    assert ops.conv3x3_halo_eligible(B, H, W, C, C) and not ops.conv3x3_halo_eligible(B, H, W + 8, C, C)
+    x, w, wp = _setup(B, H, W, 5 + B, C)
     pk = ops.conv3x3_halo_pack(wp)
-    ws = ops.conv3x3_halo_ws(B, H, W, x.device)
+    ws = ops.conv3x3_halo_ws(B, H, W, x.device, C)
     outs = []
     for _ in range(2):
-        sums = torch.full((B, 64, 2), -1.0, dtype=torch.float64, device="cuda")
+        sums = torch.full((B, C, 2), -1.0, dtype=torch.float64, device="cuda")
         y = ops.conv3x3_halo(x, pk, out_sums=sums, ws=ws)
         outs.append((y, sums))
     y0 = ops.conv3x3_halo(x, pk)                                     # the instance without statistics
@@ -45,17 +48,17 @@ def test_plain_conv_and_statistics(B, H, W):
     yf = y.double()
     s_ref = torch.stack((yf.sum((1, 2)), (yf * yf).sum((1, 2))), -1)
     es = ((sums - s_ref).abs() / (s_ref.abs() + 1.0)).max().item()
-    print(f"  {B}x{H}x{W}: max |d| vs PyTorch {err:.4f} on values up to {top:.1f}; vs the implicit-GEMM conv {d_old:.4f}; sums rel {es:.1e}")
+    print(f"  {B}x{H}x{W}x{C}: max |d| vs PyTorch {err:.4f} on values up to {top:.1f}; vs the implicit-GEMM conv {d_old:.4f}; sums rel {es:.1e}")
     assert err < 6e-3 * top and d_old <= 2.0 ** -7 * top and es < 1e-5
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 176, 176), (2, 48, 32)])
-def test_normalise_on_staging_equals_the_separate_passes(B, H, W):
+@pytest.mark.parametrize("B,H,W,C", [(2, 176, 176, 64), (2, 48, 32, 64), (2, 88, 88, 96), (5, 44, 44, 128), (2, 22, 22, 64)])
+def test_normalise_on_staging_equals_the_separate_passes(B, H, W, C):
     """conv(relu(instance_norm(x))): in_sums from the producer's statistics; the zero padding applies to the NORMALISED tensor"""
     from emip_amd import ops
-    x, w, wp = _setup(B, H, W, 11)
+    x, w, wp = _setup(B, H, W, 11, C)
     pk = ops.conv3x3_halo_pack(wp)
-    sums = torch.zeros((B, 64, 2), dtype=torch.float64, device="cuda")
+    sums = torch.zeros((B, C, 2), dtype=torch.float64, device="cuda")
     ops.chan_stats(x, B, sums=sums)
     y = ops.conv3x3_halo(x, pk, in_sums=sums, in_eps=1e-5)
     xn = ops.chan_norm_apply(x.clone(), sums, B, 1e-5, relu_inner=True)            # what the separate pass stores (bf16)
@@ -67,5 +70,5 @@ def test_normalise_on_staging_equals_the_separate_passes(B, H, W):
     torch.cuda.synchronize()
     top = ref.abs().max().item()
     err, d_old = (y.float() - ref).abs().max().item(), (y.float() - old.float()).abs().max().item()
-    print(f"  {B}x{H}x{W}: max |d| vs PyTorch {err:.4f}, vs apply + conv {d_old:.4f} on values up to {top:.1f}")
+    print(f"  {B}x{H}x{W}x{C}: max |d| vs PyTorch {err:.4f}, vs apply + conv {d_old:.4f} on values up to {top:.1f}")
     assert err < 1.2e-2 * top and d_old < 1.2e-2 * top
