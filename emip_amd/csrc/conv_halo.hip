@@ -129,25 +129,30 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ChArgs p) {
                 *reinterpret_cast<float2*>(red + 2 * tid) = make_float2(mu, rsqrtf(var + p.in_eps));
             }
             __syncthreads();
-            for (int s2 = tid; s2 < CH_HPX * 8; s2 += 512) {
-                const int P = s2 >> 3;
-                const int hy = P / CH_HS, hx = P - hy * CH_HS;
-                const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-                if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;
-                const int c = (s2 & 7) ^ ((P >> 1) & 7);
-                const ch_u32x4 v = *reinterpret_cast<const ch_u32x4*>(hb + s2 * 16);
-                unsigned vw[4] = {v.x, v.y, v.z, v.w};
+            {
+                // a thread keeps ONE logical chunk (8 channels: their mean / rstd in registers) and walks the pixels
+                const int c = tid & 7;
+                float mr[16];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 mr = *reinterpret_cast<const float4*>(red + 2 * (8 * c + 2 * j));      // (mean, rstd) of two channels
-                    const float x0 = fmaxf((__uint_as_float(vw[j] << 16) - mr.x) * mr.y, 0.f);
-                    const float x1 = fmaxf((__uint_as_float(vw[j] & 0xFFFF0000u) - mr.z) * mr.w, 0.f);
-                    ch_bf16x2 o;
-                    o[0] = (bf16_t)x0;
-                    o[1] = (bf16_t)x1;
-                    vw[j] = __builtin_bit_cast(unsigned, o);
+                for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(mr + 4 * j) = *reinterpret_cast<const float4*>(red + 16 * c + 4 * j);
+                for (int P = tid >> 3; P < CH_HPX; P += 64) {
+                    const int hy = P / CH_HS, hx = P - hy * CH_HS;
+                    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+                    if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;
+                    char* sp = hb + P * 128 + ((c ^ ((P >> 1) & 7)) * 16);
+                    const ch_u32x4 v = *reinterpret_cast<const ch_u32x4*>(sp);
+                    unsigned vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float x0 = fmaxf((__uint_as_float(vw[j] << 16) - mr[4 * j]) * mr[4 * j + 1], 0.f);
+                        const float x1 = fmaxf((__uint_as_float(vw[j] & 0xFFFF0000u) - mr[4 * j + 2]) * mr[4 * j + 3], 0.f);
+                        ch_bf16x2 o;
+                        o[0] = (bf16_t)x0;
+                        o[1] = (bf16_t)x1;
+                        vw[j] = __builtin_bit_cast(unsigned, o);
+                    }
+                    *reinterpret_cast<ch_u32x4*>(sp) = ch_u32x4{vw[0], vw[1], vw[2], vw[3]};
                 }
-                *reinterpret_cast<ch_u32x4*>(hb + s2 * 16) = ch_u32x4{vw[0], vw[1], vw[2], vw[3]};
             }
             __syncthreads();
         }
@@ -374,25 +379,31 @@ __global__ __launch_bounds__(512) void conv_halo_stream_kernel(const ChArgs p) {
                     *reinterpret_cast<float2*>(tab + 2 * tid) = make_float2(mu, rsqrtf(var + p.in_eps));
                 }
                 __syncthreads();
-                for (int s2 = tid; s2 < CS_HPX * Gm::NCH; s2 += 512) {
-                    const int P = s2 / Gm::NCH, cp = s2 - P * Gm::NCH;
-                    const int hy = P / CS_HX, hx = P - hy * CS_HX;
-                    const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
-                    if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;
-                    const int c = cp ^ Gm::swz(P);
-                    const ch_u32x4 v = *reinterpret_cast<const ch_u32x4*>(hb + s2 * 16);
-                    unsigned vw[4] = {v.x, v.y, v.z, v.w};
+                {
+                    // a thread keeps ONE logical chunk (its 8 channels' mean / rstd in registers) and walks the pixels
+                    constexpr int PPT = 512 / Gm::NCH;                   // pixels per sweep (threads beyond PPT * NCH idle)
+                    const int c = tid % Gm::NCH, pr = tid / Gm::NCH;
+                    float mr[16];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float4 mr = *reinterpret_cast<const float4*>(tab + 2 * (8 * c + 2 * j));
-                        const float x0 = fmaxf((__uint_as_float(vw[j] << 16) - mr.x) * mr.y, 0.f);
-                        const float x1 = fmaxf((__uint_as_float(vw[j] & 0xFFFF0000u) - mr.z) * mr.w, 0.f);
-                        ch_bf16x2 o;
-                        o[0] = (bf16_t)x0;
-                        o[1] = (bf16_t)x1;
-                        vw[j] = __builtin_bit_cast(unsigned, o);
+                    for (int j = 0; j < 4; ++j) *reinterpret_cast<float4*>(mr + 4 * j) = *reinterpret_cast<const float4*>(tab + 16 * c + 4 * j);
+                    for (int P = pr; P < CS_HPX && pr < PPT; P += PPT) {
+                        const int hy = P / CS_HX, hx = P - hy * CS_HX;
+                        const int gy = ty0 - 1 + hy, gx = tx0 - 1 + hx;
+                        if ((unsigned)gy >= (unsigned)p.H || (unsigned)gx >= (unsigned)p.W) continue;
+                        char* sp = hb + P * Gm::CB + ((c ^ Gm::swz(P)) * 16);
+                        const ch_u32x4 v = *reinterpret_cast<const ch_u32x4*>(sp);
+                        unsigned vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float x0 = fmaxf((__uint_as_float(vw[j] << 16) - mr[4 * j]) * mr[4 * j + 1], 0.f);
+                            const float x1 = fmaxf((__uint_as_float(vw[j] & 0xFFFF0000u) - mr[4 * j + 2]) * mr[4 * j + 3], 0.f);
+                            ch_bf16x2 o;
+                            o[0] = (bf16_t)x0;
+                            o[1] = (bf16_t)x1;
+                            vw[j] = __builtin_bit_cast(unsigned, o);
+                        }
+                        *reinterpret_cast<ch_u32x4*>(sp) = ch_u32x4{vw[0], vw[1], vw[2], vw[3]};
                     }
-                    *reinterpret_cast<ch_u32x4*>(hb + s2 * 16) = ch_u32x4{vw[0], vw[1], vw[2], vw[3]};
                 }
                 __syncthreads();
             }

@@ -53,16 +53,21 @@ __global__ __launch_bounds__(256) void sra_kernel(const SraArgs p) {
 
     const int nblk = (p.Lq + 31) >> 5;
     const int b_lo = (int)((long)split * nblk / p.splits), b_hi = (int)((long)(split + 1) * nblk / p.splits);
-    auto load_q = [&](int blk, uint4 (&qs)[4]) {           // rows beyond Lq: clamped (computed, never stored)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const long qr = min(blk * 32 + srow + 8 * j, p.Lq - 1);
-            qs[j] = *reinterpret_cast<const uint4*>(Qp + qr * p.C + sch * 8);
-        }
-    };
-    uint4 qs[4];
+    // (four named registers, not an array handed to a lambda: round 3's form kept the array in a private segment, 80 bytes of
+    // scratch per lane)
+    uint4 qs0, qs1, qs2, qs3;
+    qs0 = qs1 = qs2 = qs3 = make_uint4(0u, 0u, 0u, 0u);
+#define SRA_LOAD_Q(b)                                                                                              \
+    do {               /* rows beyond Lq: clamped (computed, never stored) */                                      \
+        const long r0_ = min((b) * 32 + srow, p.Lq - 1), r1_ = min((b) * 32 + srow + 8, p.Lq - 1);                  \
+        const long r2_ = min((b) * 32 + srow + 16, p.Lq - 1), r3_ = min((b) * 32 + srow + 24, p.Lq - 1);            \
+        qs0 = *reinterpret_cast<const uint4*>(Qp + r0_ * p.C + sch * 8);                                           \
+        qs1 = *reinterpret_cast<const uint4*>(Qp + r1_ * p.C + sch * 8);                                           \
+        qs2 = *reinterpret_cast<const uint4*>(Qp + r2_ * p.C + sch * 8);                                           \
+        qs3 = *reinterpret_cast<const uint4*>(Qp + r3_ * p.C + sch * 8);                                           \
+    } while (0)
     int blk = b_lo + wave;
-    if (blk < b_hi) load_q(blk, qs);                       // in flight while K / V are staged
+    if (blk < b_hi) SRA_LOAD_Q(blk);                       // in flight while K / V are staged
 
     // ---- K, V -> LDS in full 128-byte lines (rows >= Lk are zero), then K -> registers in MFMA A-operand form
 #pragma unroll
@@ -83,9 +88,11 @@ __global__ __launch_bounds__(256) void sra_kernel(const SraArgs p) {
     const int i16 = lane & 15, g16 = (lane >> 4) & 1;
     for (; blk < b_hi; blk += 4) {
         // ---- this block's Q rows: registers -> the wave's staging image -> B-operand fragments; next block's rows in flight
-#pragma unroll
-        for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(st_ + r_off128(srow + 8 * j, sch)) = qs[j];
-        if (blk + 4 < b_hi) load_q(blk + 4, qs);
+        *reinterpret_cast<uint4*>(st_ + r_off128(srow, sch)) = qs0;
+        *reinterpret_cast<uint4*>(st_ + r_off128(srow + 8, sch)) = qs1;
+        *reinterpret_cast<uint4*>(st_ + r_off128(srow + 16, sch)) = qs2;
+        *reinterpret_cast<uint4*>(st_ + r_off128(srow + 24, sch)) = qs3;
+        if (blk + 4 < b_hi) SRA_LOAD_Q(blk + 4);
         uint4 qf[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) qf[i] = *reinterpret_cast<const uint4*>(st_ + r_off128(lq, 2 * i + h));
