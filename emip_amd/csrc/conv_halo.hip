@@ -107,6 +107,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ChArgs p) {
     const int oy = 2 * wave + (px >> 4), ox = px & 15;
     const int P00 = oy * CH_HS + ox;
     float run1 = 0.f, run2 = 0.f;            // STATS: thread (channel tid & 63, eighth tid >> 6 of every tile) over this image's tiles
+    int tab_img = -1;                        // NORM: the image whose (mean, rstd) table is in LDS
 
     int buf = 0;
     for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
@@ -121,14 +122,15 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ChArgs p) {
         if (NORM) {
             // the image's (mean, rstd) per input channel -> LDS, then in place: relu((x - mean) * rstd) on the 16-byte slots of
             // pixels inside the image (2 592 slots; pixels outside stay zero: the reference pads the NORMALISED tensor)
-            if (tid < CH_C) {
+            if (img != tab_img && tid < CH_C) {          // (a workgroup's tiles lie in one or two images: two or three table builds)
                 const double* sm = p.in_sums + ((long)img * CH_C + tid) * 2;
                 const double n = (double)p.H * (double)p.W;
                 const float mu = (float)(sm[0] / n);
                 const float var = fmaxf((float)(sm[1] / n) - mu * mu, 0.f);
                 *reinterpret_cast<float2*>(red + 2 * tid) = make_float2(mu, rsqrtf(var + p.in_eps));
             }
-            __syncthreads();
+            if (img != tab_img) __syncthreads();
+            tab_img = img;
             {
                 // a thread keeps ONE logical chunk (8 channels: their mean / rstd in registers) and walks the pixels
                 const int c = tid & 7;
@@ -226,6 +228,7 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ChArgs p) {
                 const int lo = img * per_img, b0 = owner(lo), nb = owner(lo + per_img - 1) - b0 + 1;
                 *reinterpret_cast<float2*>(red + (part * CH_C + ch) * 2) = make_float2(run1, run2);
                 run1 = run2 = 0.f;
+                tab_img = -1;                                  // (the scratch held the NORM table)
                 __syncthreads();
                 float* pp = p.part + ((long)img * per_img) * CH_C * 2;                 // [<= per_img contributions][64][2]
                 if (tid < 2 * CH_C) {
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(512) void conv_halo_stream_kernel(const ChArgs p) {
     const int P00 = oy * CS_HX + ox;
     float run1 = 0.f, run2 = 0.f;
     float* tab = reinterpret_cast<float*>(smem + Gm::OFF_S);            // NORM: [C][2] (mean, rstd); publish: the ticket at tab[0]
+    int tab_img = -1;
 
     int buf = 0;
     int wslot = 0;                                                      // ring slot of the tap about to be used
@@ -371,14 +375,15 @@ __global__ __launch_bounds__(512) void conv_halo_stream_kernel(const ChArgs p) {
             else issue_w(0, wslot ^ 1);                                  // (nothing follows: harmless, keeps the counts)
             if (Gm::DBL && tap < 8) issue_h(t + 1 < t_end ? t + 1 : ntiles, buf ^ 1, wave + 8 * tap);
             if (NORM && tap == 0) {
-                if (tid < C) {
+                if (img != tab_img && tid < C) {
                     const double* sm = p.in_sums + ((long)img * C + tid) * 2;
                     const double n = (double)p.H * (double)p.W;
                     const float mu = (float)(sm[0] / n);
                     const float var = fmaxf((float)(sm[1] / n) - mu * mu, 0.f);
                     *reinterpret_cast<float2*>(tab + 2 * tid) = make_float2(mu, rsqrtf(var + p.in_eps));
                 }
-                __syncthreads();
+                if (img != tab_img) __syncthreads();
+                tab_img = img;
                 {
                     // a thread keeps ONE logical chunk (its 8 channels' mean / rstd in registers) and walks the pixels
                     constexpr int PPT = 512 / Gm::NCH;                   // pixels per sweep (threads beyond PPT * NCH idle)
@@ -476,6 +481,7 @@ __global__ __launch_bounds__(512) void conv_halo_stream_kernel(const ChArgs p) {
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __syncthreads();
                 unsigned* tick = reinterpret_cast<unsigned*>(tab);
+                tab_img = -1;                                              // (the ticket overwrites the table's first word)
                 if (tid == 0) *tick = atomicAdd(p.cnt + img, 1u);
                 __syncthreads();
                 if (*tick == (unsigned)(nb - 1)) {

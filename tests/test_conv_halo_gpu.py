@@ -23,7 +23,8 @@ def _ref_conv(xf, wp):
 
 # (64 channels, multiples of 16: weights resident; multiples of 11 x 22: the streamed form, also for 96 and 128 channels)
 @pytest.mark.parametrize("B,H,W,C", [(2, 176, 176, 64), (3, 32, 48, 64), (1, 16, 16, 64), (2, 33, 44, 64), (2, 88, 88, 96), (3, 22, 44, 96),
-                                     (2, 44, 44, 128), (9, 44, 44, 128), (1, 11, 22, 128)])
+                                     (2, 44, 44, 128), (9, 44, 44, 128), (1, 11, 22, 128),
+                                     (70, 32, 32, 64), (70, 22, 44, 96), (35, 22, 88, 128)])       # more tiles than workgroups: ranges cross images
 def test_plain_conv_and_statistics(B, H, W, C):
     from emip_amd import ops
     assert ops.conv3x3_halo_eligible(B, H, W, C, C) and not ops.conv3x3_halo_eligible(B, H, W + 8, C, C)
@@ -52,7 +53,8 @@ def test_plain_conv_and_statistics(B, H, W, C):
     assert err < 6e-3 * top and d_old <= 2.0 ** -7 * top and es < 1e-5
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 176, 176, 64), (2, 48, 32, 64), (2, 88, 88, 96), (5, 44, 44, 128), (2, 22, 22, 64)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 176, 176, 64), (2, 48, 32, 64), (2, 88, 88, 96), (5, 44, 44, 128), (2, 22, 22, 64),
+                                     (70, 32, 32, 64), (70, 22, 44, 96), (35, 22, 88, 128)])
 def test_normalise_on_staging_equals_the_separate_passes(B, H, W, C):
     """conv(relu(instance_norm(x))): in_sums from the producer's statistics; the zero padding applies to the NORMALISED tensor"""
     from emip_amd import ops
