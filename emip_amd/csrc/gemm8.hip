@@ -716,6 +716,7 @@ const Cfg g_cfg[] = {
     G8_CFG_LNT(128, 64, 4, 2, 3),    // 8: wave 32 x 32, 72 KB (2 per CU)
     G8_CFG_LNT(64, 128, 2, 4, 3),    // 9: wave 32 x 32, 72 KB (2 per CU)
     G8_CFG_LNTW(64, 320, 2, 4, 3, 3),  // 10: wave 32 x 80, 144 KB; per-tap LayerNorm 155 KB
+    G8_CFG_LNTW(64, 192, 2, 4, 3, 4),  // 11: wave 32 x 48; N = 320 in two tiles (192 + 128), per-tap LayerNorm ring 4 deep (139 KB)
 };
 constexpr int NCFG = sizeof(g_cfg) / sizeof(g_cfg[0]);
 

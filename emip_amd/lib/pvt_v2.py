@@ -43,7 +43,9 @@ SRA_FUSED = True
 # row statistics of the proj / fc2 GEMMs whose rows span more than two column tiles (N = 320 on 128-wide tiles) combined inside
 # the launch by the last column tile to finish (emip_gemm_ln_ws) instead of a row_stats launch behind it
 STATS_IN_LAUNCH = True
-SR_WIDE_TILE = True         # the spatial-reduction conv of the 22 x 22 stage on ONE 64 x 320 tile per 64 rows (gemm8 configuration 10)
+SR_WIDE_TILE = 192          # the spatial-reduction conv of the 22 x 22 stage on wide tiles: True = ONE 64 x 320 tile per 64 rows (gemm8 configuration
+                            # 10, ring 3 deep), 192 = two tiles of 64 x 192 (configuration 11, ring 4 deep: round 4, 11.07 -> 10.75 ms one step at a
+                            # time, 2439 / 2436 pairs/s in flight), False = 64 x 128 tiles
 FC1DW_BAND_MIN_ROWS = 3     # banded fc1 + depthwise launch for maps of > 512 tokens when a band has at least this many output rows (0: off;
                             # in-call at 16 pairs: off 1592, the 44 x 44 stage only 1618, the 88 x 88 stage too 1628 pairs/s)
 MLP_BLOCK = False
@@ -282,9 +284,9 @@ class Block(EmipModule):
                 # that launch form keeps a tile's tap sums in LDS: one tile per workgroup, at most 256 tiles -- beyond (more than
                 # ~44 images at C = 320) the batch goes in image chunks
                 rows_img = (H // sr) * (W // sr)
-                wide = SR_WIDE_TILE and C == 320           # N = 320 in one 64 x 320 tile: the token panel is read once
-                scfg = 10 if wide else 0
-                per_tile, ntile_n = (128, 1) if C <= 64 else (64, 1 if wide else (C + 127) // 128)
+                wide = SR_WIDE_TILE and C == 320           # N = 320 in one 64 x 320 tile (or two of 192): the token panel is read once (twice)
+                scfg = (11 if SR_WIDE_TILE == 192 else 10) if wide else 0
+                per_tile, ntile_n = (128, 1) if C <= 64 else (64, (2 if SR_WIDE_TILE == 192 else 1) if wide else (C + 127) // 128)
                 per = max(1, ((256 // ntile_n) * per_tile) // rows_img)
                 if B <= per:
                     s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"],

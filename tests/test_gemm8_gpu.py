@@ -7,7 +7,7 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
-NCFG = 10
+NCFG = 11
 
 
 def dev():

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from emip_amd import _lib, ops  # noqa: E402
 
-NCFG = 10
+NCFG = 11
 
 
 def timeit(fn, iters=30):
