@@ -45,6 +45,25 @@ def test_library_exports_every_declared_symbol():
     assert lib.emip_version() >= 100
 
 
+def test_bench_knows_every_gemm8_tile():
+    """bench.py names a launch's kernel symbol from the library's tile table: a configuration added to gemm8.hip without its
+    wave layout in bench.WAVES used to stop the whole benchmark (round 4, configuration 11)"""
+    import bench
+    from emip_amd import _lib
+    lib = _lib.load()
+    cfg = 1
+    while lib.emip_gemm8_cfg_tile(cfg):
+        t = lib.emip_gemm8_cfg_tile(cfg)
+        assert (t // 1000, t % 1000) in bench.WAVES, (cfg, t)
+        assert bench._g8_key(lib, cfg, False, False).startswith("gemm8_kernel<%d, %d," % (t // 1000, t % 1000))
+        cfg += 1
+    assert cfg - 1 >= 11
+    assert lib.emip_conv3x3_halo_eligible(32, 176, 176, 64, 64) and lib.emip_conv3x3_halo_eligible(32, 88, 88, 96, 96)
+    assert not lib.emip_conv3x3_halo_eligible(32, 90, 88, 96, 96)
+    assert lib.emip_gemm_stats_ws_bytes(7744, 320) >= 4 * 121 + 7744 * 3 * 8
+    assert lib.emip_conv3x3_halo(None, 64, None, None, 64, 1, 16, 16, 64, 64, None, 0.0, None, None, 0, None) == -1
+
+
 def test_argument_checks_refuse_before_launch():
     """invalid shapes return EMIP_E_INVALID without touching the GPU (callable on a CPU-only box)."""
     from emip_amd import _lib
