@@ -123,6 +123,11 @@ def _launch_info(lib, name, a):
         if a[4]:                                            # raw scores (the correlation volume) written out
             byt += 2.0 * z * Lq * Lk
         return 2.0 * z * Lq * Lk * (D + dv), "attn_kernel<bf16,%d,%d,64>%s" % (D, DV, "+scores" if a[4] else ""), byt
+    if name == "emip_gemm8_batched":      # (A, W, C, bias, M, N, K, lda, ldw, ldc, act, batch, bsA, bsW, bsC, cfg, stream)
+        M, N, K, batch, cfg = a[4], a[5], a[6], a[11], a[15]
+        key = _g8_key(lib, cfg if cfg > 0 else lib.emip_gemm8_auto_cfg(min(M * batch, 1 << 30), N, K), False, False)
+        Kr = {1984: 1936}.get(K, K)       # (conv_corr.0's first factor: K = 1936 target pixels padded to the 64-wide K tile)
+        return 2.0 * M * N * Kr * batch, key, 2.0 * ((1 if a[12] == 0 else batch) * M * Kr + batch * (N * Kr + M * N))
     if name == "emip_gemm_ln_ws":         # emip_gemm_ln's arguments + (stats_ws, stats_ws_bytes) in front of the stream
         name, a = "emip_gemm_ln", tuple(a[:-3]) + (a[-1],)
     if name in ("emip_gemm", "emip_gemm_ln", "emip_gemm_lne"):

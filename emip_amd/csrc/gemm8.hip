@@ -17,6 +17,7 @@
 //     32-column block are PERMUTED when they are staged so that the two accumulators of the block give every lane 8
 //     consecutive channels: the epilogue stores 16 B per lane straight from registers (no LDS bounce), with bias /
 //     output-side LayerNorm / GELU / ReLU / residual / row statistics fused.
+#include <algorithm>
 #include "common.h"
 #include <stdlib.h>
 
@@ -80,6 +81,8 @@ struct G8Args {
     unsigned s_bytes;
     unsigned a_bytes, a2_bytes, w_bytes;            // descriptor extents (< 2^31)
     int tiles_m, tiles_n;
+    int tpb, ntiles;        // tiles per batch entry, tiles of the launch (batch * tpb)
+    long bsA, bsW, bsC;     // strided-batched dense launches: element strides between batch entries (bias shared; no R, no statistics)
 #ifdef EMIP_TUNING
     int dbg;      // ablations (tuning library only): 1 = no epilogue stores, 2 = no MFMA, 4 = no operand loads, 8 = return at entry
 #endif
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     // Persistent over output tiles: workgroup b works on tiles {round * G + remap(b)}; inside a round every XCD owns a
     // contiguous chunk of tile ids (tiles that share an A panel sit in one L2).  The stage ring runs on ACROSS tile
     // boundaries: the first K tiles of the next output tile are in flight while the current one is finished and stored.
-    const int ntiles = p.tiles_m * p.tiles_n;
+    const int ntiles = p.ntiles;
     const int G = gridDim.x;
     const int rounds = (ntiles - (int)blockIdx.x + G - 1) / G;
     auto tile_of = [&](int i) {
@@ -164,7 +167,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
     bool s_ok = false;
     const i32x4 rsS = make_rsrc(LNT ? (const void*)p.ln_stats : (const void*)p.A, LNT ? p.s_bytes : 0u);
     auto setup = [&](int t) {
-        const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+        const int bz = t / p.tpb, tr = t - bz * p.tpb;           // batch entry (0 unless strided-batched), tile inside it
+        const int m0 = (tr / p.tiles_n) * BM, n0 = (tr % p.tiles_n) * BN;
+        const unsigned boffA = (unsigned)(bz * p.bsA * 2), boffW = (unsigned)(bz * p.bsW * 2);
         if (LNT) {
             const int m = m0 + (sidx >> 1), hw = p.Ho * p.Wo;
             const int b = m / hw, rem = m - b * hw;
@@ -185,7 +190,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                 arow[j] = m < p.M ? 0u : OOB;
                 arow2[j] = 0u;
             } else {
-                arow[j] = m < p.M ? (unsigned)((long)m * p.lda * 2) + chunk * 16u : OOB;
+                arow[j] = m < p.M ? boffA + (unsigned)((long)m * p.lda * 2) + chunk * 16u : OOB;
                 arow2[j] = m < p.M ? (unsigned)((long)m * p.lda2 * 2) + chunk * 16u : OOB;
                 a_oy[j] = a_ox[j] = a_img[j] = 0;
             }
@@ -200,7 +205,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                 nl = (wi & ~31) + 8 * (i >> 2) + 4 * ((wi >> 4) & 1) + (i & 3);
             }
             const int n = n0 + wv * WTN + nl;
-            woff[j] = n < p.N ? (unsigned)((long)n * p.ldw * 2) + chunk * 16u : OOB;
+            woff[j] = n < p.N ? boffW + (unsigned)((long)n * p.ldw * 2) + chunk * 16u : OOB;
         }
     };
 
@@ -361,7 +366,9 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
         if (++kt < nk) continue;
         kt = 0;
         const int t = tile_of(ci++);
-        const int m0 = (t / p.tiles_n) * BM, n0 = (t % p.tiles_n) * BN;
+        const int bz = t / p.tpb, tr = t - bz * p.tpb;
+        const int m0 = (tr / p.tiles_n) * BM, n0 = (tr % p.tiles_n) * BN;
+        bf16_t* const Cb = p.C + bz * p.bsC;
 
         // ---- epilogue: registers -> HBM, 16 B per lane (32-column blocks outermost: 16 live bias / colsum registers) ----
         if (G8_DBG(p, 1) && acc[0][0][0] != 123456.f) {          // tuning build: skip the stores, keep the accumulators live
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                     for (int j = 0; j < 8; ++j) v[j] *= rsc[a];
                 }
                 if (m < p.M && n < p.N) {
-                    bf16_t* cp = p.C + (long)m * p.ldc + n;
+                    bf16_t* cp = Cb + (long)m * p.ldc + n;
                     if (vec_ok && n + 8 <= p.N) {
                         if (p.R) {
                             const uint4 rr = *reinterpret_cast<const uint4*>(p.R + (long)m * p.ldr + n);
@@ -525,7 +532,7 @@ __global__ __launch_bounds__(512) void gemm8_kernel(const G8Args p) {
                             if (RS) x *= rsc[a];
                             if (p.R) x += (float)p.R[(long)m * p.ldr + n + j];
                             const bf16_t o = (bf16_t)x;
-                            p.C[(long)m * p.ldc + n + j] = o;
+                            Cb[(long)m * p.ldc + n + j] = o;
                             st1[a] += (float)o;
                             st2[a] += (float)o * (float)o;
                         }
@@ -748,6 +755,10 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     const Cfg& g = g_cfg[cfg - 1];
     a.tiles_m = (a.M + g.bm - 1) / g.bm;
     a.tiles_n = (a.N + g.bn - 1) / g.bn;
+    const int nbatch = a.ntiles > 0 ? a.ntiles : 1;      // (the batched entry point passes its batch count here)
+    a.tpb = a.tiles_m * a.tiles_n;
+    a.ntiles = a.tpb * nbatch;
+    if (nbatch > 1 && (conv || a.R || a.out_stats || a.rowscale || a.lno_gamma || a.A2)) return EMIP_E_INVALID;
     size_t lds = (size_t)g.nst * (g.bm + g.bn) * 128;
     if (lnt) lds = (size_t)g.nst_lnt * ((g.bm + g.bn) * 128 + 2048) + (size_t)a.KH * a.KW * g.bn * 4;
     if (lds > 160 * 1024) return EMIP_E_INVALID;
@@ -793,7 +804,7 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     }
     // persistent grid: one workgroup per CU, two where LDS (<= 80 KB) and registers (<= 128, true of those tiles) allow
     const int per_cu = lds <= 80 * 1024 ? 2 : 1;
-    const int tiles = a.tiles_m * a.tiles_n;
+    const int tiles = a.ntiles;
     const int grid = tiles < 256 * per_cu ? tiles : 256 * per_cu;
     if (lnt && grid != tiles) return EMIP_E_INVALID;          // the tapsum slice in LDS belongs to ONE tile
     hipLaunchKernelGGL(fn, dim3(grid), dim3(512), lds, s, a);
@@ -854,6 +865,23 @@ extern "C" int emip_gemm8_dispatch(int M, int N, int K, long lda, long ldw, int 
 }
 extern "C" int emip_conv8_dispatch(int M, int Cout, int Cin, int KH, int KW, long a_elems) {
     return emip_internal::conv8_choice(M, Cout, Cin, KH, KW, a_elems);
+}
+
+// strided-batched dense GEMM on the 8-wave body: C[b] = act(A[b] W[b]^T + bias), b < batch, element strides bsA / bsW / bsC (0 = shared)
+extern "C" int emip_gemm8_batched(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, long lda, long ldw,
+                                  long ldc, int act, int batch, long bsA, long bsW, long bsC, int cfg, void* stream) {
+    EMIP_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0 && (K % 64) == 0 && batch > 0 && bsA >= 0 && bsW >= 0 && bsC >= 0);
+    EMIP_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C) && (lda % 8) == 0 && (ldw % 8) == 0 && lda >= K && ldw >= K && ldc >= N &&
+                 (bsA % 8) == 0 && (bsW % 8) == 0 && (bsC % 8) == 0);
+    const long ab = ((long)(batch - 1) * bsA + (long)(M - 1) * lda + K) * 2, wb = ((long)(batch - 1) * bsW + (long)(N - 1) * ldw + K) * 2;
+    EMIP_REQUIRE(ab < (1L << 31) && wb < (1L << 31));
+    G8Args a = {};
+    a.A = (const bf16_t*)A; a.W = (const bf16_t*)W; a.C = (bf16_t*)C; a.bias = bias; a.M = M; a.N = N; a.K = K; a.K1 = K; a.lda = lda;
+    a.ldw = ldw; a.ldc = ldc; a.act = act; a.a_bytes = (unsigned)ab; a.a2_bytes = 0; a.w_bytes = (unsigned)wb;
+    a.bsA = bsA; a.bsW = bsW; a.bsC = bsC; a.ntiles = batch;
+    // (the tile choice sees the whole batch's rows: 16 x 1 936 rows fill the chip with 128 x 128 tiles, one image would not)
+    if (cfg <= 0) cfg = pick_cfg((int)std::min<long>((long)M * batch, 1L << 30), N, K);
+    return launch(a, cfg, false, (hipStream_t)stream);
 }
 
 extern "C" int emip_gemm8(const void* A, const void* A2, const void* W, void* C, const float* bias, const void* R, int M,

@@ -31,6 +31,8 @@ STAGGER = True
 # eval mode: conv_corr.0 computed from the rank-128 factors of the correlation volume (run_conv_corr_factored: 8.6 instead of
 # 65 GFLOP per pair, no 7.5-MB volume per pair); False = the reference's literal order, the 3 x 3 conv over 1936 channels
 CONV_CORR_FACTORED = True
+# the two per-image GEMMs of the factored conv_corr.0 on the 8-wave body (emip_gemm8_batched) instead of the 4-wave strided-batched one
+CONV_CORR_GEMM8 = True
 # The reference runs the whole PVT backbone on BOTH frames (model.py:87-88) and then reads fea_2[0] only (:92; fea_1[1], fea_1[2]
 # feed the decoder, :99-100): stages 3 and 4 of the second frame -- 43 of the 52 blocks -- produce values nothing reads, in the
 # forward and (zero gradient) in the backward.  True: those stages run on the frame whose deep features are read (frame 1;
@@ -108,20 +110,30 @@ class CoUpdater(EmipModule):
         c0, bn, c3 = self.conv_corr[0], self.conv_corr[1], self.conv_corr[3]
         cout = c0.weight.shape[0]
 
+        g8 = CONV_CORR_GEMM8 and dt == torch.bfloat16 and (9 * C) % 64 == 0 and C % 8 == 0 and cout % 8 == 0
+        npad = (n + 63) // 64 * 64 if g8 else n      # the 8-wave body walks K in tiles of 64: the 1936 target pixels padded to 1984
+
         def build(cw, cb, *_):
             wf, bf = fold_bn(cw, cb, bn)                                         # [968, 1936, 3, 3] f32
             wr = (wf * C ** -0.5).permute(0, 2, 3, 1).reshape(cout * 9, n)       # rows (co, tap), columns q
+            if npad != n:
+                wr = torch.nn.functional.pad(wr, (0, npad - n))
             return wr.to(dt).contiguous(), bf
-        wr, b0 = self.packed("ccf", (c0.weight, c0.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var), build)
+        wr, b0 = self.packed("ccf%d" % npad, (c0.weight, c0.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var), build)
         w3, b3 = self.packed("cc3", (c3.weight, c3.bias), lambda a, b: (pack_conv(a, dt), f32(b)))
         f0, f1 = tokens[:B], tokens[B:]
-        f1t = ops.transpose_pad(f1, n)                                           # [B, C, n]
+        f1t = ops.transpose_pad(f1, npad)                                        # [B, C, n (padded with zeros)]
         g = torch.empty((B, cout * 9, C), dtype=dt, device=tokens.device)        # = per-image conv weights [968][(tap, d)]
-        ops.gemm_batched(wr, f1t, g, B, cout * 9, C, n, n, n, C, 0, C * n, cout * 9 * C)
         pm = ops.im2col3x3(f0.reshape(B, h, w, C))                               # [B, n, 9 C]
         y = torch.empty((B, h, w, cout), dtype=dt, device=tokens.device)
-        ops.gemm_batched_bias(pm, g, y, B, n, cout, 9 * C, 9 * C, 9 * C, cout, n * 9 * C, cout * 9 * C, n * cout,
+        if g8:
+            ops.gemm8_batched(wr, f1t, g, B, cout * 9, C, npad, npad, npad, C, 0, C * npad, cout * 9 * C)
+            ops.gemm8_batched(pm, g, y, B, n, cout, 9 * C, 9 * C, 9 * C, cout, n * 9 * C, cout * 9 * C, n * cout,
                               bias=b0, act=ops.ACT_RELU)
+        else:
+            ops.gemm_batched(wr, f1t, g, B, cout * 9, C, n, n, n, C, 0, C * n, cout * 9 * C)
+            ops.gemm_batched_bias(pm, g, y, B, n, cout, 9 * C, 9 * C, 9 * C, cout, n * 9 * C, cout * 9 * C, n * cout,
+                                  bias=b0, act=ops.ACT_RELU)
         return ops.conv2d(y, w3, 3, 3, 1, 1, bias=b3)
 
     def run_conv_corr_factored_train(self, tokens, h, w):

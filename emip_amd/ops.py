@@ -372,6 +372,15 @@ def gemm_batched_bias(a, w, out, batch, M, N, K, lda, ldw, ldc, bsA, bsW, bsC, b
     return out
 
 
+def gemm8_batched(a, w, out, batch, M, N, K, lda, ldw, ldc, bsA, bsW, bsC, bias=None, act=ACT_NONE, cfg=0):
+    """gemm_batched_bias on the 8-wave bf16 body (K % 64 == 0, strides multiples of 8)"""
+    _dev(a)
+    assert a.dtype == torch.bfloat16 and K % 64 == 0
+    _lib.call("emip_gemm8_batched", _p(a), _p(w), _p(out), _p(bias), M, N, K, lda, ldw, ldc, act, batch, bsA, bsW, bsC, int(cfg),
+              _stream())
+    return out
+
+
 def im2col3x3(x):
     """x [B,H,W,C] channels-last -> the 3 x 3 patch matrix [B, H*W, 9*C] (zero padding, tap-major columns)"""
     _dev(x)

@@ -87,6 +87,13 @@ int emip_gemm_lne(const void* A, const void* W, void* C, const float* bias, cons
                   long ldw, long ldc, long ldr, int act, const float* ln_stats, const float* colsum, float ln_eps,
                   float* out_stats, void* zero_ptr, long zero_bytes, int dtype, void* stream);
 
+/* Strided-batched dense GEMM on the 8-wave bf16 body: C[b] = act(A[b] W[b]^T + bias) for b < batch, element strides bsA / bsW /
+ * bsC between batch entries (0 = the operand is shared), bias f32 [N] shared; K % 64 == 0, strides and leading dimensions
+ * multiples of 8, every operand below 2 GB.  The two per-image GEMMs of conv_corr.0 through the correlation volume's rank-128
+ * factors (model/EMIP_short/model.py:59,96 with gmflow/matching.py:16-20): G[b] = W' F1[b] and out[b] = patches(F0[b]) G[b]^T. */
+int emip_gemm8_batched(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, long lda, long ldw, long ldc,
+                       int act, int batch, long bsA, long bsW, long bsC, int cfg, void* stream);
+
 /* The large-launch bf16 body of emip_gemm / emip_gemm_ln(e) / emip_conv2d (gemm8.hip): 8-wave workgroups, 64..256-row
  * output tiles, operands by LDS-DMA through a 2-3 stage ring, epilogue stored 16 B per lane from registers.  Same
  * arithmetic and the same hooks as above (bias, output-side LayerNorm from ln_stats + colsum, GELU / ReLU, residual R,

@@ -184,3 +184,22 @@ def test_gemm8_layernorm_on_output(M, N, K, res, bias):
         r2 = r.clone()
         ops.gemm_ln_out(a, w, gamma, beta, 1e-5, bias=b, res=r2, out=r2)
         assert torch.equal(r2, got)
+
+
+@pytest.mark.parametrize("batch,M,N,K,shared_a", [(16, 8712, 128, 1984, True), (16, 1936, 968, 1152, False), (3, 1000, 72, 64, False)])
+def test_strided_batched(batch, M, N, K, shared_a):
+    """emip_gemm8_batched (the two per-image GEMMs of the factored conv_corr.0) against torch.bmm in f32 and the 4-wave form"""
+    from emip_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(batch + M)
+    a = torch.randn(1 if shared_a else batch, M, K, device="cuda", generator=g).to(torch.bfloat16)
+    w = (torch.randn(batch, N, K, device="cuda", generator=g) / K ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(N, device="cuda", generator=g)
+    out = torch.full((batch, M, N), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.gemm8_batched(a, w, out, batch, M, N, K, K, K, N, 0 if shared_a else M * K, N * K, M * N, bias=bias, act=ops.ACT_RELU)
+    old = torch.empty_like(out)
+    ops.gemm_batched_bias(a, w, old, batch, M, N, K, K, K, N, 0 if shared_a else M * K, N * K, M * N, bias=bias, act=ops.ACT_RELU)
+    ref = torch.relu(torch.matmul(a.float(), w.float().transpose(1, 2)) + bias)
+    torch.cuda.synchronize()
+    top = ref.abs().max().item()
+    assert (out.float() - ref).abs().max().item() < 8e-3 * top
+    assert (out.float() - old.float()).abs().max().item() <= 2.0 ** -7 * top
