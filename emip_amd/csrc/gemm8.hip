@@ -851,7 +851,8 @@ int gemm8_choice(int M, int N, long K, long lda, long ldw, int K1, bool has_a2, 
     return pick_cfg(M, N, K);
 }
 int conv8_choice(int M, int Cout, int Cin, int KH, int KW, long a_elems) {
-    if (M < 2048 || Cout < 64 || Cin < 64 || (Cin % 8) != 0 || a_elems * 2 >= (1L << 31) ||
+    // (round 4: 1024, was 2048 -- with the deep PVT stages on one frame the 11 x 11-stage convolutions have 1 936 rows)
+    if (M < 1024 || Cout < 64 || Cin < 64 || (Cin % 8) != 0 || a_elems * 2 >= (1L << 31) ||
         (long)Cout * KH * KW * Cin * 2 >= (1L << 31))
         return 0;
     return pick_cfg(M, Cout, (long)KH * KW * Cin);
