@@ -279,12 +279,12 @@ __global__ __launch_bounds__(512) void conv_halo_kernel(const ChArgs p) {
 // 192 B: c ^ ((P >> 2) & 3), 256 B: c ^ (P & 15) -- each makes the 16 lanes of a b128 read cover the 64 banks.
 constexpr int CS_TH = 11, CS_TW = 22, CS_TPX = CS_TH * CS_TW, CS_HY = CS_TH + 2, CS_HX = CS_TW + 2, CS_HPX = CS_HY * CS_HX;   // 242, 13 x 24 = 312
 
-template <int C>
+template <int C, bool DBLP>
 struct CsGeo {
     static constexpr int NCH = C / 8, CB = 2 * C, NKS = C / 16, NCT = C / 32;
     static constexpr int TAPW = C * C * 2, NWI = (TAPW / 1024 + 7) / 8;              // weight DMA instructions per wave and tap
     static constexpr int HINS = (CS_HPX * NCH + 63) / 64, HALO = HINS * 1024;
-    static constexpr bool DBL = C <= 96;                                            // two halo buffers
+    static constexpr bool DBL = DBLP;                                               // two halo buffers (the next tile's halo rides along)
     static constexpr int OFF_W = (DBL ? 2 : 1) * HALO, OFF_S = OFF_W + 2 * TAPW;    // scratch: 1 KB table / ticket + 1 KB dump
     static constexpr int LDS = OFF_S + 2048;
     static constexpr int NP = 512 / C, PP = (CS_TPX + NP - 1) / NP;                 // statistics: parts of the tile, pixels per part
@@ -292,9 +292,9 @@ struct CsGeo {
     __device__ static __forceinline__ int swz(int P) { return C == 64 ? (P >> 1) & 7 : (C == 96 ? (P >> 2) & 3 : P & 15); }
 };
 
-template <int C, bool NORM, bool STATS>
+template <int C, bool NORM, bool STATS, bool DBLP>
 __global__ __launch_bounds__(512) void conv_halo_stream_kernel(const ChArgs p) {
-    typedef CsGeo<C> Gm;
+    typedef CsGeo<C, DBLP> Gm;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -511,19 +511,25 @@ __global__ __launch_bounds__(512) void conv_halo_stream_kernel(const ChArgs p) {
     }
 }
 
-template <int C>
-int launch_stream(const ChArgs& a, bool norm, bool stats, int grid, hipStream_t s) {
-    void (*fn)(const ChArgs) = norm ? (stats ? conv_halo_stream_kernel<C, true, true> : conv_halo_stream_kernel<C, true, false>)
-                                    : (stats ? conv_halo_stream_kernel<C, false, true> : conv_halo_stream_kernel<C, false, false>);
+template <int C, bool DBLP>
+int launch_stream(const ChArgs& a, bool norm, bool stats, int ntiles, hipStream_t s) {
+    void (*fn)(const ChArgs) = norm ? (stats ? conv_halo_stream_kernel<C, true, true, DBLP> : conv_halo_stream_kernel<C, true, false, DBLP>)
+                                    : (stats ? conv_halo_stream_kernel<C, false, true, DBLP> : conv_halo_stream_kernel<C, false, false, DBLP>);
     static bool attr[4] = {false, false, false, false};
     const int which = (norm ? 2 : 0) + (stats ? 1 : 0);
+    constexpr int lds = CsGeo<C, DBLP>::LDS;
     if (!attr[which]) {
-        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, CsGeo<C>::LDS) != hipSuccess) return EMIP_E_LAUNCH;
+        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return EMIP_E_LAUNCH;
         attr[which] = true;
     }
-    hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), CsGeo<C>::LDS, s, a);
+    const int slots = lds <= 80 * 1024 ? 512 : 256;                  // two workgroups per CU where the LDS allows
+    hipLaunchKernelGGL(fn, dim3((unsigned)(ntiles < slots ? ntiles : slots)), dim3(512), lds, s, a);
     return emip_launch_status();
 }
+
+#ifdef EMIP_TUNING
+int g_halo_mode = 0;     // 1: 64 channels on the streamed form (two halo buffers); 2: the same with ONE halo buffer, two workgroups per CU
+#endif
 
 }  // namespace
 
@@ -562,12 +568,20 @@ extern "C" int emip_conv3x3_halo(const void* X, long ldx, const void* Wp, void* 
         a.cnt = (unsigned*)ws;
         a.part = (float*)((char*)ws + (((long)B * 4 + 63) & ~63L));
     }
-    if (!ch_resident(H, W, C)) {
+    bool resident = ch_resident(H, W, C);
+#ifdef EMIP_TUNING
+    if (g_halo_mode && ch_stream(H, W, C)) resident = false;
+#endif
+    if (!resident) {
         a.tx = W / CS_TW; a.ty = H / CS_TH;
-        const int nt = B * a.tx * a.ty, gr = nt < 256 ? nt : 256;
-        if (C == 64) return launch_stream<64>(a, in_sums != nullptr, out_sums != nullptr, gr, (hipStream_t)stream);
-        if (C == 96) return launch_stream<96>(a, in_sums != nullptr, out_sums != nullptr, gr, (hipStream_t)stream);
-        return launch_stream<128>(a, in_sums != nullptr, out_sums != nullptr, gr, (hipStream_t)stream);
+        const int nt = B * a.tx * a.ty;
+        const bool nm = in_sums != nullptr, st = out_sums != nullptr;
+#ifdef EMIP_TUNING
+        if (C == 64 && g_halo_mode == 2) return launch_stream<64, false>(a, nm, st, nt, (hipStream_t)stream);
+#endif
+        if (C == 64) return launch_stream<64, true>(a, nm, st, nt, (hipStream_t)stream);
+        if (C == 96) return launch_stream<96, true>(a, nm, st, nt, (hipStream_t)stream);
+        return launch_stream<128, false>(a, nm, st, nt, (hipStream_t)stream);
     }
     a.tx = W / CH_T; a.ty = H / CH_T;
     const int ntiles = B * a.tx * a.ty;
@@ -583,3 +597,7 @@ extern "C" int emip_conv3x3_halo(const void* X, long ldx, const void* Wp, void* 
     hipLaunchKernelGGL(fn, dim3((unsigned)grid), dim3(512), CH_LDS, (hipStream_t)stream, a);
     return emip_launch_status();
 }
+
+#ifdef EMIP_TUNING
+extern "C" int emip_debug_set_halo(int mode) { g_halo_mode = mode; return 0; }
+#endif

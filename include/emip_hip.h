@@ -791,6 +791,7 @@ int emip_debug_set_lnb(int wide);               /* 0 = the narrow LayerNorm-back
 int emip_debug_set_dww(int chunks);             /* row chunks per image of the depthwise weight gradient (0 = auto) */
 int emip_debug_set_tn8(int ring_depth, int target_workgroups);   /* emip_gemm_tn8: 2..4 stages; 0 = heuristic split count */
 int emip_debug_set_wa(int flags);              /* emip_window_attention ablations: 1 no S MFMAs, 2 no softmax, 4 no PV, 8 no DMA */
+int emip_debug_set_halo(int mode);         /* emip_conv3x3_halo at 64 channels: 1 = the streamed-weights form, 2 = that with one halo buffer and two workgroups per CU */
 int emip_debug_set_md(int flags);              /* emip_mlp_band ablations: 1 no fc1 MFMAs, 2 no depthwise pass, 4 no fc2 MFMAs, 8 no weight DMA, 16 no H / G stores, 32 constant taps */
 int emip_debug_set_md_prof(void* buf);         /* emip_mlp_band: u64 [workgroups * 8 waves][6] cycle counters (barrier wait, DMA issue, fc1, fc2, depthwise, total) or NULL */
 int emip_debug_set_mb(int flags);              /* emip_mlp_block ablations: 1 no fc1 MFMAs, 2 no depthwise pass, 4 no fc2 MFMAs, 8 no weight DMA, 16 no H store */
