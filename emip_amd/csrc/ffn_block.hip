@@ -14,7 +14,7 @@
 //     the key order the accumulator registers have), so a chunk is 24 contiguous KB: LDS-DMA into a 4-slot ring (3 chunks in
 //     flight, one s_barrier + one counted vmcnt per chunk), fragment reads are conflict-free ds_read_b128 at lane * 16;
 //   * epilogue: the lane pair (lq, lq + 32) holds the 128 outputs of a token: LayerNorm statistics by one shuffle, gamma / beta
-//     from LDS, residual added, the pair trades halves (v_permlane32_swap): 16-byte stores.
+//     from LDS, residual added, the tile leaves through an LDS image in the drained ring: whole 256-byte rows.
 #include "common.h"
 
 namespace {
@@ -151,40 +151,47 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2))) void f
     s2 += __shfl_xor(s2, 32);
     const float mean = s1 * (1.0f / FF_C);
     const float rstd = rsqrtf(fmaxf(s2 * (1.0f / FF_C) - mean * mean, 0.f) + p.eps);
-    // Round 4: 16-byte stores.  A lane holds 4 channels (8 bytes) of every 8-channel group and its partner (lane ^ 32) the other 4;
+    // Round 4: whole lines out.  A lane holds 4 channels (8 bytes) of every 8-channel group and its partner (lane ^ 32) the other 4;
     // stored as they were, every 128-byte line of the output took sixteen 8-byte partial writes (PMC WRITE_SIZE 50.9 MB for 15.9 MB
-    // of output).  Now the pair trades halves (v_permlane32_swap, as match.hip does for the correlation rows): lane half 0 stores the
-    // 8 channels of group g, lane half 1 those of group g + 1.  Every lane of the wave takes part in the swap (clamped rows of the
-    // last workgroup compute and drop).
+    // of output); with the pair trading halves (v_permlane32_swap: 16 bytes per lane, second form of the round) still 33.7 MB.  Now
+    // the workgroup's 256 x 128 outputs go through an image in the drained weight ring (row pitch 256 B, 16-byte chunk c of row q
+    // at c ^ (q & 15)) and leave as whole 256-byte rows, 16 lanes each.  The residual is read by the token's own lane pair before
+    // the barrier, so Res may alias Out.
+    __builtin_amdgcn_s_barrier();                          // every wave is out of the last chunk's slot
+    __builtin_amdgcn_sched_barrier(0);
     {
         const bf16_t* rp = p.Res ? p.Res + tc * p.ldr : nullptr;
-        bf16_t* op = p.Out + tc * p.ldo;
+        const int q = wave * 32 + lq;
+        char* ib = smem + q * 256;
 #pragma unroll
         for (int d = 0; d < 4; ++d)
 #pragma unroll
-            for (int g = 0; g < 4; g += 2) {
-                bf16x4 o2[2];
+            for (int g = 0; g < 4; ++g) {
+                const int ch = 32 * d + 8 * g + 4 * h;
+                const float4 gm = *reinterpret_cast<const float4*>(tg + ch), bt = *reinterpret_cast<const float4*>(tg + FF_C + ch);
+                const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
+                float rv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (rp) {
+                    const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp + ch);
 #pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int ch = 32 * d + 8 * (g + e) + 4 * h;
-                    const float4 gm = *reinterpret_cast<const float4*>(tg + ch), bt = *reinterpret_cast<const float4*>(tg + FF_C + ch);
-                    const float gv[4] = {gm.x, gm.y, gm.z, gm.w}, bv[4] = {bt.x, bt.y, bt.z, bt.w};
-                    float rv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (rp) {
-                        const bf16x4 r4 = *reinterpret_cast<const bf16x4*>(rp + ch);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) rv[j] = (float)r4[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o2[e][j] = (bf16_t)(fmaf((oacc[d][4 * (g + e) + j] - mean) * rstd, gv[j], bv[j]) + rv[j]);
+                    for (int j = 0; j < 4; ++j) rv[j] = (float)r4[j];
                 }
-                const ff_u32x2 a2 = __builtin_bit_cast(ff_u32x2, o2[0]), b2 = __builtin_bit_cast(ff_u32x2, o2[1]);
-                const auto r0 = __builtin_amdgcn_permlane32_swap(a2.x, b2.x, false, false);
-                const auto r1 = __builtin_amdgcn_permlane32_swap(a2.y, b2.y, false, false);
-                // lanes 0..31: group g = [own half | partner's half]; lanes 32..63: group g + 1 likewise
-                const ff_u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
-                if (ok) *reinterpret_cast<ff_u32x4*>(op + 32 * d + 8 * (g + h)) = v;
+                bf16x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)(fmaf((oacc[d][4 * g + j] - mean) * rstd, gv[j], bv[j]) + rv[j]);
+                *reinterpret_cast<bf16x4*>(ib + (((4 * d + g) ^ (q & 15)) * 16) + 8 * h) = o;
             }
+    }
+    __syncthreads();
+    {
+        const int c = tid & 15;
+#pragma unroll
+        for (int pass = 0; pass < 8; ++pass) {
+            const int q = 32 * pass + (tid >> 4);
+            const long t2 = (long)blockIdx.x * 256 + q;
+            const ff_u32x4 v = *reinterpret_cast<const ff_u32x4*>(smem + q * 256 + ((c ^ (q & 15)) * 16));
+            if (t2 < p.M) *reinterpret_cast<ff_u32x4*>(p.Out + t2 * p.ldo + 8 * c) = v;
+        }
     }
 }
 
