@@ -965,9 +965,13 @@ __global__ __launch_bounds__(256) void chan_norm_apply_wide_kernel(const T* __re
                                                                    const double* __restrict__ sums,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta, long rows, int C,
-                                                                   float eps, int relu_inner, int relu_outer) {
+                                                                   float eps, int relu_inner, int relu_outer,
+                                                                   const double* __restrict__ rsums, int r_relu) {
     constexpr int VEC = 16 / sizeof(T);
     __shared__ float s_mean[1024], s_rstd[1024];
+    // rsums: the residual R is itself a RAW tensor whose InstanceNorm (+ ReLU with r_relu) was never stored: it is normalised
+    // here from its own sums and rounded to T as the stored tensor would have been (same bits as the two-pass form)
+    __shared__ float s_rmean[1024], s_rrstd[1024];
     const int nv = C / VEC, rl = 256 / nv;
     const long g = blockIdx.y;
     for (int c = threadIdx.x; c < C; c += 256) {               // one channel per thread: the float64 part, once per workgroup
@@ -975,16 +979,24 @@ __global__ __launch_bounds__(256) void chan_norm_apply_wide_kernel(const T* __re
         const double var = fmax(sums[(g * C + c) * 2 + 1] / (double)rows - m * m, 0.0);
         s_mean[c] = (float)m;
         s_rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (rsums) {
+            const double rm = rsums[(g * C + c) * 2] / (double)rows;
+            const double rvar = fmax(rsums[(g * C + c) * 2 + 1] / (double)rows - rm * rm, 0.0);
+            s_rmean[c] = (float)rm;
+            s_rrstd[c] = (float)(1.0 / sqrt(rvar + (double)eps));
+        }
     }
     __syncthreads();
     if ((int)threadIdx.x >= nv * rl) return;
     const int vi = threadIdx.x % nv, lr = threadIdx.x / nv;
-    float mean[VEC], rstd[VEC], ga[VEC], be[VEC];
+    float mean[VEC], rstd[VEC], ga[VEC], be[VEC], rmean[VEC], rrstd[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
         const int c = vi * VEC + j;
         mean[j] = s_mean[c];
         rstd[j] = s_rstd[c];
+        rmean[j] = rsums ? s_rmean[c] : 0.f;
+        rrstd[j] = rsums ? s_rrstd[c] : 1.f;
         ga[j] = gamma ? gamma[c] : 1.f;
         be[j] = gamma ? beta[c] : 0.f;
     }
@@ -1001,7 +1013,15 @@ __global__ __launch_bounds__(256) void chan_norm_apply_wide_kernel(const T* __re
             float t = (to_f32<T>(reinterpret_cast<const T*>(&xv)[j]) - mean[j]) * rstd[j];
             if (gamma) t = t * ga[j] + be[j];
             if (relu_inner) t = fmaxf(t, 0.f);
-            if (R) t += to_f32<T>(reinterpret_cast<const T*>(&rv)[j]);
+            if (R) {
+                float rr = to_f32<T>(reinterpret_cast<const T*>(&rv)[j]);
+                if (rsums) {
+                    rr = (rr - rmean[j]) * rrstd[j];
+                    if (r_relu) rr = fmaxf(rr, 0.f);
+                    rr = to_f32<T>(from_f32<T>(rr));
+                }
+                t += rr;
+            }
             if (relu_outer) t = fmaxf(t, 0.f);
             reinterpret_cast<T*>(&ov)[j] = from_f32<T>(t);
         }
@@ -1686,7 +1706,16 @@ extern "C" int emip_chan_stats(const void* X, long ldx, double* sums, long group
 extern "C" int emip_chan_norm_apply(const void* X, long ldx, void* Y, long ldy, const void* R, long ldr,
                                     const double* sums, const float* gamma, const float* beta, long groups, long rows,
                                     int C, float eps, int relu_inner, int relu_outer, int dtype, void* stream) {
+    return emip_chan_norm_apply_res(X, ldx, Y, ldy, R, ldr, sums, gamma, beta, groups, rows, C, eps, relu_inner, relu_outer, nullptr,
+                                    0, dtype, stream);
+}
+
+extern "C" int emip_chan_norm_apply_res(const void* X, long ldx, void* Y, long ldy, const void* R, long ldr,
+                                        const double* sums, const float* gamma, const float* beta, long groups, long rows,
+                                        int C, float eps, int relu_inner, int relu_outer, const double* res_sums, int res_relu,
+                                        int dtype, void* stream) {
     REQ_DT(dtype);
+    EMIP_REQUIRE(!res_sums || R);
     EMIP_REQUIRE(X && Y && sums && groups > 0 && rows > 0 && C >= 4 && (C & 3) == 0);
     EMIP_REQUIRE((ldx & 3) == 0 && (ldy & 3) == 0 && ldx >= C && ldy >= C);
     EMIP_REQUIRE((gamma == nullptr) == (beta == nullptr));
@@ -1701,9 +1730,10 @@ extern "C" int emip_chan_norm_apply(const void* X, long ldx, void* Y, long ldy, 
         if (chunks < 1) chunks = 1;
         DISPATCH_T(dtype, hipLaunchKernelGGL(chan_norm_apply_wide_kernel<T>, dim3((unsigned)chunks, (unsigned)groups),
                                              dim3(256), 0, (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, (const T*)R,
-                                             ldr, sums, gamma, beta, rows, C, eps, relu_inner, relu_outer));
+                                             ldr, sums, gamma, beta, rows, C, eps, relu_inner, relu_outer, res_sums, res_relu));
         return emip_launch_status();
     }
+    EMIP_REQUIRE(!res_sums);               // the raw-residual form exists on the wide kernel only
     const long total = groups * rows * (C >> 2);
     DISPATCH_T(dtype, hipLaunchKernelGGL(chan_norm_apply_kernel<T>, dim3(grid_for(total, 256)), dim3(256), 0,
                                          (hipStream_t)stream, (const T*)X, ldx, (T*)Y, ldy, (const T*)R, ldr, sums,

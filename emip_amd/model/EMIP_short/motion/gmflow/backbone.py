@@ -33,14 +33,21 @@ CNN_HALO = True
 CNN_HALO_MAXC = 96
 
 
-def _halo_block(x, w1p, w2p, ws):
-    """backbone.py:39-69 for in_planes == planes, stride 1: relu(x + norm2(conv2(relu(norm1(conv1(x))))))"""
+# a block input that is itself relu(InstanceNorm(raw conv output)) -- the stem's -- or a residual that is InstanceNorm(raw) -- the
+# downsample branch's -- is never stored: the consumers normalise the raw tensor from its sums (the halo conv while it stages,
+# emip_chan_norm_apply_res for the skip connection, rounding as the stored tensor would have been: the same bits, one pass less)
+CNN_RAW_RES = True
+
+
+def _halo_block(x, w1p, w2p, ws, x_sums=None):
+    """backbone.py:39-69 for in_planes == planes, stride 1: relu(x + norm2(conv2(relu(norm1(conv1(x)))))); x_sums: x is a raw
+    conv output whose relu(InstanceNorm(.)) is the block's real input"""
     B, C = x.shape[0], x.shape[-1]
     s1 = torch.empty((B, C, 2), dtype=torch.float64, device=x.device)
     s2 = torch.empty((B, C, 2), dtype=torch.float64, device=x.device)
-    y1 = ops.conv3x3_halo(x, w1p, out_sums=s1, ws=ws)
+    y1 = ops.conv3x3_halo(x, w1p, in_sums=x_sums, in_eps=1e-5, out_sums=s1, ws=ws)
     y2 = ops.conv3x3_halo(y1, w2p, in_sums=s1, in_eps=1e-5, out_sums=s2, ws=ws, out=torch.empty_like(y1))
-    return ops.chan_norm_apply(y2, s2, B, 1e-5, relu_inner=True, relu_outer=True, res=x, out=y2)
+    return ops.chan_norm_apply(y2, s2, B, 1e-5, relu_inner=True, relu_outer=True, res=x, out=y2, res_sums=x_sums, res_relu=True)
 
 
 class ResidualBlock(EmipModule):
@@ -58,7 +65,7 @@ class ResidualBlock(EmipModule):
             self.downsample = nn.Sequential(nn.Conv2d(in_planes, planes, kernel_size=1, stride=stride),
                                             norm_layer(planes))
 
-    def run(self, x, halo_ws=None):
+    def run(self, x, halo_ws=None, x_sums=None):
         dt = self.cdtype
         planes = self.conv2.weight.shape[0]
         B, Ho, Wo = x.shape[0], (x.shape[1] - 1) // self.stride + 1, (x.shape[2] - 1) // self.stride + 1
@@ -68,7 +75,8 @@ class ResidualBlock(EmipModule):
         if halo_ws is not None and self.downsample is None and self.stride == 1:
             w1p, w2p = self.packed("wh", (self.conv1.weight, self.conv2.weight),
                                    lambda a, b: (ops.conv3x3_halo_pack(pack_conv(a, dt)), ops.conv3x3_halo_pack(pack_conv(b, dt))))
-            return _halo_block(x, w1p, w2p, halo_ws)
+            return _halo_block(x, w1p, w2p, halo_ws, x_sums)
+        assert x_sums is None
         if halo_ws is not None:
             # the strided first convolution and the 1 x 1 downsample stay implicit GEMMs; conv2 normalises conv1's raw output
             # while it stages it and takes its own sums
@@ -79,6 +87,11 @@ class ResidualBlock(EmipModule):
             y1 = ops.conv2d(x, w1, 3, 3, self.stride, 1, zero=s1)
             ops.chan_stats(y1, B, sums=s1)
             y2 = ops.conv3x3_halo(y1, w2p, in_sums=s1, in_eps=1e-5, out_sums=s2, ws=halo_ws, out=torch.empty_like(y1))
+            if CNN_RAW_RES:
+                sd = torch.empty((B, planes, 2), dtype=torch.float64, device=x.device)
+                yd = ops.conv2d(x, wd, 1, 1, self.stride, 0, bias=bd, zero=sd)
+                ops.chan_stats(yd, B, sums=sd)
+                return ops.chan_norm_apply(y2, s2, B, 1e-5, relu_inner=True, relu_outer=True, res=yd, out=y2, res_sums=sd, res_relu=False)
             res = _conv_inorm(x, wd, 1, self.stride, 0, relu=False, bias=bd)
             return ops.chan_norm_apply(y2, s2, B, 1e-5, relu_inner=True, relu_outer=True, res=res, out=y2)
         w1, w2 = self.packed("w", (self.conv1.weight, self.conv2.weight),
@@ -134,11 +147,16 @@ class CNNEncoder(EmipModule):
             sums, ws = buf[:nb].view(torch.float64).view(B, 64, 2), buf[nb:]
             y = ops.conv2d(img_cl, w1, 7, 7, 2, 3, zero=buf[:nb + (4 * B + 63) // 64 * 64])
             ops.chan_stats(y, B, sums=sums)
-            x = ops.chan_norm_apply(y, sums, B, 1e-5, relu_inner=True, out=y)
+            if CNN_RAW_RES and CNN_HALO_MAXC >= 64:
+                x = self.layer1[0].run(y, ws, x_sums=sums)        # the stem's norm + relu happen inside layer1.0
+            else:
+                x = self.layer1[0].run(ops.chan_norm_apply(y, sums, B, 1e-5, relu_inner=True, out=y), ws)
+            x = self.layer1[1].run(x, ws)
         else:
             ws = None
             x = _conv_inorm(img_cl, w1, 7, 2, 3, relu=True)
-        for layer in (self.layer1, self.layer2, self.layer3):
+            x = self.layer1[1].run(self.layer1[0].run(x))
+        for layer in (self.layer2, self.layer3):
             x = layer[1].run(layer[0].run(x, ws), ws)
         return ops.gemm(x, w2, bias=b2)
 

@@ -995,12 +995,19 @@ def chan_stats(x, groups, sums=None):
     return sums
 
 
-def chan_norm_apply(x, sums, groups, eps, relu_inner, relu_outer=False, res=None, gamma=None, beta=None, out=None):
+def chan_norm_apply(x, sums, groups, eps, relu_inner, relu_outer=False, res=None, gamma=None, beta=None, out=None, res_sums=None,
+                    res_relu=False):
+    """res_sums: the residual is a raw conv output, normalised on the fly from its own sums (+ ReLU with res_relu)"""
     M, C, ldx = rows(x)
     if out is None:
         out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
     _, _, ldy = rows(out)
     ldr = rows(res)[2] if res is not None else 0
+    if res_sums is not None:
+        assert res is not None and res_sums.dtype == torch.float64 and res_sums.is_contiguous() and res_sums.numel() == groups * C * 2
+        _lib.call("emip_chan_norm_apply_res", _p(x), ldx, _p(out), ldy, _p(res), ldr, _p(sums), _p(gamma), _p(beta), groups,
+                  M // groups, C, float(eps), int(relu_inner), int(relu_outer), _p(res_sums), int(res_relu), dt_code(x.dtype), _stream())
+        return out
     _lib.call("emip_chan_norm_apply", _p(x), ldx, _p(out), ldy, _p(res), ldr, _p(sums), _p(gamma), _p(beta), groups,
               M // groups, C, float(eps), int(relu_inner), int(relu_outer), dt_code(x.dtype), _stream())
     return out

@@ -353,6 +353,13 @@ int emip_chan_stats(const void* X, long ldx, double* sums, long groups, long row
 int emip_chan_norm_apply(const void* X, long ldx, void* Y, long ldy, const void* R, long ldr, const double* sums,
                          const float* gamma, const float* beta, long groups, long rows, int C, float eps,
                          int relu_inner, int relu_outer, int dtype, void* stream);
+/* emip_chan_norm_apply whose residual R is itself a RAW convolution output: with res_sums f64 [groups][C][2] the residual is
+ * normalised on the fly from its own sums (+ ReLU with res_relu) and rounded to the storage type as the stored tensor would
+ * have been -- the InstanceNorm pass that would have materialised it disappears (gmflow/backbone.py:39-69: the stem's norm1 +
+ * relu feeding layer1's skip connection, the downsample branch's norm).  res_sums NULL: emip_chan_norm_apply. */
+int emip_chan_norm_apply_res(const void* X, long ldx, void* Y, long ldy, const void* R, long ldr, const double* sums,
+                             const float* gamma, const float* beta, long groups, long rows, int C, float eps, int relu_inner,
+                             int relu_outer, const double* res_sums, int res_relu, int dtype, void* stream);
 
 /* ---- depthwise / resampling / elementwise ---------------------------------------------------- */
 
