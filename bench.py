@@ -146,6 +146,8 @@ def _launch_info(lib, name, a):
             key = "gemm_kernel<bf16,%d,%d,dense>" % (t // 1000, t % 1000)
         Kr = {344: 340}.get(K, K)
         return 2.0 * M * N * Kr * batch, key, 2.0 * batch * (M * Kr + N * Kr + M * N * (2 if res else 1))
+    if name == "emip_conv8_ws":           # emip_conv8's arguments + (stats_ws, stats_ws_bytes) in front of the stream
+        name, a = "emip_conv8", tuple(a[:-3]) + (a[-1],)
     if name in ("emip_conv2d", "emip_conv2d_ln", "emip_conv8"):
         B, H, W, Cin, ldx, Cout, KH, KW, s, p = a[5], a[6], a[7], a[8], a[9], a[10], a[11], a[12], a[13], a[14]
         Ho, Wo = (H + 2 * p - KH) // s + 1, (W + 2 * p - KW) // s + 1

@@ -772,12 +772,13 @@ int launch(const G8Args& a0, int cfg, bool conv, hipStream_t s) {
     float* late_stats = nullptr;
     if (a.out_stats) {
         const int wgn = (g.bm == 256 && g.bn <= 128) || (g.bm == 128 && g.bn == 64) ? 2 : 4;       // configurations 1, 6, 8: 4 x 2 waves
-        // workspace for the in-launch combine: tickets (64-byte aligned block) then the partials
-        // (the ticket block has ONE size per M, whatever the tile: launches with different tiles may share a workspace)
-        const size_t cnt_bytes = ((size_t)((a.M + 63) / 64) * 4 + 63) & ~(size_t)63;
+        // workspace for the in-launch combine: a ticket block of FIXED size (launches of any shape may use one workspace in
+        // turn: a block sized by M let one launch's partials overwrite another's tickets -- NaNs in stage 3, round 4), then
+        // the partials
+        constexpr size_t cnt_bytes = 4 * 4096;
         const size_t ws_need = cnt_bytes + (size_t)a.tiles_m * a.tiles_n * g.bm * 8;
         void* ws = emip_internal::t_stats_ws;
-        const bool ws_ok = ws && (size_t)emip_internal::t_stats_ws_bytes >= ws_need && !lno &&
+        const bool ws_ok = ws && a.tiles_m <= 4096 && (size_t)emip_internal::t_stats_ws_bytes >= ws_need && !lno &&
                            lds + (size_t)g.bm * wgn * 8 <= 160 * 1024;
         if (a.tiles_n > 2 && ws_ok) {
             a.stats_cnt = (unsigned*)ws;
@@ -826,11 +827,11 @@ int row_stats(const void* C, long ldc, float* out_stats, int M, int N, void* str
 }  // namespace emip_internal
 
 extern "C" int emip_gemm8_auto_cfg(int M, int N, int K) { return pick_cfg(M, N, K); }
-// bytes of the workspace emip_gemm_ln_ws wants for an M x N output, whatever tile it picks (tickets + row partials of every
-// column tile); the first 4 * ceil(M / 64) bytes must be ZERO at the first launch (launches leave them zero)
+// bytes of the workspace emip_gemm_ln_ws wants for an M x N output, whatever tile it picks: 16 KB of tickets (ZERO at the first
+// launch; launches leave them zero) + row partials of every column tile
 extern "C" long emip_gemm_stats_ws_bytes(int M, int N) {
-    const long tm = (M + 63) / 64, tn = (N + 63) / 64;
-    return ((tm * 4 + 63) & ~63L) + ((long)M + 256) * tn * 8;
+    const long tn = (N + 63) / 64;
+    return 4 * 4096 + ((long)M + 256) * tn * 8;
 }
 #ifdef EMIP_TUNING
 extern "C" int emip_tuning_gemm8_dbg(int v) { g8_dbg = v; return 0; }
@@ -981,4 +982,20 @@ extern "C" int emip_conv8(const void* X, const void* W, void* Y, const float* bi
     a.a_bytes = (unsigned)ab; a.w_bytes = (unsigned)wb;
     a.ln_stats = ln_stats; a.tapsum = tapsum; a.ln_eps = ln_eps; a.s_bytes = ln_stats ? (unsigned)((long)B * H * Wd * 8) : 0u;
     return launch(a, cfg, true, (hipStream_t)stream);
+}
+
+// emip_conv8 with the statistics workspace of emip_gemm_ln_ws (row statistics of an output whose rows span more than two column
+// tiles combined inside the launch; emip_gemm_stats_ws_bytes(B Ho Wo, Cout) bytes, ticket block zero)
+extern "C" int emip_conv8_ws(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd,
+                             int Cin, long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act,
+                             const float* ln_stats, const float* tapsum, float ln_eps, float* out_stats, void* zero_ptr,
+                             long zero_bytes, int cfg, void* stats_ws, long stats_ws_bytes, void* stream) {
+    EMIP_REQUIRE(!stats_ws || (stats_ws_bytes > 0 && (reinterpret_cast<uintptr_t>(stats_ws) & 63u) == 0));
+    emip_internal::t_stats_ws = stats_ws;
+    emip_internal::t_stats_ws_bytes = stats_ws ? stats_ws_bytes : 0;
+    const int rc = emip_conv8(X, W, Y, bias, R, B, H, Wd, Cin, ldx, Cout, KH, KW, stride, pad, ldy, ldr, act, ln_stats, tapsum, ln_eps,
+                              out_stats, zero_ptr, zero_bytes, cfg, stream);
+    emip_internal::t_stats_ws = nullptr;
+    emip_internal::t_stats_ws_bytes = 0;
+    return rc;
 }

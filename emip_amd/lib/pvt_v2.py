@@ -43,9 +43,11 @@ SRA_FUSED = True
 # row statistics of the proj / fc2 GEMMs whose rows span more than two column tiles (N = 320 on 128-wide tiles) combined inside
 # the launch by the last column tile to finish (emip_gemm_ln_ws) instead of a row_stats launch behind it
 STATS_IN_LAUNCH = True
-SR_WIDE_TILE = 192          # the spatial-reduction conv of the 22 x 22 stage on wide tiles: True = ONE 64 x 320 tile per 64 rows (gemm8 configuration
-                            # 10, ring 3 deep), 192 = two tiles of 64 x 192 (configuration 11, ring 4 deep: round 4, 11.07 -> 10.75 ms one step at a
-                            # time, 2439 / 2436 pairs/s in flight), False = 64 x 128 tiles
+SR_WIDE_TILE = False        # the spatial-reduction conv of the 22 x 22 stage: False = 64 x 128 tiles (gemm8 configuration 9: 93 workgroups, ring 5
+                            # deep; its row statistics span three column tiles: combined inside the launch, STATS_IN_LAUNCH), 192 = two tiles of
+                            # 64 x 192 (configuration 11, ring 4 deep), True = ONE 64 x 320 tile per 64 rows (configuration 10, ring 3 deep).
+                            # Round 4, 16 pairs (pairs/s with 4 steps in flight | ms one step at a time): False 2369 | 10.79, 192: 2376 |
+                            # 11.07, True 2373 | 11.34 -- round 3 preferred True when False still cost a statistics pass behind the launch
 FC1DW_BAND_MIN_ROWS = 3     # banded fc1 + depthwise launch for maps of > 512 tokens when a band has at least this many output rows (0: off;
                             # in-call at 16 pairs: off 1592, the 44 x 44 stage only 1618, the 88 x 88 stage too 1628 pairs/s)
 MLP_BLOCK = False
@@ -261,8 +263,8 @@ class Block(EmipModule):
     def run_fused(self, x, stats, buf, alt=None, ws=None):
         """Inference block without LayerNorm launches.  x [B,H,W,C] (updated in place), stats f32 [B*H*W, 2] = (sum, sum of
         squares) of its rows, buf: this block's slice of the stage's ZEROED scratch, alt: a second token buffer of x's shape
-        (the one-launch Mlp half writes out of place), ws: the stage's workspace for row statistics combined inside a GEMM
-        launch (ops.gemm stats_ws; its ticket block lies in the zeroed scratch) -> (new x, stats of its rows, the token buffer
+        (the one-launch Mlp half writes out of place), ws: the stage's two workspaces (token GEMMs, sr conv) for row statistics
+        combined inside a launch (ops.gemm / ops.conv8 stats_ws; their ticket blocks lie in the zeroed scratch) -> (new x, stats of its rows, the token buffer
         that is free now)."""
         a = self.attn
         dt, C, heads, sr = self.cdtype, a.dim, a.num_heads, a.sr_ratio
@@ -271,6 +273,7 @@ class Block(EmipModule):
         M = B * N
         w = self._folded()
         bf = dt == torch.bfloat16
+        ws, ws_sr = ws if ws is not None else (None, None)
         Ms = B * (H // sr) * (W // sr) if sr > 1 else 0
         st_sr, st1, st2 = buf[:2 * Ms], buf[2 * Ms:2 * Ms + 2 * M], buf[2 * Ms + 2 * M:]
         cs = (lambda k: w["s" + k]) if bf else (lambda k: None)       # bf16: output-side LayerNorm (column sums); f32: loader
@@ -290,7 +293,8 @@ class Block(EmipModule):
                 per = max(1, ((256 // ntile_n) * per_tile) // rows_img)
                 if B <= per:
                     s = ops.conv8(x, w["sr"], sr, sr, sr, 0, bias=w["bsr"], ln_stats=stats, tapsum=w["tsr"],
-                                  ln_eps=self.norm1.eps, out_stats=st_sr, cfg=scfg)
+                                  ln_eps=self.norm1.eps, out_stats=st_sr, cfg=scfg,
+                                  stats_ws=ws_sr if (STATS_IN_LAUNCH and not wide) else None)
                 else:
                     s = torch.empty((B, H // sr, W // sr, C), dtype=dt, device=x.device)
                     for b0 in range(0, B, per):
@@ -463,10 +467,15 @@ class PyramidVisionTransformerV2(EmipModule):
                 a0 = blocks[0].attn
                 per = Block.scratch_floats(x.shape[0], Ho, Wo, a0.dim, a0.sr_ratio)
                 # + the stage's workspace for row statistics combined inside a launch (tickets first: they must be zero)
-                wsb = ops.gemm_stats_ws_bytes(x.shape[0] * Ho * Wo, a0.dim) if x.dtype == torch.bfloat16 else 0
+                # (two of them: the sr conv's output has other row counts, hence another ticket block, than the token GEMMs')
+                bf16 = x.dtype == torch.bfloat16
+                wsb = (ops.gemm_stats_ws_bytes(x.shape[0] * Ho * Wo, a0.dim) + 63) // 64 * 64 if bf16 else 0
+                srr = a0.sr_ratio
+                wsb2 = ops.gemm_stats_ws_bytes(x.shape[0] * (Ho // srr) * (Wo // srr), a0.dim) if (bf16 and srr > 1) else 0
                 off = (len(blocks) * per + 15) // 16 * 16
-                scratch = torch.empty(off + (wsb + 3) // 4, dtype=torch.float32, device=x.device)
-                ws = scratch[off:].view(torch.uint8) if wsb else None
+                scratch = torch.empty(off + (wsb + wsb2 + 3) // 4, dtype=torch.float32, device=x.device)
+                wsu = scratch[off:].view(torch.uint8)
+                ws = (wsu[:wsb], wsu[wsb:wsb + wsb2] if wsb2 else None) if wsb else None
                 x = pe.run(x, out_stats=stats, zero=scratch)
                 alt = torch.empty_like(x)
                 for j, blk in enumerate(blocks):

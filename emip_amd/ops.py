@@ -329,7 +329,7 @@ def gemm8(a, w, bias=None, res=None, act=ACT_NONE, out=None, a2=None, ln_stats=N
 
 
 def conv8(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=None, zero=None, out_stats=None, cfg=0,
-          ln_stats=None, tapsum=None, ln_eps=0.0):
+          ln_stats=None, tapsum=None, ln_eps=0.0, stats_ws=None):
     """emip_conv8: implicit-GEMM conv on the 8-wave bf16 body; x [B,H,W,Cin] channels-last, w packed [Cout, kh*kw*Cin];
     ln_stats f32 [B*H*W, 2] + tapsum f32 [kh*kw, Cout]: LayerNorm of the input pixels applied on the output side, per tap"""
     _dev(x)
@@ -351,6 +351,11 @@ def conv8(x, w, kh, kw, stride=1, pad=0, bias=None, res=None, act=ACT_NONE, out=
     if ln_stats is not None:
         assert ln_stats.dtype == torch.float32 and ln_stats.numel() == 2 * B * H * W and ln_stats.is_contiguous()
         assert tapsum.dtype == torch.float32 and tuple(tapsum.shape) == (kh * kw, Cout) and tapsum.is_contiguous()
+    if stats_ws is not None and out_stats is not None:      # row statistics of wide rows combined inside the launch (see gemm)
+        _lib.call("emip_conv8_ws", _p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, ldx, Cout, kh, kw, stride, pad, ldy,
+                  ldr, act, _p(ln_stats), _p(tapsum), float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), int(cfg),
+                  _p(stats_ws), stats_ws.numel(), _stream())
+        return out
     _lib.call("emip_conv8", _p(x), _p(w), _p(out), _p(bias), _p(res), B, H, W, Cin, ldx, Cout, kh, kw, stride, pad, ldy,
               ldr, act, _p(ln_stats), _p(tapsum), float(ln_eps), _p(out_stats), _p(zero), _nbytes(zero), int(cfg), _stream())
     return out

@@ -69,7 +69,8 @@ int emip_gemm_ln(const void* A, const void* A2, const void* W, void* C, const fl
  * without a workspace the launch is followed by a statistics pass over its output (row_stats_kernel).  With one, every column
  * tile leaves its row partials there and draws a ticket, and the tile that draws the last ticket of its row tile adds the
  * partials in column order and stores out_stats -- one launch, same bits as the pass.  stats_ws: emip_gemm_stats_ws_bytes(M, N)
- * bytes, 64-byte aligned, the first 4 ceil(M / 64) bytes ZERO before the first use (every launch leaves them zero); it must
+ * bytes, 64-byte aligned, the first 16 384 bytes (the ticket block, one size for every shape) ZERO before the first use (every launch leaves them
+ * zero: launches of different shapes may use one workspace in turn); it must
  * not be shared by launches that may run at the same time.  NULL or too small: emip_gemm_ln's behaviour.
  * (lib/pvt_v2.py:126,165-169: proj / fc2 + the statistics of the next LayerNorm) */
 long emip_gemm_stats_ws_bytes(int M, int N);
@@ -121,6 +122,12 @@ int emip_conv8(const void* X, const void* W, void* Y, const float* bias, const v
                long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act,
                const float* ln_stats, const float* tapsum, float ln_eps, float* out_stats, void* zero_ptr,
                long zero_bytes, int cfg, void* stream);
+/* emip_conv8 with the statistics workspace of emip_gemm_ln_ws (below): out_stats of rows that span more than two column tiles
+ * are combined inside the launch instead of by a pass behind it (lib/pvt_v2.py:106-110: sr conv -> norm -> kv) */
+int emip_conv8_ws(const void* X, const void* W, void* Y, const float* bias, const void* R, int B, int H, int Wd, int Cin,
+                  long ldx, int Cout, int KH, int KW, int stride, int pad, long ldy, long ldr, int act,
+                  const float* ln_stats, const float* tapsum, float ln_eps, float* out_stats, void* zero_ptr,
+                  long zero_bytes, int cfg, void* stats_ws, long stats_ws_bytes, void* stream);
 int emip_gemm8_auto_cfg(int M, int N, int K);
 /* Introspection (bench.py names the kernel symbol a launch ran on): the configuration the dispatcher inside emip_gemm* /
  * emip_conv2d* hands a bf16 launch to (0 = the 4-wave body), and a configuration's tile BM*1000+BN / ring depth. */

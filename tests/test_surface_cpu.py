@@ -60,7 +60,7 @@ def test_bench_knows_every_gemm8_tile():
     assert cfg - 1 >= 11
     assert lib.emip_conv3x3_halo_eligible(32, 176, 176, 64, 64) and lib.emip_conv3x3_halo_eligible(32, 88, 88, 96, 96)
     assert not lib.emip_conv3x3_halo_eligible(32, 90, 88, 96, 96)
-    assert lib.emip_gemm_stats_ws_bytes(7744, 320) >= 4 * 121 + 7744 * 3 * 8
+    assert lib.emip_gemm_stats_ws_bytes(7744, 320) >= 16384 + 7744 * 3 * 8
     assert lib.emip_conv3x3_halo(None, 64, None, None, 64, 1, 16, 16, 64, 64, None, 0.0, None, None, 0, None) == -1
 
 

@@ -12,7 +12,7 @@ from emip_amd.filler import synthetic_gt, synthetic_pair
 pytestmark = pytest.mark.gpu
 
 INFERENCE = [("emip_amd.lib.pvt_v2", "SRA_FUSED", False), ("emip_amd.lib.pvt_v2", "SRA_BLOCK_MAXC", 320),
-             ("emip_amd.lib.pvt_v2", "SRA_BLOCK_WIDE_ROWS", 10 ** 9), ("emip_amd.lib.pvt_v2", "SR_WIDE_TILE", False), ("emip_amd.lib.pvt_v2", "SR_WIDE_TILE", True),
+             ("emip_amd.lib.pvt_v2", "SRA_BLOCK_WIDE_ROWS", 10 ** 9), ("emip_amd.lib.pvt_v2", "SR_WIDE_TILE", 192), ("emip_amd.lib.pvt_v2", "SR_WIDE_TILE", True),
              ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_HALO", False),
              ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_HALO_MAXC", 128),
              ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_RAW_RES", False),
