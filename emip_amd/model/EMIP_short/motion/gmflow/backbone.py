@@ -28,9 +28,9 @@ def _conv_inorm(x, w, k, stride, pad, relu, bias=None, res=None, relu_outer=Fals
 # the shapes that kernel takes (352 x 352 inputs: all three levels); anything else takes conv + statistics + normalise launches
 CNN_HALO = True
 # widest block that takes it.  Measured (MI355X, 16 pairs, tools/flag_ab.py; pairs/s with 4 steps in flight | one step at a time):
-# none 2223 | 1344, 64: 2327 | 1400, 96: 2405 | 1432, 128: 2027 | 1440 -- the 128-channel form (one 11 x 22 tile per CU at 32
-# images, one halo buffer, 146 KB of LDS) is the shortest alone and the most expensive beside other steps' kernels
-CNN_HALO_MAXC = 96
+# none 2223 | 1344, 64: 2327 | 1400, 96: 2405 | 1432; the 128-channel level on the final build 2417 -> 2433 | 1515 -> 1526 (its
+# first version, which rebuilt the normalisation table from global memory for every tile, lost 16 % in flight)
+CNN_HALO_MAXC = 128
 
 
 # a block input that is itself relu(InstanceNorm(raw conv output)) -- the stem's -- or a residual that is InstanceNorm(raw) -- the

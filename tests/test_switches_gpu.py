@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 INFERENCE = [("emip_amd.lib.pvt_v2", "SRA_FUSED", False), ("emip_amd.lib.pvt_v2", "SRA_BLOCK_MAXC", 320),
              ("emip_amd.lib.pvt_v2", "SRA_BLOCK_WIDE_ROWS", 10 ** 9), ("emip_amd.lib.pvt_v2", "SR_WIDE_TILE", 192), ("emip_amd.lib.pvt_v2", "SR_WIDE_TILE", True),
              ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_HALO", False),
-             ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_HALO_MAXC", 128),
+             ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_HALO_MAXC", 64),
              ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_RAW_RES", False),
              ("emip_amd.model.EMIP_short.model", "CONV_CORR_GEMM8", False), ("emip_amd.lib.pvt_v2", "STATS_IN_LAUNCH", False),
              ("emip_amd.lib.pvt_v2", "FC1DW_BAND_MIN_ROWS", 0), ("emip_amd.lib.pvt_v2", "FC1DW_BAND_MIN_ROWS", 9),
