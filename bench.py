@@ -461,6 +461,7 @@ def report_rows(out, world):
              # the headline is a THROUGHPUT with several whole-batch steps in flight; one step at a time:
              "steps_in_flight": (out.get("config") or {}).get("steps_in_flight"),
              "latency_ms": out.get("per_step", {}).get("latency_ms"),
+             "latency_ms_forked_graph": out.get("per_step", {}).get("latency_ms_forked_graph"),
              "pairs_per_s_one_step_at_a_time": out.get("per_step", {}).get("pairs_per_s_one_step_at_a_time"),
              "literal_order_value": (out.get("literal_order") or {}).get("value"),
              "rate_in_the_references_literal_order": (out.get("literal_order") or {}).get("value")}]
@@ -910,6 +911,24 @@ def main():
                 torch.cuda.synchronize()
                 lat.append((time.perf_counter() - t1) * 1e3)
             latency_ms = round(_pct(lat, 0.5), 3)
+            latency_forked = fork_parity = None
+            if pipelined and hasattr(runner, "replay_alone"):
+                # the runner's LATENCY graph (PVT stages 3-4 on a forked branch of the graph): what a serving loop replays
+                # while its queue is empty; its outputs against the linear graph's
+                try:
+                    m_alone = runner.replay_alone()[0]
+                    lat2 = []
+                    for _ in range(7):
+                        torch.cuda.synchronize()
+                        t1 = time.perf_counter()
+                        runner.replay_alone()
+                        lat2.append((time.perf_counter() - t1) * 1e3)
+                    latency_forked = round(_pct(lat2, 0.5), 3)
+                    m_lin = runner.outputs(0)[0]
+                    torch.cuda.synchronize()
+                    fork_parity = float((m_alone.float() - m_lin.float()).abs().max().item())
+                except Exception as e:                           # noqa: BLE001
+                    latency_forked = {"error": repr(e)[:200]}
         agg = kernel_breakdown(net, im1, im2, nsplit)
         kernels = {k: v for k, v in agg.items() if v[1] > 0 and "blocker" not in k}
         dom = max(kernels, key=lambda k: kernels[k][0])
@@ -937,7 +956,12 @@ def main():
                          "pairs_per_s_p10": round(B / _pct(step_ms, 0.9) * 1e3, 1),
                          "pairs_per_s_p90": round(B / _pct(step_ms, 0.1) * 1e3, 1),
                          "latency_ms": latency_ms,
-                         "pairs_per_s_one_step_at_a_time": (round(B / latency_ms * 1e3, 1) if latency_ms else None)},
+                         "pairs_per_s_one_step_at_a_time": (round(B / latency_ms * 1e3, 1) if latency_ms else None),
+                         "latency_ms_forked_graph": latency_forked if not args.no_graph else None,
+                         "forked_graph_max_abs_dlogit_vs_linear_graph": fork_parity if not args.no_graph else None,
+                         "latency_note": "latency_ms: one replay of an in-flight (linear) graph on an idle device; "
+                                         "latency_ms_forked_graph: the runner's latency graph (graph.PipelinedShort.replay_alone: "
+                                         "PVT stages 3-4 on a forked branch beside the GMFlow half), same outputs"},
             "config": {"workload": "EMIP-short inference forward (CoUpdater.forward), batch=16 352x352 frame pairs "
                                    "per GPU, bf16 storage / f32 accumulate, random-filled weights",
                        "pairs_per_gpu": B, "parallelism": "dp%d (independent replicas, no collective)" % world,

@@ -11,13 +11,18 @@ import torch
 
 
 class _Part:
-    def __init__(self, net, batch, size, device, warmup, cnn_first=False):
+    def __init__(self, net, batch, size, device, warmup, cnn_first=False, fork_deep=None):
+        """fork_deep: capture with PVT stages 3-4 on a forked branch of the graph (model.FORK_DEEP); None = the module's setting"""
         from .model.EMIP_short import model as _m
         prev, _m.CNN_FIRST = _m.CNN_FIRST, bool(cnn_first and _m.STAGGER)
+        prev_f = _m.FORK_DEEP
+        if fork_deep is not None:
+            _m.FORK_DEEP = bool(fork_deep)
         try:
             self._build(net, batch, size, device, warmup)
         finally:
             _m.CNN_FIRST = prev
+            _m.FORK_DEEP = prev_f
 
     def _build(self, net, batch, size, device, warmup):
         self.batch = batch
@@ -134,6 +139,24 @@ class PipelinedShort:
             self.done[i] = torch.cuda.Event()
             self.done[i].record(s)
         return i
+
+    def replay_alone(self):
+        """ONE step on an otherwise idle device, from the LATENCY graph: the same forward captured with PVT stages 3-4 on a
+        forked branch beside the GMFlow half (model.FORK_DEEP: 10.6 -> 9.6 ms alone; with four steps in flight the branches
+        only compete, -1.2 %, so the in-flight graphs stay linear).  What a serving loop replays while its queue is empty.
+        Built on first use from slot 0's inputs; returns (mask, flow_fw, flow_bw) after a device synchronisation."""
+        if getattr(self, "alone", None) is None:
+            torch.cuda.synchronize()
+            p0 = self.parts[0]
+            self.alone = _Part(self.net, self.batch, p0.im1.shape[-1], p0.im1.device, 1, fork_deep=True)
+            self.alone.im1.copy_(p0.im1)
+            self.alone.im2.copy_(p0.im2)
+            self.alone.graph.replay()
+            torch.cuda.synchronize()
+        p = self.alone
+        p.graph.replay()
+        torch.cuda.synchronize()
+        return p.mask, [q[:p.batch] for q in p.preds], [q[p.batch:] for q in p.preds]
 
     def outputs(self, slot=0):
         """the static output buffers of a slot; the caller's stream waits for the slot's last replay first (the buffers are

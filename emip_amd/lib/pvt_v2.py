@@ -444,12 +444,29 @@ class PyramidVisionTransformerV2(EmipModule):
             setattr(self, f"norm{i + 1}", norm_layer(embed_dims[i]))
             cur += depths[i]
 
-    def run(self, x, deep=None):
+    def run(self, x, deep=None, fork=None):
         """x: channels-last image [B,H,W,8] -> list of the 4 stage outputs, channels-last.
         deep = (lo, hi): only the images lo .. hi - 1 of the batch go on past stage 2 (the outputs of stages 3 and 4 then hold
-        hi - lo images) -- for callers that read the deep features of part of the batch only (CoUpdater.run)."""
+        hi - lo images) -- for callers that read the deep features of part of the batch only (CoUpdater.run).
+        fork: a HIP stream.  Stages 3 and 4 are enqueued on it (behind everything the current stream holds so far), so that
+        the caller's following launches run beside them; the caller makes its stream wait for `fork` before it reads outs[2:]
+        (inside a graph capture this is a fork / join of the graph; inference only)."""
         outs = []
+        cur = torch.cuda.current_stream() if fork is not None else None
+        if fork is not None:
+            assert not torch.is_grad_enabled()
+        try:
+            return self._run_stages(x, deep, fork, cur, outs)
+        finally:
+            if fork is not None:
+                torch.cuda.set_stream(cur)
+
+    def _run_stages(self, x, deep, fork, cur, outs):
         for i in range(self.num_stages):
+            if i == 2 and fork is not None:
+                fork.wait_stream(cur)
+                x.record_stream(fork)
+                torch.cuda.set_stream(fork)
             if i == 2 and deep is not None:
                 x = x[deep[0]:deep[1]]
             pe = getattr(self, f"patch_embed{i + 1}")
@@ -493,6 +510,8 @@ class PyramidVisionTransformerV2(EmipModule):
                 continue
             g, b = self.packed(f"n{i}", (norm.weight, norm.bias), lambda a, c: (f32(a), f32(c)))
             x = ops.layernorm(x, g, b, norm.eps)
+            if fork is not None and i >= 2:
+                x.record_stream(cur)
             outs.append(x)
         return outs
 

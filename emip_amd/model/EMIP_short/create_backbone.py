@@ -184,9 +184,10 @@ class FeatureExtraction(EmipModule):
         from ...lib.pvt_v2 import pvt_v2_b5
         self.pvtv2_en = pvt_v2_b5(pretrained=None, in_channel_list=input_shape)
 
-    def run(self, img_cl, deep=None):
-        """stage outputs 2..4; deep = (lo, hi): stages 3 and 4 for the images lo .. hi - 1 only (pvt_v2.run)"""
-        return self.pvtv2_en.run(img_cl, deep=deep)[1:]
+    def run(self, img_cl, deep=None, fork=None):
+        """stage outputs 2..4; deep = (lo, hi): stages 3 and 4 for the images lo .. hi - 1 only; fork: the stream they run on
+        (pvt_v2.run)"""
+        return self.pvtv2_en.run(img_cl, deep=deep, fork=fork)[1:]
 
     def forward(self, x):
         return tuple(to_planar(o) for o in self.run(to_cl(x, self.cdtype, 8)))

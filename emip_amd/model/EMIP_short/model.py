@@ -38,6 +38,12 @@ CONV_CORR_GEMM8 = True
 # forward and (zero gradient) in the backward.  True: those stages run on the frame whose deep features are read (frame 1;
 # frame 2 for EMIP-long's steps, model_long.py:71,89-90,113-116).  Outputs and gradients are the reference's; False: literal order.
 PVT_DEEP_ONE_FRAME = True
+# PVT stages 3-4 on a forked stream beside the GMFlow half of the forward (inference).  One step at a time: 10.59 -> 9.56 ms;
+# with four steps in flight the two branches only compete: 2421 -> 2391 pairs/s (tools/flag_ab.py).  So the module default is
+# off and graph.PipelinedShort captures its LATENCY graph (replay_alone) with it on
+FORK_DEEP = False
+FORK_PRIORITY = 0       # priority of the forked stream (-1 = high: no effect measured)
+FORK_CNN = False        # with FORK_DEEP: the GMFlow CNN on a third branch beside PVT stages 1-2
 
 class CoUpdater(EmipModule):
     def __init__(self, args=None):
@@ -193,11 +199,33 @@ class CoUpdater(EmipModule):
             ops.planar_to_cl(image2.contiguous(), dt, 8, out=imgs[B:])
         # stage 2 of both frames; stages 3, 4 of the frame whose deep features are read (tail=False: EMIP-long reads frame 2's)
         deep = ((0, B) if tail else (B, 2 * B)) if PVT_DEEP_ONE_FRAME else None
-        if CNN_FIRST:
+        # PVT stages 3-4 (40 + 3 blocks of small launches, 40 % of a step's serial time) feed only the reductions in front of the
+        # decoder: on a forked stream they run beside the GMFlow half (inside a captured graph: a fork / join of the graph)
+        fork = None
+        if FORK_DEEP and tail and not torch.is_grad_enabled() and imgs.is_cuda:
+            fork = getattr(self, "_fork", None)
+            if fork is None or fork.device != imgs.device:
+                fork = torch.cuda.Stream(device=imgs.device, priority=FORK_PRIORITY)
+                object.__setattr__(self, "_fork", fork)
+        if fork is not None and FORK_CNN:
+            # ... and the GMFlow CNN on a third branch from the start, beside PVT stages 1-2
+            cur = torch.cuda.current_stream()
+            fork2 = getattr(self, "_fork2", None)
+            if fork2 is None or fork2.device != imgs.device:
+                fork2 = torch.cuda.Stream(device=imgs.device)
+                object.__setattr__(self, "_fork2", fork2)
+            fork2.wait_stream(cur)
+            imgs.record_stream(fork2)
+            with torch.cuda.stream(fork2):
+                gm = self.GMFlow.backbone.run(imgs)
+            gm.record_stream(cur)
+            fea = self.backbone.feat_net.run(imgs, deep=deep, fork=fork)
+            cur.wait_stream(fork2)
+        elif CNN_FIRST:
             gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
-            fea = self.backbone.feat_net.run(imgs, deep=deep)
+            fea = self.backbone.feat_net.run(imgs, deep=deep, fork=fork)
         else:
-            fea = self.backbone.feat_net.run(imgs, deep=deep)
+            fea = self.backbone.feat_net.run(imgs, deep=deep, fork=fork)
             gm = self.GMFlow.backbone.run(imgs)                        # [2B,44,44,128]
         ab = self.injector.run(gm, fea[0])                             # camouflage feeder (shared weights)
         if torch.is_grad_enabled() and ab.requires_grad:
@@ -219,6 +247,8 @@ class CoUpdater(EmipModule):
             return None, preds
         fea_new = self.injector1.run(fea[0][:B], cc)
         f1 = self.dr1.run(fea_new)
+        if fork is not None:
+            torch.cuda.current_stream().wait_stream(fork)              # the deep features
         f2 = self.dr2.run(fea[1][:B])
         f3 = self.dr3.run(fea[2][:B])
         mask = self.decoder.run(f3, f2, f1)

@@ -85,5 +85,20 @@ def test_steps_in_flight_reproduce_the_eager_bits(model_args, short_sd):
                 m, fw, bw = runner.outputs(slot)
                 assert torch.equal(m, ref), (rnd, slot, (m.float() - ref.float()).abs().max().item())
                 assert torch.equal(fw[0], ref_fw) and torch.equal(bw[0], ref_bw), (rnd, slot)
+        # the runner's latency graph (PVT stages 3-4 on a forked branch of the graph): the same bits, alone and after in-flight work
+        for _ in range(3):
+            m, fw, bw = runner.replay_alone()
+            assert torch.equal(m, ref) and torch.equal(fw[0], ref_fw) and torch.equal(bw[0], ref_bw)
+            runner.replay_free()
+        torch.cuda.synchronize()
+        from emip_amd.model.EMIP_short import model as M
+        prev, M.FORK_DEEP = M.FORK_DEEP, True                     # the eager forked forward (real streams, no graph)
+        try:
+            with torch.no_grad():
+                o = net(im1, im2)
+            torch.cuda.synchronize()
+            assert torch.equal(o[0], ref) and torch.equal(o[1][0], ref_fw)
+        finally:
+            M.FORK_DEEP = prev
     finally:
         nn_base.set_default_dtype(torch.float32)
