@@ -531,6 +531,161 @@ int launch_stream(const ChArgs& a, bool norm, bool stats, int ntiles, hipStream_
 int g_halo_mode = 0;     // 1: 64 channels on the streamed form (two halo buffers); 2: the same with ONE halo buffer, two workgroups per CU
 #endif
 
+// ---- the encoder's stem: 7 x 7, stride 2, zero padding 3, 3 (stored as 8) -> 64 channels, no bias (backbone.py:84,154-160), with
+// the InstanceNorm sums of its output in the epilogue.  A pixel is one 16-byte chunk, so the halo of a 16 x 16 output tile --
+// 37 x 37 input pixels -- is 22 KB; it is stored in column-parity planes ([row][column & 1][column >> 1]) so that the 16 lanes of
+// a fragment read (16 neighbouring outputs = input columns two apart, same tap) are consecutive chunks.  K = 49 taps x 8 = 392,
+// walked as 25 k-steps of two taps (the 50th is zero); the 50 weight fragments (50 KB) stay in LDS.  Epilogue and statistics
+// as in conv_halo_kernel (the image buffers are sized for the 32-KB output tile).
+constexpr int ST_HS = 37, ST_PL = 19, ST_SLOTS = ST_HS * 2 * ST_PL;                    // 37 rows x 2 parity planes x 19 columns = 1406 chunks
+constexpr int ST_HINS = (ST_SLOTS + 63) / 64, ST_BUF = 32 * 1024;                      // 22 DMA instructions; buffer = the 32-KB output image
+constexpr int ST_NKS = 25, ST_W = 2 * ST_NKS * 1024;                                   // 51 200 B of weights
+constexpr int ST_OFF_H = ST_W, ST_OFF_S = ST_W + 2 * ST_BUF, ST_LDS = ST_OFF_S + 8 * CH_C * 2 * 4 + 64;
+static_assert(ST_HINS * 1024 <= ST_BUF && ST_LDS <= 160 * 1024, "LDS");
+
+template <bool STATS>
+__global__ __launch_bounds__(512) void conv_stem_kernel(const ChArgs p) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int px = lane & 31, h = lane >> 5;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void*)smem;
+    const i32x4 rsX = ch_rsrc(p.X, p.x_bytes);
+    const i32x4 rsW = ch_rsrc(p.Wp, (unsigned)ST_W);
+    const int Ho = p.H / 2, Wo = p.W / 2;                     // output map (p.H, p.W: the input image)
+    const int per_img = p.tx * p.ty, ntiles = p.B * per_img;
+
+    auto issue = [&](int t, int b) {
+        const int img = t / per_img, r = t - img * per_img;
+        const int y0 = 2 * (r / p.tx) * CH_T - 3, x0 = 2 * (r % p.tx) * CH_T - 3;
+        for (int i = wave; i < ST_HINS; i += 8) {
+            const int sl = 64 * i + lane;                     // chunk (row hy, parity pr, column pair cc) = input pixel (hy, 2 cc + pr)
+            const int hy = sl / (2 * ST_PL), rem = sl - hy * 2 * ST_PL;
+            const int pr = rem / ST_PL, cc = rem - pr * ST_PL, hx = 2 * cc + pr;
+            const int gy = y0 + hy, gx = x0 + hx;
+            const bool in = sl < ST_SLOTS && hx < ST_HS && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+            const unsigned off = in ? (unsigned)((((long)img * p.H + gy) * p.W + gx) * p.ldx * 2) : CH_OOB;
+            ch_dma16((unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + ST_OFF_H + b * ST_BUF + i * 1024)), off, rsX);
+        }
+    };
+    for (int i = wave; i < 2 * ST_NKS; i += 8)
+        ch_dma16((unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + i * 1024)), (unsigned)(i * 1024 + lane * 16), rsW);
+    const int G = gridDim.x;
+    const int t_begin = (int)(((long)blockIdx.x * ntiles) / G), t_end = (int)(((long)(blockIdx.x + 1) * ntiles) / G);
+    auto owner = [&](int t) { return (int)((((long)t + 1) * G - 1) / ntiles); };
+    if (t_begin < t_end) issue(t_begin, 0);
+
+    const int oy = 2 * wave + (px >> 4), ox = px & 15;
+    // this lane's two taps of k-step ks: tap = 2 ks + h -> byte offset of its input pixel's chunk in a halo buffer
+    float run1 = 0.f, run2 = 0.f;
+    float* red = reinterpret_cast<float*>(smem + ST_OFF_S);
+
+    int buf = 0;
+    for (int t = t_begin; t < t_end; ++t, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < t_end) issue(t + 1, buf ^ 1);
+        const int img = t / per_img, r = t - img * per_img;
+        const int ty0 = (r / p.tx) * CH_T, tx0 = (r % p.tx) * CH_T;
+        char* hb = smem + ST_OFF_H + buf * ST_BUF;
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int d = 0; d < 2; ++d)
+#pragma unroll
+            for (int r2 = 0; r2 < 16; ++r2) acc[d][r2] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < ST_NKS; ++ks) {
+            const int tap = min(2 * ks + h, 48);              // (tap 49 does not exist: its weights are zero, any pixel will do)
+            const int ky = tap / 7, kx = tap - ky * 7;
+            const int hy = 2 * oy + ky, hx = 2 * ox + kx;
+            const ch_u32x4 bf = *reinterpret_cast<const ch_u32x4*>(hb + ((hy * 2 + (hx & 1)) * ST_PL + (hx >> 1)) * 16);
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                const ch_u32x4 af = *reinterpret_cast<const ch_u32x4*>(smem + (d * ST_NKS + ks) * 1024 + lane * 16);
+                acc[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bf), acc[d], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue through an LDS image of the tile (as conv_halo_kernel)
+        __syncthreads();
+        {
+            const int q = 32 * wave + px, sw = (q >> 1) & 7;
+#pragma unroll
+            for (int d = 0; d < 2; ++d)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (bf16_t)acc[d][4 * g + j];
+                    *reinterpret_cast<bf16x4*>(hb + q * 128 + (((4 * d + g) ^ sw) * 16) + 8 * h) = o;
+                }
+        }
+        __syncthreads();
+        {
+            const int c = tid & 7;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int q = 64 * pass + (tid >> 3);
+                const ch_u32x4 v = *reinterpret_cast<const ch_u32x4*>(hb + q * 128 + ((c ^ ((q >> 1) & 7)) * 16));
+                bf16_t* op = p.Y + (((long)img * Ho + ty0 + (q >> 4)) * Wo + tx0 + (q & 15)) * p.ldy;
+                *reinterpret_cast<ch_u32x4*>(op + 8 * c) = v;
+            }
+        }
+        if (STATS) {
+            const int ch = tid & 63, part = tid >> 6;
+#pragma unroll 8
+            for (int k = 0; k < 32; ++k) {
+                const int q = 32 * part + k;
+                const unsigned short u = *reinterpret_cast<const unsigned short*>(hb + q * 128 + (((ch >> 3) ^ ((q >> 1) & 7)) * 16) + 2 * (ch & 7));
+                const float x = __uint_as_float((unsigned)u << 16);
+                run1 += x;
+                run2 = fmaf(x, x, run2);
+            }
+            if (t + 1 == t_end || (t + 1) / per_img != img) {
+                const int lo = img * per_img, b0 = owner(lo), nb = owner(lo + per_img - 1) - b0 + 1;
+                *reinterpret_cast<float2*>(red + (part * CH_C + ch) * 2) = make_float2(run1, run2);
+                run1 = run2 = 0.f;
+                __syncthreads();
+                float* pp = p.part + ((long)img * per_img) * CH_C * 2;
+                if (tid < 2 * CH_C) {
+                    float sacc = 0.f;
+#pragma unroll
+                    for (int w = 0; w < 8; ++w) sacc += red[w * CH_C * 2 + tid];
+                    __hip_atomic_store(reinterpret_cast<unsigned*>(pp + (long)((int)blockIdx.x - b0) * CH_C * 2 + tid), __float_as_uint(sacc),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                unsigned* tick = reinterpret_cast<unsigned*>(smem + ST_OFF_S + 8 * CH_C * 2 * 4);
+                if (tid == 0) *tick = atomicAdd(p.cnt + img, 1u);
+                __syncthreads();
+                if (*tick == (unsigned)(nb - 1)) {
+                    if (tid < 2 * CH_C) {
+                        double sd = 0.0;
+                        for (int k = 0; k < nb; k += 8) {
+                            float v[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                const float* a = pp + (long)min(k + e, nb - 1) * CH_C * 2 + tid;
+                                asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[e]) : "v"(a) : "memory");
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) asm volatile("" : "+v"(v[e]));
+#pragma unroll
+                            for (int e = 0; e < 8; ++e)
+                                if (k + e < nb) sd += (double)v[e];
+                        }
+                        p.out_sums[(long)img * CH_C * 2 + tid] = sd;
+                    }
+                    if (tid == 0) __hip_atomic_store(p.cnt + img, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 static bool ch_resident(int H, int W, int C) { return C == CH_C && (H % CH_T) == 0 && (W % CH_T) == 0; }
@@ -601,3 +756,34 @@ extern "C" int emip_conv3x3_halo(const void* X, long ldx, const void* Wp, void* 
 #ifdef EMIP_TUNING
 extern "C" int emip_debug_set_halo(int mode) { g_halo_mode = mode; return 0; }
 #endif
+
+// The encoder's stem (see conv_stem_kernel): Y [B, H / 2, W / 2, 64] = conv7x7(X [B, H, W, 8], stride 2, zero padding 3), bf16,
+// H and W multiples of 32; Wp: 51 200 bytes in fragment order (ops.conv_stem_pack); out_sums / ws as in emip_conv3x3_halo
+// (workspace of the OUTPUT map: emip_conv3x3_halo_ws_bytes(B, H / 2, W / 2, 64)).
+extern "C" int emip_conv_stem_eligible(int B, int H, int W, int Cin, int Cout) {
+    return B > 0 && Cin == 8 && Cout == CH_C && H >= 32 && W >= 32 && (H % 32) == 0 && (W % 32) == 0;
+}
+extern "C" int emip_conv_stem(const void* X, long ldx, const void* Wp, void* Y, long ldy, int B, int H, int W, int Cin, int Cout,
+                              double* out_sums, void* ws, long ws_bytes, void* stream) {
+    EMIP_REQUIRE(X && Wp && Y && emip_conv_stem_eligible(B, H, W, Cin, Cout));
+    EMIP_REQUIRE(ldx >= 8 && (ldx & 7) == 0 && ldy >= CH_C && (ldy & 7) == 0 && aligned16(X) && aligned16(Wp) && aligned16(Y));
+    const long xb = (((long)B * H * W - 1) * ldx + 8) * 2;
+    EMIP_REQUIRE(xb < (1L << 31));
+    EMIP_REQUIRE(!out_sums || (ws && ws_bytes >= emip_conv3x3_halo_ws_bytes(B, H / 2, W / 2, CH_C) && (reinterpret_cast<uintptr_t>(ws) & 63u) == 0));
+    ChArgs a{};
+    a.X = (const bf16_t*)X; a.Wp = (const bf16_t*)Wp; a.Y = (bf16_t*)Y; a.ldx = ldx; a.ldy = ldy; a.B = B; a.H = H; a.W = W;
+    a.tx = W / 32; a.ty = H / 32; a.x_bytes = (unsigned)xb; a.out_sums = out_sums;
+    if (out_sums) {
+        a.cnt = (unsigned*)ws;
+        a.part = (float*)((char*)ws + (((long)B * 4 + 63) & ~63L));
+    }
+    const int ntiles = B * a.tx * a.ty;
+    void (*fn)(const ChArgs) = out_sums ? conv_stem_kernel<true> : conv_stem_kernel<false>;
+    static bool attr[2] = {false, false};
+    if (!attr[out_sums ? 1 : 0]) {
+        if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS) != hipSuccess) return EMIP_E_LAUNCH;
+        attr[out_sums ? 1 : 0] = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)(ntiles < 256 ? ntiles : 256)), dim3(512), ST_LDS, (hipStream_t)stream, a);
+    return emip_launch_status();
+}

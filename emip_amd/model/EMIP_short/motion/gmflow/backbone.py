@@ -37,6 +37,8 @@ CNN_HALO_MAXC = 128
 # downsample branch's -- is never stored: the consumers normalise the raw tensor from its sums (the halo conv while it stages,
 # emip_chan_norm_apply_res for the skip connection, rounding as the stored tensor would have been: the same bits, one pass less)
 CNN_RAW_RES = True
+# the 7 x 7 stride-2 stem as a direct convolution with its sums in the epilogue (emip_conv_stem): alone 132 -> 64 us at 32 images
+CNN_STEM = True
 
 
 def _halo_block(x, w1p, w2p, ws, x_sums=None):
@@ -145,8 +147,15 @@ class CNNEncoder(EmipModule):
             wsb = ops.conv3x3_halo_ws_bytes(B, H, W, 64)
             buf = torch.empty(nb + wsb, dtype=torch.uint8, device=img_cl.device)
             sums, ws = buf[:nb].view(torch.float64).view(B, 64, 2), buf[nb:]
-            y = ops.conv2d(img_cl, w1, 7, 7, 2, 3, zero=buf[:nb + (4 * B + 63) // 64 * 64])
-            ops.chan_stats(y, B, sums=sums)
+            if CNN_STEM and cin == 8 and ops.conv_stem_eligible(B, img_cl.shape[1], img_cl.shape[2], 8, 64):
+                # the 7 x 7 stem as a direct convolution too, its InstanceNorm sums from the epilogue; the ticket block is cleared
+                # by a small fill (the stem no longer runs through the GEMM whose first workgroup used to clear it)
+                buf[nb:nb + (4 * B + 63) // 64 * 64].zero_()
+                w1s = self.packed("ws", (self.conv1.weight,), lambda a: (ops.conv_stem_pack(pack_conv(a, dt, cin_pad=8)),))[0]
+                y = ops.conv_stem(img_cl, w1s, out_sums=sums, ws=ws)
+            else:
+                y = ops.conv2d(img_cl, w1, 7, 7, 2, 3, zero=buf[:nb + (4 * B + 63) // 64 * 64])
+                ops.chan_stats(y, B, sums=sums)
             if CNN_RAW_RES and CNN_HALO_MAXC >= 64:
                 x = self.layer1[0].run(y, ws, x_sums=sums)        # the stem's norm + relu happen inside layer1.0
             else:

@@ -968,6 +968,32 @@ def conv3x3_halo(x, wp, out=None, in_sums=None, in_eps=1e-5, out_sums=None, ws=N
     return out
 
 
+def conv_stem_eligible(B, H, W, Cin, Cout):
+    return bool(_lib.load().emip_conv_stem_eligible(B, H, W, Cin, Cout))
+
+
+def conv_stem_pack(w):
+    """pack_conv's [64, 7 * 7 * 8] bf16 -> the fragment order of emip_conv_stem: [d][ks][lane][e] = w[32 d + lane % 32][tap = 2 ks +
+    lane // 32][e], zero for tap 49"""
+    assert w.dtype == torch.bfloat16 and w.shape == (64, 392)
+    wz = torch.zeros((64, 50, 8), dtype=w.dtype, device=w.device)
+    wz[:, :49] = w.view(64, 49, 8)
+    v = wz.view(2, 32, 25, 2, 8)                      # [d][row][ks][half][e]
+    return v.permute(0, 2, 3, 1, 4).contiguous().view(-1)        # [d][ks][half][row][e]: lane = 32 half + row
+
+
+def conv_stem(x, wp, out_sums=None, ws=None, out=None):
+    """y [B, H / 2, W / 2, 64] = conv7x7(x [B, H, W, 8], stride 2, pad 3), bf16; out_sums f64 [B, 64, 2] of y (needs ws)"""
+    B, H, W, C = x.shape
+    assert x.dtype == torch.bfloat16 and C == 8 and x.stride(-1) == 1 and x.stride(1) == W * x.stride(2)
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, 64), dtype=x.dtype, device=x.device)
+    assert out_sums is None or (out_sums.dtype == torch.float64 and out_sums.is_contiguous() and out_sums.numel() == B * 128)
+    _lib.call("emip_conv_stem", _p(x), x.stride(2), _p(wp), _p(out), out.stride(2), B, H, W, 8, 64, _p(out_sums), _p(ws), _nbytes(ws),
+              _stream())
+    return out
+
+
 def dwconv3x3_dual(x, wt, bias, act):
     """-> (act(dwconv(x)), dwconv(x)): activation output and pre-activation values from one pass"""
     B, H, W, C = x.shape

@@ -795,6 +795,16 @@ long emip_conv3x3_halo_ws_bytes(int B, int H, int W, int C);
 int emip_conv3x3_halo(const void* X, long ldx, const void* Wp, void* Y, long ldy, int B, int H, int W, int Cin, int Cout,
                       const double* in_sums, float in_eps, double* out_sums, void* ws, long ws_bytes, void* stream);
 
+/* The GMFlow CNN encoder's stem (gmflow/backbone.py:84,154-160: Conv2d(3, 64, 7, stride 2, padding 3, bias=False) + norm1 + relu1)
+ * as a direct convolution on an LDS halo tile: Y [B, H / 2, W / 2, 64] = conv7x7(X [B, H, W, 8]) (the 3 image channels stored
+ * as 8), bf16 channels-last, H and W multiples of 32; Wp: 51 200 bytes in MFMA-fragment order [2][25 k-steps of two taps][64
+ * lanes][8] (emip_amd/ops.py: conv_stem_pack); out_sums f64 [B][64][2] (may be NULL) = (sum, sum of squares) of the stored Y per
+ * image and channel from the epilogue, through ws (emip_conv3x3_halo_ws_bytes(B, H / 2, W / 2, 64) bytes, tickets zero): the
+ * InstanceNorm itself is applied by the consumers (emip_conv3x3_halo in_sums, emip_chan_norm_apply_res). */
+int emip_conv_stem_eligible(int B, int H, int W, int Cin, int Cout);
+int emip_conv_stem(const void* X, long ldx, const void* Wp, void* Y, long ldy, int B, int H, int W, int Cin, int Cout,
+                   double* out_sums, void* ws, long ws_bytes, void* stream);
+
 /* ---- calibration switches: libemip_hip_tuning.so ONLY (make -C emip_amd/csrc tuning, -DEMIP_TUNING) ----------------------
  * Tile / ring-depth overrides and work-skipping ablations (no stores / no MFMA / no loads) for tools/.  The product
  * library libemip_hip.so does not contain them (bench.py checks), so nothing a benchmark runs can skip work. */

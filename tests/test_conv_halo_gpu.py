@@ -74,3 +74,37 @@ def test_normalise_on_staging_equals_the_separate_passes(B, H, W, C):
     err, d_old = (y.float() - ref).abs().max().item(), (y.float() - old.float()).abs().max().item()
     print(f"  {B}x{H}x{W}x{C}: max |d| vs PyTorch {err:.4f}, vs apply + conv {d_old:.4f} on values up to {top:.1f}")
     assert err < 1.2e-2 * top and d_old < 1.2e-2 * top
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 352, 352), (3, 64, 96), (40, 64, 64)])
+def test_stem_conv(B, H, W):
+    """emip_conv_stem (7 x 7, stride 2, 3 -> 64 channels with the image stored as 8) against PyTorch f32, the implicit-GEMM conv
+    it replaces (same bits) and a statistics pass over its output"""
+    from emip_amd import ops
+    assert ops.conv_stem_eligible(B, H, W, 8, 64) and not ops.conv_stem_eligible(B, H + 16, W, 8, 64)
+    g = torch.Generator(device="cuda").manual_seed(B)
+    x = torch.zeros(B, H, W, 8, device="cuda", dtype=torch.bfloat16)
+    x[..., :3] = torch.randn(B, H, W, 3, device="cuda", generator=g).to(torch.bfloat16)
+    w = torch.randn(64, 3, 7, 7, device="cuda", generator=g) / 12.0
+    wp = torch.zeros(64, 7, 7, 8, device="cuda")
+    wp[..., :3] = w.permute(0, 2, 3, 1)
+    wp = wp.reshape(64, -1).to(torch.bfloat16).contiguous()
+    pk = ops.conv_stem_pack(wp)
+    ws = ops.conv3x3_halo_ws(B, H // 2, W // 2, x.device, 64)
+    outs = []
+    for _ in range(2):
+        sums = torch.full((B, 64, 2), -1.0, dtype=torch.float64, device="cuda")
+        outs.append((ops.conv_stem(x, pk, out_sums=sums, ws=ws), sums))
+    y0 = ops.conv_stem(x, pk)
+    old = ops.conv2d(x, wp, 7, 7, 2, 3)
+    ref = torch.nn.functional.conv2d(x[..., :3].float().permute(0, 3, 1, 2), w.to(torch.bfloat16).float(), stride=2, padding=3).permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    (y, sums), (yb, sumsb) = outs
+    assert torch.equal(y, yb) and torch.equal(sums, sumsb) and torch.equal(y, y0) and int(ws[:4 * B].max()) == 0
+    top = ref.abs().max().item()
+    err, d_old = (y.float() - ref).abs().max().item(), (y.float() - old.float()).abs().max().item()
+    yf = y.double()
+    s_ref = torch.stack((yf.sum((1, 2)), (yf * yf).sum((1, 2))), -1)
+    es = ((sums - s_ref).abs() / (s_ref.abs() + 1.0)).max().item()
+    print(f"  {B}x{H}x{W}: max |d| vs PyTorch {err:.4f} on values up to {top:.1f}; vs the implicit-GEMM conv {d_old:.4f}; sums rel {es:.1e}")
+    assert err < 6e-3 * top and d_old <= 2.0 ** -7 * top and es < 1e-5

@@ -16,6 +16,7 @@ INFERENCE = [("emip_amd.lib.pvt_v2", "SRA_FUSED", False), ("emip_amd.lib.pvt_v2"
              ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_HALO", False),
              ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_HALO_MAXC", 64),
              ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_RAW_RES", False),
+             ("emip_amd.model.EMIP_short.motion.gmflow.backbone", "CNN_STEM", False),
              ("emip_amd.model.EMIP_short.model", "CONV_CORR_GEMM8", False), ("emip_amd.lib.pvt_v2", "STATS_IN_LAUNCH", False),
              ("emip_amd.lib.pvt_v2", "FC1DW_BAND_MIN_ROWS", 0), ("emip_amd.lib.pvt_v2", "FC1DW_BAND_MIN_ROWS", 9),
              ("emip_amd.lib.pvt_v2", "MLP_BLOCK", True), ("emip_amd.lib.pvt_v2", "SR_KSPLIT", True),

@@ -53,3 +53,17 @@ rep("halo conv", timeit(lambda: ops.conv3x3_halo(x, pk, out=y)))
 rep("halo conv + statistics", timeit(lambda: ops.conv3x3_halo(x, pk, out=y, out_sums=s_out, ws=ws)))
 rep("halo conv, normalise on staging", timeit(lambda: ops.conv3x3_halo(x, pk, out=y, in_sums=s_in)))
 rep("halo conv, normalise on staging + statistics", timeit(lambda: ops.conv3x3_halo(x, pk, out=y, in_sums=s_in, out_sums=s_out, ws=ws)))
+
+# ---- the stem (7 x 7, stride 2, 3 -> 64 channels)
+xs = torch.zeros(B, 352, 352, 8, device="cuda", dtype=torch.bfloat16)
+xs[..., :3] = torch.randn(B, 352, 352, 3, device="cuda", generator=g).to(torch.bfloat16)
+wps = (torch.randn(64, 392, device="cuda", generator=g) / 12).to(torch.bfloat16)
+pks = ops.conv_stem_pack(wps)
+fl = 2.0 * B * 176 * 176 * 64 * 147
+rep("stem: implicit-GEMM conv", timeit(lambda: ops.conv2d(xs, wps, 7, 7, 2, 3, out=y)))
+def stem_old():
+    ops.conv2d(xs, wps, 7, 7, 2, 3, out=y, zero=s_out)
+    ops.chan_stats(y, B, sums=s_out)
+rep("stem: implicit-GEMM conv + statistics pass", timeit(stem_old))
+rep("stem: direct conv", timeit(lambda: ops.conv_stem(xs, pks, out=y)))
+rep("stem: direct conv + statistics", timeit(lambda: ops.conv_stem(xs, pks, out_sums=s_out, ws=ws, out=y)))
