@@ -514,14 +514,14 @@ F_EXEC_LONG_FRAME_GFLOP = F_ALG_LONG_FRAME_GFLOP - CONV_CORR_REF_GFLOP + CONV_CO
 F_EXEC_TRAIN_PAIR_GFLOP = F_ALG_TRAIN_PAIR_GFLOP - 3 * CONV_CORR_REF_GFLOP + CONV_CORR_EXEC_GFLOP + 4 * 4.32 - 3 * PVT_DEEP_IMAGE_GFLOP
 
 
-def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allreduce", comm="f32"):
+def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allreduce", comm="f32", graph=True):
     """BASELINE.json configs[2] / configs[4]: one EMIP-short training step (forward, hybrid_e_loss + unFlowLoss, backward,
     bucketed gradient all-reduce over RCCL when N > 1, fused clamp + AdamW) on B synthetic pairs per GPU in bf16."""
     from emip_amd import _lib, dist as edist, nn_base
     from emip_amd.dp import GradReducer, broadcast_parameters
     from emip_amd.filler import state_dict_from_manifest, synthetic_gt, synthetic_pair
     from emip_amd.model.EMIP_short.model import CoUpdater
-    from emip_amd.train import build_optimizer, freeze_like_reference, train_step, trainable
+    from emip_amd.train import GraphedTrainStep, build_optimizer, freeze_like_reference, train_step, trainable
     _lib.load()
     g = os.path.join(ROOT, "tests", "golden")
     margs = json.load(open(os.path.join(g, "model_args.json")))
@@ -539,12 +539,33 @@ def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allre
     im1, im2, gt = im1.to(dev), im2.to(dev), gt.to(dev)
     loss = None
     torch.cuda.reset_peak_memory_stats(dev)
+    # One process, one GPU: forward + both losses + backward + weight gradients replayed as ONE hipGraph (the same Functions
+    # and kernels as the eager step, train.GraphedTrainStep), the batch copied into the graph's input buffers and the fused
+    # clamp + AdamW launched eagerly inside every timed step.  The eager step is timed beside it.  N > 1: the eager step (the
+    # gradient buckets' collectives are not captured).
+    graphed = graph and world == 1
+    eager = None
+    if graphed:
+        for _ in range(3):
+            loss = train_step(net, opt, red, im1, im2, gt)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(8):
+            loss = train_step(net, opt, red, im1, im2, gt)
+        torch.cuda.synchronize(dev)
+        te = (time.perf_counter() - t0) / 8
+        eager = {"ms_per_step": round(te * 1e3, 3), "value": round(B / te, 3), "unit": "pairs/s", "steps": 8,
+                 "what": "emip_amd.train.train_step launch by launch (PVT stages 3-4 on the forked stream as well)"}
+        gs = GraphedTrainStep(net, opt, im1, im2, gt)
+        step = lambda: gs.step(im1, im2, gt)
+    else:
+        step = lambda: train_step(net, opt, red, im1, im2, gt)
     for _ in range(warmup):
-        loss = train_step(net, opt, red, im1, im2, gt)
+        loss = step()
     _barrier(dist)
     t0 = time.perf_counter()
     for _ in range(steps):
-        loss = train_step(net, opt, red, im1, im2, gt)
+        loss = step()
     _barrier(dist)
     dt = edist.max_over_ranks(time.perf_counter() - t0, red_dev)
     value = world * B * steps / dt
@@ -555,8 +576,10 @@ def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allre
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "EMIP-short training step (fwd + hybrid_e_loss + unFlowLoss + bwd + clamp/AdamW), "
                                "batch=%d 352x352 pairs per GPU, bf16 storage / f32 accumulate and f32 master "
-                               "weights, DropPath 0.1, GMFlow frozen" % B,
-                   "pairs_per_gpu": B,
+                               "weights, DropPath 0.1, GMFlow frozen%s" % (
+                                   B, "; forward + backward + weight gradients as one hipGraph per step (PVT stages 3-4 on a "
+                                      "forked branch), optimizer launch eager" if graphed else ""),
+                   "pairs_per_gpu": B, "graph": bool(graphed),
                    "parallelism": "dp%d (bucketed gradient exchange over RCCL: %s, %s on the wire)" % (
                        world, "one all-reduce per 64-MB bucket" if algo == "allreduce" else
                        "direct reduce-scatter + all-gather on the xGMI mesh", comm)},
@@ -569,6 +592,8 @@ def measure_train(B, steps, warmup, world, rank, dev, dist, red_dev, algo="allre
                             "forward / input gradient / weight gradient)" % F_EXEC_TRAIN_PAIR_GFLOP,
         "last_loss": [round(float(x), 5) for x in loss],
         "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)}
+    if eager is not None:
+        rec["eager_step"] = eager
     if red is not None:
         red.remove()
     del net, opt, red
@@ -618,7 +643,8 @@ def measure_literal_order(net, B, im1, im2, dev, inflight, steps=12, warmup=4):
 def main_train(args):
     """--workload train: reported beside, never instead of, the inference headline."""
     world, rank, dev, dist, red_dev = _dist_setup()
-    rec = measure_train(args.pairs or 32, args.steps, args.warmup, world, rank, dev, dist, red_dev, args.dp_algo, args.dp_comm)
+    rec = measure_train(args.pairs or 32, args.steps, args.warmup, world, rank, dev, dist, red_dev, args.dp_algo, args.dp_comm,
+                        graph=not args.train_eager)
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if dist is not None:
@@ -798,6 +824,8 @@ def main():
                          "a time, its batch split into --streams sub-batch graphs)")
     ap.add_argument("--long-group", type=int, default=2, help="EMIP-long: consecutive time steps per graph of the memory-independent part")
     ap.add_argument("--no-sub", action="store_true", help="skip the train / long / f32 sub-records of the default run")
+    ap.add_argument("--train-eager", action="store_true",
+                    help="train workload: the launch-by-launch step only (default at N = 1: the step replayed as a hipGraph)")
     ap.add_argument("--dp-algo", choices=("allreduce", "direct"), default="allreduce",
                     help="train workload, N > 1: gradient exchange of emip_amd.dp.GradReducer")
     ap.add_argument("--dp-comm", choices=("f32", "bf16"), default="f32", help="... and its transport dtype")
@@ -1056,7 +1084,18 @@ def main():
             except Exception as e:                               # noqa: BLE001
                 sub["literal_order"] = {"error": repr(e)[:300]}
         try:
-            sub["train"] = measure_train(32, 6, 4, world, rank, dev, dist, red_dev, args.dp_algo, args.dp_comm)
+            if world == 1 and not args.train_eager:
+                # the graphed training step in a process of its own: a capture that goes wrong ends in the runtime, not in a
+                # Python exception, and must not take the headline with it
+                import subprocess
+                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "train", "--steps", "6",
+                                      "--warmup", "4"], capture_output=True, text=True, timeout=600)
+                lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+                if out.returncode != 0 or not lines:
+                    raise RuntimeError("train sub-record: exit %d: %s" % (out.returncode, out.stderr[-200:]))
+                sub["train"] = json.loads(lines[-1])
+            else:
+                sub["train"] = measure_train(32, 6, 4, world, rank, dev, dist, red_dev, args.dp_algo, args.dp_comm, graph=False)
         except Exception as e:                                   # noqa: BLE001
             sub["train"] = {"error": repr(e)[:300]}
         if world == 1:

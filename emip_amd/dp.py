@@ -237,13 +237,16 @@ class GradReducer:
         ref = b.params[0]
         dev = ref.device
         self._ensure(dev)
+        from . import ops
         if ref.is_cuda:
-            from . import ops
             ops.flush_wgrads()              # weight gradients the step has deferred must be on the compute stream first
             ops.WGRADS.fixup(b.params)      # ... and be what these parameters' .grad holds
         side = self._stream(dev)
         if side is not None:
-            side.wait_stream(torch.cuda.current_stream(dev))
+            # gradients of this bucket may come from the step's main stream or from a forked branch (model.FORK_DEEP_TRAIN);
+            # the hook that fills the bucket runs on only one of them
+            for st in ops.step_streams(dev):
+                side.wait_stream(st)
             ctx = torch.cuda.stream(side)
         else:
             import contextlib

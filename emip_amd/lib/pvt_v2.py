@@ -450,11 +450,11 @@ class PyramidVisionTransformerV2(EmipModule):
         hi - lo images) -- for callers that read the deep features of part of the batch only (CoUpdater.run).
         fork: a HIP stream.  Stages 3 and 4 are enqueued on it (behind everything the current stream holds so far), so that
         the caller's following launches run beside them; the caller makes its stream wait for `fork` before it reads outs[2:]
-        (inside a graph capture this is a fork / join of the graph; inference only)."""
+        (inside a graph capture this is a fork / join of the graph).  Under autograd the Functions of stages 3 and 4 record `fork`
+        as their stream, so their backward kernels run there too, beside the backward of whatever the caller enqueued meanwhile
+        (the engine orders the gradient edges between the streams)."""
         outs = []
         cur = torch.cuda.current_stream() if fork is not None else None
-        if fork is not None:
-            assert not torch.is_grad_enabled()
         try:
             return self._run_stages(x, deep, fork, cur, outs)
         finally:
@@ -506,6 +506,8 @@ class PyramidVisionTransformerV2(EmipModule):
             norm = getattr(self, f"norm{i + 1}")
             if torch.is_grad_enabled():
                 x = LayerNormFn.apply(x, norm.weight, norm.bias, norm.eps)
+                if fork is not None and i >= 2:
+                    x.record_stream(cur)
                 outs.append(x)
                 continue
             g, b = self.packed(f"n{i}", (norm.weight, norm.bias), lambda a, c: (f32(a), f32(c)))

@@ -142,7 +142,9 @@ class NeighborConnectionDecoder(EmipModule):
             return w8.to(dt).contiguous(), w8.t().to(dt).contiguous(), b8
         wp, wpt, b8 = self.packed("c5t", (w5, self.conv5.bias), build)
         pc = LinearFn.apply(x, w5, self.conv5.bias, None, wp, wpt, b8)          # [B,44,44,8], channel 0 = logits
-        self.last_pc = pc
+        # detached: a module attribute that carries a grad_fn keeps the step's whole autograd graph alive until the next
+        # forward, and with it every parameter's AccumulateGrad node and the stream that node was created under
+        self.last_pc = pc.detach()
         return BilinearPlanarFn.apply(pc, 0, 1, 8 * pc.shape[1], 8 * pc.shape[2], False, 1.0)
 
     def run(self, zt5, zt4, zt3):

@@ -44,6 +44,21 @@ PVT_DEEP_ONE_FRAME = True
 FORK_DEEP = False
 FORK_PRIORITY = 0       # priority of the forked stream (-1 = high: no effect measured)
 FORK_CNN = False        # with FORK_DEEP: the GMFlow CNN on a third branch beside PVT stages 1-2
+# The training step (one step at a time by nature): PVT stages 3-4 on ops.fork_stream in the forward; autograd runs a node's
+# backward on the stream of its forward, so the backward of those 43 blocks runs beside the backward of the GMFlow half as well.
+# The deferred weight-gradient queue (ops.WgradQueue.flush) and the end of the step (train.train_step) order the two streams.
+FORK_DEEP_TRAIN = True
+
+def _detach_tree(v):
+    """the same nest of dicts / lists / tuples with every tensor detached"""
+    if torch.is_tensor(v):
+        return v.detach()
+    if isinstance(v, dict):
+        return {k: _detach_tree(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return type(v)(_detach_tree(x) for x in v)
+    return v
+
 
 class CoUpdater(EmipModule):
     def __init__(self, args=None):
@@ -202,12 +217,15 @@ class CoUpdater(EmipModule):
         # PVT stages 3-4 (40 + 3 blocks of small launches, 40 % of a step's serial time) feed only the reductions in front of the
         # decoder: on a forked stream they run beside the GMFlow half (inside a captured graph: a fork / join of the graph)
         fork = None
-        if FORK_DEEP and tail and not torch.is_grad_enabled() and imgs.is_cuda:
+        if FORK_DEEP_TRAIN and tail and torch.is_grad_enabled() and self.training and imgs.is_cuda:
+            # training step: the same branch on ops.fork_stream (its backward then runs there as well); train_step joins it
+            fork = ops.fork_stream(imgs.device)
+        elif FORK_DEEP and tail and not torch.is_grad_enabled() and imgs.is_cuda:
             fork = getattr(self, "_fork", None)
             if fork is None or fork.device != imgs.device:
                 fork = torch.cuda.Stream(device=imgs.device, priority=FORK_PRIORITY)
                 object.__setattr__(self, "_fork", fork)
-        if fork is not None and FORK_CNN:
+        if fork is not None and FORK_CNN and not torch.is_grad_enabled():
             # ... and the GMFlow CNN on a third branch from the start, beside PVT stages 1-2
             cur = torch.cuda.current_stream()
             fork2 = getattr(self, "_fork2", None)
@@ -244,6 +262,7 @@ class CoUpdater(EmipModule):
             cc = self.run_conv_corr(corr)
         if not tail:
             self.last = dict(fea=fea, gm=gm, ab=ab, corr=corr, conv_corr=cc)
+            self._release_graph()
             return None, preds
         fea_new = self.injector1.run(fea[0][:B], cc)
         f1 = self.dr1.run(fea_new)
@@ -253,7 +272,16 @@ class CoUpdater(EmipModule):
         f3 = self.dr3.run(fea[2][:B])
         mask = self.decoder.run(f3, f2, f1)
         self.last = dict(fea=fea, gm=gm, ab=ab, corr=corr, conv_corr=cc, inj1=fea_new, dr=(f1, f2, f3))
+        self._release_graph()
         return mask, preds
+
+    def _release_graph(self):
+        """the kept intermediates (`.last`: values for parity checks) must not hold the autograd graph of a training forward:
+        a graph that outlives its step keeps every parameter's AccumulateGrad node, and those remember the stream they were
+        created under -- the next step on another stream (a capture stream, train.GraphedTrainStep) would be ordered against it"""
+        if torch.is_grad_enabled():
+            self.last = _detach_tree(self.last)
+            self.GMFlow.last = _detach_tree(self.GMFlow.last)
 
     def forward(self, image1, image2):
         B = image1.shape[0]

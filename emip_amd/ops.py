@@ -61,6 +61,9 @@ class GradArena:
         if self.need and (self.buf is None or self.buf.numel() < self.need or self.buf.device != torch.device(device)):
             self.buf = torch.empty(self.need + (self.need >> 4), dtype=torch.float32, device=device)
         self.limit = min(self.need, self.buf.numel()) if self.buf is not None else 0
+        dev = torch.device(device)
+        if dev.type == "cuda":
+            STEP_STREAM[dev.index if dev.index is not None else torch.cuda.current_device()] = torch.cuda.current_stream(dev)
         if self.limit:
             self.buf[:self.limit].zero_()
         self.cursor, self.need, self.active = 0, 0, True
@@ -107,6 +110,8 @@ class WgradQueue:
 
     def __init__(self):
         self.items, self.enabled = [], True
+        self.streams = {}               # raw handle -> torch stream of every stream that queued an item since the last flush
+        self.capture_pool = None        # pinned staging buffers handed in for a hipGraph capture (train.GraphedTrainStep)
         self.stage = {}
         self.owners = []                # (arena slice, parameter) of every deferred result of this step
         self.post = []                  # (packed result, parameter, unpack): convolution gradients, added to .grad by fixup()
@@ -116,6 +121,7 @@ class WgradQueue:
         # wide (256 x 320) tiles where the output shape fills them (gemm_tn16.hip), 128 x 128 otherwise (gemm_tn8.hip)
         kind = 16 if WIDE_WGRAD and _lib.load().emip_gemm_tn16_eligible(M, N, K, lda, ldb) else 8
         self.items.append((a, b, c, db, M, N, K, lda, ldb, kind, None))
+        self._note_stream(a)
         self.owners += [(t, p) for t, p in owners if t is not None and p is not None]
         if len(self.items) >= self.MAX:
             self.flush()
@@ -124,15 +130,25 @@ class WgradQueue:
         B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad = cv
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
         self.items.append((dy, x, dw, db, B * Ho * Wo, Cout, kh * kw * Cin, lddy, ldx, 16, cv))
+        self._note_stream(dy)
         self.post.append((dw, param, unpack))
         if db is not None and bias_param is not None:
             self.owners.append((db, bias_param))
         if len(self.items) >= self.MAX:
             self.flush()
 
+    def _note_stream(self, t):
+        """the stream an item's operands were produced on (backward nodes run on the stream of their forward: with PVT stages
+        3-4 on a forked stream, model.FORK_DEEP_TRAIN, the queue collects items from two streams)"""
+        if t.is_cuda:
+            h = _stream()
+            if h not in self.streams:
+                self.streams[h] = torch.cuda.current_stream(t.device)
+
     def reset(self):
         """drop everything queued or registered (the exception path of a training step): no launch, no gradient touched"""
         self.items, self.owners, self.post = [], [], []
+        self.streams = {}
 
     def fixup(self, params=None):
         """A deferred result is written into its arena slice AFTER autograd has taken that (still zero) slice as the
@@ -174,24 +190,34 @@ class WgradQueue:
         if not self.items:
             return
         items, self.items = self.items, []
+        streams, self.streams = self.streams, {}
+        if items[0][0].is_cuda:
+            # the grouped launch runs on the CURRENT stream and reads operands other streams may have produced: wait for those
+            # streams (everything they hold so far, which includes the producers: add() runs behind them), and tell the
+            # allocator that this stream reads the operands (they are released right after the launch is enqueued)
+            here = _stream()
+            foreign = [st for h, st in streams.items() if h != here]
+            if foreign:
+                cur = torch.cuda.current_stream(items[0][0].device)
+                for st in foreign:
+                    cur.wait_stream(st)
+                for it in items:
+                    it[0].record_stream(cur)
+                    it[1].record_stream(cur)
         for kind in (8, 16):
             sel = [it for it in items if it[9] == kind]
             if sel:
                 self._launch(sel, kind)
 
-    def _launch(self, items, kind):
+    def capture_buffers(self, n):
+        """n pinned buffers, each large enough for the record table of one flush of either kind"""
         lib = _lib.load()
-        rs = lib.emip_gemm_tn8_group_recsize() if kind == 8 else lib.emip_gemm_tn16_recsize()
-        dev = items[0][0].device
-        # The records go to the device through one of two pinned staging buffers and a non-blocking copy: a pageable .to()
-        # is stream-ordered AND blocking, i.e. it stalls the host until the GPU has caught up (5 ms per flush, measured).
-        st = self.stage.get(kind)
-        if st is None or st[0][0].numel() < rs * self.MAX:
-            st = self.stage[kind] = [[torch.empty(rs * self.MAX, dtype=torch.uint8).pin_memory() for _ in range(2)], [None, None], 0]
-        k = st[2] = st[2] ^ 1
-        if st[1][k] is not None:
-            st[1][k].synchronize()                 # the copy that read this buffer two flushes ago (long done)
-        host = st[0][k]
+        rs = max(lib.emip_gemm_tn8_group_recsize(), lib.emip_gemm_tn16_recsize())
+        return [torch.empty(rs * self.MAX, dtype=torch.uint8).pin_memory() for _ in range(n)]
+
+    @staticmethod
+    def _plan(lib, items, kind, host, rs):
+        """the work-item records of one grouped launch, written into the pinned buffer `host`; returns the item count"""
         total = 0
         for i, (a, b, c, db, M, N, K, lda, ldb, _, cv) in enumerate(items):
             rec = host.data_ptr() + i * rs
@@ -204,6 +230,34 @@ class WgradQueue:
             if n <= 0:
                 raise _lib.EmipLibraryError("weight-gradient plan (%d) failed for %r" % (kind, (M, N, K, lda, ldb, cv)))
             total += n
+        return total
+
+    def _launch(self, items, kind):
+        lib = _lib.load()
+        rs = lib.emip_gemm_tn8_group_recsize() if kind == 8 else lib.emip_gemm_tn16_recsize()
+        dev = items[0][0].device
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            # inside a hipGraph capture: the table goes through a pinned buffer that belongs to the graph's owner (the copy node
+            # reads it on every replay; the operand addresses in it are the graph pool's and do not change), no events
+            if not self.capture_pool:
+                raise _lib.EmipLibraryError("weight-gradient flush inside a graph capture without a staging buffer "
+                                            "(WgradQueue.capture_pool: see train.GraphedTrainStep)")
+            host = self.capture_pool.pop()
+            total = self._plan(lib, items, kind, host, rs)
+            table = torch.empty(rs * len(items), dtype=torch.uint8, device=dev)
+            table.copy_(host[:rs * len(items)], non_blocking=True)
+            _lib.call("emip_gemm_tn8_group" if kind == 8 else "emip_gemm_tn16_group", _p(table), len(items), total, _stream())
+            return
+        # The records go to the device through one of two pinned staging buffers and a non-blocking copy: a pageable .to()
+        # is stream-ordered AND blocking, i.e. it stalls the host until the GPU has caught up (5 ms per flush, measured).
+        st = self.stage.get(kind)
+        if st is None or st[0][0].numel() < rs * self.MAX:
+            st = self.stage[kind] = [[torch.empty(rs * self.MAX, dtype=torch.uint8).pin_memory() for _ in range(2)], [None, None], 0]
+        k = st[2] = st[2] ^ 1
+        if st[1][k] is not None:
+            st[1][k].synchronize()                 # the copy that read this buffer two flushes ago (long done)
+        host = st[0][k]
+        total = self._plan(lib, items, kind, host, rs)
         with torch.cuda.device(dev):
             table = torch.empty(rs * len(items), dtype=torch.uint8, device=dev)
             table.copy_(host[:rs * len(items)], non_blocking=True)
@@ -215,6 +269,51 @@ class WgradQueue:
 WIDE_WGRAD = True      # deferred weight gradients on the 256 x 320 tiles of gemm_tn16.hip where the shape fills them (else all on gemm_tn8)
 
 WGRADS = WgradQueue()
+
+
+FORK_STREAMS = {}       # device index -> side streams the model enqueues whole branches on (CoUpdater.run: PVT stages 3-4)
+
+
+FORK_USED = set()       # device indices whose side stream took work since the last join_forks()
+
+
+def fork_stream(device, priority=0):
+    """the side stream of `device` for a forked branch (one per device, created on first use); the caller is about to enqueue
+    on it, so the next join_forks() waits for it"""
+    dev = torch.device(device)
+    st = FORK_STREAMS.get(dev.index)
+    if st is None:
+        st = FORK_STREAMS[dev.index] = torch.cuda.Stream(device=dev, priority=priority)
+    FORK_USED.add(dev.index)
+    return st
+
+
+def step_streams(device):
+    """every stream a training step may have enqueued backward kernels on: the caller's current one and the forked branches'"""
+    dev = torch.device(device)
+    out = [torch.cuda.current_stream(dev)]
+    st = FORK_STREAMS.get(dev.index)
+    if st is not None:
+        out.append(st)
+    main = STEP_STREAM.get(dev.index)
+    if main is not None and all(main.cuda_stream != o.cuda_stream for o in out):
+        out.append(main)
+    return out
+
+
+STEP_STREAM = {}        # device index -> the stream train_step runs on (GradArena.begin notes it)
+
+
+def join_forks(device=None):
+    """the current stream waits for everything the forked branches hold so far (end of backward, before the optimizer reads the
+    gradients / the arena is cleared again / a gradient bucket leaves)"""
+    for idx in sorted(FORK_USED):
+        # only streams that took work in this step: inside a hipGraph capture a wait on a stream that is not part of the
+        # capture would tie the graph to work outside it
+        if device is None or torch.device(device).index == idx:
+            st = FORK_STREAMS[idx]
+            torch.cuda.current_stream(st.device).wait_stream(st)
+            FORK_USED.discard(idx)
 
 
 def flush_wgrads():

@@ -60,7 +60,9 @@ def test_linear_dgrad_via_transposed_pack(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,C", [(7744, 64), (1936, 128), (485, 320), (121, 512)])
+@pytest.mark.parametrize("M,C", [(7744, 64), (1936, 128), (485, 320), (121, 512),
+                                 # the > 128-channel bf16 form: 16 / 32 lanes per row, 2 / 3 vectors per lane, ragged last vector
+                                 (777, 256), (50, 384), (333, 640), (15488, 320), (19, 200)])
 def test_layernorm_backward(dtype, M, C):
     from emip_amd import ops
     x, xf = prep(rnd(M, C, seed=1) * 2 + 0.3, dtype)

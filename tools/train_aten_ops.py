@@ -20,6 +20,7 @@ class Count(TorchDispatchMode):
     def __init__(self):
         super().__init__()
         self.c = collections.Counter()
+        self.shapes = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = str(func)
@@ -30,6 +31,9 @@ class Count(TorchDispatchMode):
                     site = "%s:%s:%d" % (os.path.basename(f.filename), f.name, f.lineno)
                     break
             self.c[(name, site)] += 1
+            if name.startswith("aten.add.Tensor") or name.startswith("aten.clone") or name.startswith("aten.zeros"):
+                shp = tuple(args[0].shape) if args and hasattr(args[0], "shape") else tuple(args[0]) if args else ()
+                self.shapes[(name, site, shp)] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -62,3 +66,6 @@ for n, k in byop.most_common(30):
 print("---- by site")
 for (n, s), k in m.c.most_common(90):
     print("  %5d %-40s %s" % (k, n, s))
+print("---- add / clone / zeros by shape")
+for (n, s, shp), k in m.shapes.most_common(60):
+    print("  %5d %-28s %-36s %s" % (k, n, s, shp))
