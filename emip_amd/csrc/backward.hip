@@ -618,11 +618,11 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__
                                                            float mul) {
     const int nv = C >> 2;
     const long total = (long)B * Ho * Wo * nv;
+    const IdxDiv D(total);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int vi = (int)(idx % nv);
-        const long pix = idx / nv;
-        const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
-        const long b = pix / ((long)Wo * Ho);
+        const long pix = D.div(idx, nv), orow = D.div(pix, Wo), b = D.div(orow, Ho);
+        const int vi = (int)(idx - pix * nv);
+        const int ox = (int)(pix - orow * Wo), oy = (int)(orow - b * Ho);
         int y0, y1, x0, x1;
         float ly, lx;
         bl_src(oy, H, Ho, align, y0, y1, ly);
@@ -655,10 +655,11 @@ __global__ __launch_bounds__(256) void bilinear_planar_bwd_kernel(const float* _
     const float ay = (float)Ho / (float)H, by = H > 1 ? (float)(Ho - 1) / (float)(H - 1) : ay;
     const float ax = (float)Wo / (float)Wd, bx = Wd > 1 ? (float)(Wo - 1) / (float)(Wd - 1) : ax;
     const float invy_lo = fminf(ay, by), invy = fmaxf(ay, by), invx_lo = fminf(ax, bx), invx = fmaxf(ax, bx);
+    const IdxDiv D(total);
     for (long e = wave; e < total; e += nw) {
-        const int x = (int)(e % Wd), y = (int)((e / Wd) % H);
-        const int c = (int)((e / ((long)Wd * H)) % C);
-        const long b = e / ((long)Wd * H * C);
+        const long row = D.div(e, Wd), bc = D.div(row, H), b = D.div(bc, C);
+        const int x = (int)(e - row * Wd), y = (int)(row - bc * H);
+        const int c = (int)(bc - b * C);
         const int oy_lo = max(0, (int)floorf((float)(y - 1) * invy_lo) - 1);
         const int oy_hi = min(Ho - 1, (int)ceilf((float)(y + 2) * invy) + 1);
         const int ox_lo = max(0, (int)floorf((float)(x - 1) * invx_lo) - 1);
@@ -886,11 +887,11 @@ __global__ __launch_bounds__(256) void zero_insert_kernel(const T* __restrict__ 
                                                           int Ho, int Wo, int H, int Wd, int C, int s) {
     const int nv = C >> 2;
     const long total = (long)B * H * Wd * nv;
+    const IdxDiv D(total);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int vi = (int)(idx % nv);
-        const long pix = idx / nv;
-        const int x = (int)(pix % Wd), y = (int)((pix / Wd) % H);
-        const long b = pix / ((long)Wd * H);
+        const long pix = D.div(idx, nv), row = D.div(pix, Wd), b = D.div(row, H);
+        const int vi = (int)(idx - pix * nv);
+        const int x = (int)(pix - row * Wd), y = (int)(row - b * H);
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (y % s == 0 && x % s == 0 && y / s < Ho && x / s < Wo)
             Vec4<T>::load(DY + ((b * Ho + y / s) * (long)Wo + x / s) * lddy + vi * 4, v);
@@ -904,11 +905,11 @@ __global__ __launch_bounds__(256) void depatchify_kernel(const T* __restrict__ P
     const int nv = C >> 2;
     const int H = Ho * k, Wd = Wo * k;
     const long total = (long)B * H * Wd * nv;
+    const IdxDiv D(total);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int vi = (int)(idx % nv);
-        const long pix = idx / nv;
-        const int x = (int)(pix % Wd), y = (int)((pix / Wd) % H);
-        const long b = pix / ((long)Wd * H);
+        const long pix = D.div(idx, nv), row = D.div(pix, Wd), b = D.div(row, H);
+        const int vi = (int)(idx - pix * nv);
+        const int x = (int)(pix - row * Wd), y = (int)(row - b * H);
         const long m = (b * Ho + y / k) * Wo + x / k;
         const int tap = (y % k) * k + (x % k);
         float v[4];

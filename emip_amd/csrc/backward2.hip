@@ -97,11 +97,12 @@ __global__ __launch_bounds__(256) void convex_up_bwd_kernel(const T* __restrict_
                                                             T* __restrict__ DL, long lddl, float* __restrict__ DF, int N,
                                                             int H, int Wd) {
     const long total = (long)N * H * Wd * 64;
+    const IdxDiv D(total);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const int ij = (int)(idx & 63);
         const long pix = idx >> 6;
-        const int x = (int)(pix % Wd), y = (int)((pix / Wd) % H);
-        const long n = pix / ((long)Wd * H);
+        const long row = D.div(pix, Wd), n = D.div(row, H);
+        const int x = (int)(pix - row * Wd), y = (int)(row - n * H);
         const int i = ij >> 3, j = ij & 7;
         const long Ho = 8L * H, Wo = 8L * Wd;
         const long o = (n * 2 * Ho + (8L * y + i)) * Wo + 8L * x + j;
@@ -196,10 +197,10 @@ __global__ __launch_bounds__(256) void photometric_bwd1_kernel(const float* __re
                                                                int B, int C, int H, int W) {
     const long hw = (long)H * W;
     const long total = (long)B * C * hw;
+    const IdxDiv D(total);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % W), y = (int)((idx / W) % H);
-        const long bc = idx / hw;
-        const long b = bc / C;
+        const long row = D.div(idx, W), bc = D.div(row, H), b = D.div(bc, C);
+        const int x = (int)(idx - row * W), y = (int)(row - bc * H);
         float A = 0.f, Bq = 0.f, Cq = 0.f;
         if (y >= 1 && y < H - 1 && x >= 1 && x < W - 1) {
             const float* im = IM + bc * hw;
@@ -248,10 +249,10 @@ __global__ __launch_bounds__(256) void photometric_bwd2_kernel(const float* __re
     const float inv_mmean = (float)((double)B * hw / sums[2]);
     const float cl1 = 0.15f / (float)total * inv_mmean * weight * gout[0];
     const float cs = 0.85f / (float)((double)B * C * (H - 2) * (W - 2)) * inv_mmean * weight * gout[0];
+    const IdxDiv D(total);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % W), y = (int)((idx / W) % H);
-        const long bc = idx / hw;
-        const long b = bc / C;
+        const long row = D.div(idx, W), bc = D.div(row, H), b = D.div(bc, C);
+        const int x = (int)(idx - row * W), y = (int)(row - bc * H);
         const long o = (long)y * W + x;
         const float m = MK[b * hw + o];
         const float a = REC[bc * hw + o] * m, bb = IM[bc * hw + o] * m;
@@ -279,9 +280,10 @@ __global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const float* __restr
                                                             int C, int H, int W) {
     const long hw = (long)H * W;
     const long total = (long)B * hw;
+    const IdxDiv D(total);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % W), y = (int)((idx / W) % H);
-        const long b = idx / hw;
+        const long row = D.div(idx, W), b = D.div(row, H);
+        const int x = (int)(idx - row * W), y = (int)(row - b * H);
         const float vx = (float)x + F[(b * 2) * hw + (long)y * W + x];
         const float vy = (float)y + F[(b * 2 + 1) * hw + (long)y * W + x];
         const float gx = 2.0f * vx / (float)(W - 1) - 1.0f, gy = 2.0f * vy / (float)(H - 1) - 1.0f;

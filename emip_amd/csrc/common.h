@@ -179,3 +179,16 @@ static inline int emip_zero_async(void* ptr, size_t bytes, hipStream_t s) {
     hipLaunchKernelGGL(emip_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<unsigned*>(ptr), nwords);
     return emip_launch_status();
 }
+
+// Index arithmetic of the grid-stride loops over planar / channels-last tensors.  A 64-bit division costs ~150 VALU
+// instructions on gfx950 (no hardware divider, wave64 on 16-lane SIMDs): `x = idx % W, y = idx / W % H, b = idx / (H * W)`
+// written with `long` made the loss kernels VALU-bound (flow_warp: 181 us for 127 MB at batch 32).  IdxDiv divides in 32 bits
+// whenever the loop's extent allows it (a wave-uniform choice made once per kernel) and the callers chain quotients
+// (idx / W, then that / H) instead of dividing idx three times.
+struct IdxDiv {
+    bool small;
+    __device__ __forceinline__ explicit IdxDiv(long total) : small(total < (1L << 31)) {}
+    __device__ __forceinline__ long div(long n, long d) const {
+        return small ? (long)((unsigned)n / (unsigned)d) : n / d;
+    }
+};

@@ -19,9 +19,10 @@ __global__ __launch_bounds__(256) void flow_warp_kernel(const float* __restrict_
                                                         float* __restrict__ Y, int B, int C, int H, int W) {
     const long hw = (long)H * W;
     const long total = (long)B * hw;
+    const IdxDiv D(total);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % W), y = (int)((idx / W) % H);
-        const long b = idx / hw;
+        const long row = D.div(idx, W), b = D.div(row, H);
+        const int x = (int)(idx - row * W), y = (int)(row - b * H);
         const float vx = (float)x + F[(b * 2) * hw + (long)y * W + x];
         const float vy = (float)y + F[(b * 2 + 1) * hw + (long)y * W + x];
         // norm_grid, then ATen's grid_sampler unnormalize (align_corners) + border clip
@@ -269,10 +270,11 @@ __global__ __launch_bounds__(256) void photometric_kernel(const float* __restric
     const long hw = (long)H * W;
     const long total = (long)B * C * hw;
     double l1 = 0, ss = 0, ms = 0;
+    const IdxDiv D(total);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int x = (int)(idx % W), y = (int)((idx / W) % H);
-        const int c = (int)((idx / hw) % C);
-        const long b = idx / (hw * C);
+        const long row = D.div(idx, W), bc = D.div(row, H), b = D.div(bc, C);
+        const int x = (int)(idx - row * W), y = (int)(row - bc * H);
+        const int c = (int)(bc - b * C);
         const float* im = IM + (b * C + c) * hw;
         const float* rc = REC + (b * C + c) * hw;
         const float* mk = MK + b * hw;

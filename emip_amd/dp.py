@@ -239,7 +239,12 @@ class GradReducer:
         self._ensure(dev)
         from . import ops
         if ref.is_cuda:
-            ops.flush_wgrads()              # weight gradients the step has deferred must be on the compute stream first
+            ops.flush_wgrads()              # weight gradients the step has deferred must be on their compute streams first
+            # ... each queue was launched on its own stream (ops.WgradQueue): fixup() adds convolution gradients on THIS one
+            cur = torch.cuda.current_stream(dev)
+            for st in ops.step_streams(dev):
+                if st.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(st)
             ops.WGRADS.fixup(b.params)      # ... and be what these parameters' .grad holds
         side = self._stream(dev)
         if side is not None:

@@ -28,6 +28,14 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+class _nullcontext:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
 def _dev(t):
     if not t.is_cuda:
         raise _lib.EmipLibraryError("emip_amd ops need device tensors (there is no CPU path)")
@@ -104,51 +112,60 @@ class WgradQueue:
     queued to ONE grouped launch (emip_gemm_tn8_group: thousands of work items, no launch short of tiles, m splits only to
     bound the item length).  The operands (dY, X) stay alive until then -- a few GB at batch 32 on a 288-GB device.
     Flush points: the end of backward (train_step), before a gradient bucket leaves for its all-reduce (GradReducer), and
-    whenever MAX problems are waiting."""
+    whenever MAX problems are waiting.
+
+    One queue PER STREAM: an item waits in the queue of the stream its backward node ran on and is launched there.  With PVT
+    stages 3-4 on a forked stream (model.FORK_DEEP_TRAIN) the grouped launch of that branch's ~250 weight gradients then
+    depends on that branch only -- in the captured step it runs beside the backward of stages 1-2 instead of behind it --
+    and no launch reads operands another stream produced."""
 
     MAX = 160
 
     def __init__(self):
-        self.items, self.enabled = [], True
-        self.streams = {}               # raw handle -> torch stream of every stream that queued an item since the last flush
+        self.queues, self.enabled = {}, True    # raw stream handle -> [torch stream or None (host tensors), items]
         self.capture_pool = None        # pinned staging buffers handed in for a hipGraph capture (train.GraphedTrainStep)
         self.stage = {}
         self.owners = []                # (arena slice, parameter) of every deferred result of this step
         self.post = []                  # (packed result, parameter, unpack): convolution gradients, added to .grad by fixup()
         self.fixed = 0                  # results fixup() had to add by hand (diagnostics / tests)
 
+    @property
+    def items(self):
+        """everything waiting, whatever its stream"""
+        return [it for _, q in self.queues.values() for it in q]
+
+    def _queue(self, t):
+        if not t.is_cuda:
+            return self.queues.setdefault(0, [None, []])
+        h = _stream()
+        q = self.queues.get(h)
+        if q is None:
+            q = self.queues[h] = [torch.cuda.current_stream(t.device), []]
+        return q
+
     def add(self, a, b, c, db, M, N, K, lda, ldb, owners=()):
         # wide (256 x 320) tiles where the output shape fills them (gemm_tn16.hip), 128 x 128 otherwise (gemm_tn8.hip)
         kind = 16 if WIDE_WGRAD and _lib.load().emip_gemm_tn16_eligible(M, N, K, lda, ldb) else 8
-        self.items.append((a, b, c, db, M, N, K, lda, ldb, kind, None))
-        self._note_stream(a)
+        q = self._queue(a)
+        q[1].append((a, b, c, db, M, N, K, lda, ldb, kind, None))
         self.owners += [(t, p) for t, p in owners if t is not None and p is not None]
-        if len(self.items) >= self.MAX:
-            self.flush()
+        if len(q[1]) >= self.MAX:
+            self._flush_queue(q)
 
     def add_conv(self, dy, x, dw, db, cv, param, unpack, bias_param=None):
         B, H, W, Cin, ldx, Cout, lddy, kh, kw, stride, pad = cv
         Ho, Wo = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
-        self.items.append((dy, x, dw, db, B * Ho * Wo, Cout, kh * kw * Cin, lddy, ldx, 16, cv))
-        self._note_stream(dy)
+        q = self._queue(dy)
+        q[1].append((dy, x, dw, db, B * Ho * Wo, Cout, kh * kw * Cin, lddy, ldx, 16, cv))
         self.post.append((dw, param, unpack))
         if db is not None and bias_param is not None:
             self.owners.append((db, bias_param))
-        if len(self.items) >= self.MAX:
-            self.flush()
-
-    def _note_stream(self, t):
-        """the stream an item's operands were produced on (backward nodes run on the stream of their forward: with PVT stages
-        3-4 on a forked stream, model.FORK_DEEP_TRAIN, the queue collects items from two streams)"""
-        if t.is_cuda:
-            h = _stream()
-            if h not in self.streams:
-                self.streams[h] = torch.cuda.current_stream(t.device)
+        if len(q[1]) >= self.MAX:
+            self._flush_queue(q)
 
     def reset(self):
         """drop everything queued or registered (the exception path of a training step): no launch, no gradient touched"""
-        self.items, self.owners, self.post = [], [], []
-        self.streams = {}
+        self.queues, self.owners, self.post = {}, [], []
 
     def fixup(self, params=None):
         """A deferred result is written into its arena slice AFTER autograd has taken that (still zero) slice as the
@@ -187,27 +204,22 @@ class WgradQueue:
             raise _lib.EmipLibraryError("a deferred weight gradient has no parameter .grad to live in")
 
     def flush(self):
-        if not self.items:
+        """every queue, each on its own stream"""
+        queues, self.queues = self.queues, {}
+        for q in queues.values():
+            self._flush_queue(q)
+
+    def _flush_queue(self, q):
+        st, items = q
+        if not items:
             return
-        items, self.items = self.items, []
-        streams, self.streams = self.streams, {}
-        if items[0][0].is_cuda:
-            # the grouped launch runs on the CURRENT stream and reads operands other streams may have produced: wait for those
-            # streams (everything they hold so far, which includes the producers: add() runs behind them), and tell the
-            # allocator that this stream reads the operands (they are released right after the launch is enqueued)
-            here = _stream()
-            foreign = [st for h, st in streams.items() if h != here]
-            if foreign:
-                cur = torch.cuda.current_stream(items[0][0].device)
-                for st in foreign:
-                    cur.wait_stream(st)
-                for it in items:
-                    it[0].record_stream(cur)
-                    it[1].record_stream(cur)
-        for kind in (8, 16):
-            sel = [it for it in items if it[9] == kind]
-            if sel:
-                self._launch(sel, kind)
+        q[1] = []
+        ctx = torch.cuda.stream(st) if st is not None else _nullcontext()
+        with ctx:
+            for kind in (8, 16):
+                sel = [it for it in items if it[9] == kind]
+                if sel:
+                    self._launch(sel, kind)
 
     def capture_buffers(self, n):
         """n pinned buffers, each large enough for the record table of one flush of either kind"""

@@ -52,8 +52,8 @@ def forward_backward(model, image1, image2, gts):
             loss_flow = _flow_loss.compute_loss(flow_pair, image_pair)[0]
             loss = loss_pred + loss_flow
             loss.backward()
-            ops.join_forks(image1.device)       # backward kernels of a forked branch (model.FORK_DEEP_TRAIN) before anything reads gradients
-            ops.flush_wgrads()                  # the Linear weight gradients backward deferred, as one grouped launch
+            ops.flush_wgrads()                  # the weight gradients backward deferred: one grouped launch per kind and stream
+            ops.join_forks(image1.device)       # the forked branch (model.FORK_DEEP_TRAIN) before anything reads gradients
         failed = False
     finally:
         ops.ARENA.end(failed)               # on an exception: the deferred queue is dropped, the original error propagates
@@ -112,7 +112,7 @@ class GraphedTrainStep:
         torch.cuda.synchronize(dev)
         # pinned staging buffers for the record tables of the captured weight-gradient flushes (no host allocation, event or
         # synchronisation may happen inside a capture); the graph's copy nodes read them on every replay
-        self._hosts = ops.WGRADS.capture_buffers(8)
+        self._hosts = ops.WGRADS.capture_buffers(16)
         ops.WGRADS.capture_pool = list(self._hosts)
         self.graph = torch.cuda.CUDAGraph()
         try:

@@ -42,9 +42,12 @@ def _rel(a, b):
 def _check(got, ref, again):
     """`got` against `ref`, every gradient within 8 x what two eager runs of the same pass differ by (`again` vs `ref`: the
     weight- and bias-gradient reductions add in f32 with atomics; gradients that are zero in exact arithmetic -- a bias in
-    front of a BatchNorm -- are ALL rounding noise, hence the per-tensor yardstick) or 1e-5"""
+    front of a BatchNorm -- are ALL rounding noise, hence the per-tensor yardstick) or 2e-3 of the tensor's largest entry (one
+    pair of runs underestimates the spread of a 60 000-term f32 sum whose order changes with what runs beside it: the decoder's
+    gradients repeat to 3e-6 back to back and move by 3e-4 when another stream shares the chip; a missing ordering between
+    streams shows as O(1) differences, not as this)"""
     noise, d = _rel(again, ref), _rel(got, ref)
-    bad = {n: (d[n], noise[n]) for n in d if d[n] > max(8 * noise[n], 1e-5)}
+    bad = {n: (d[n], noise[n]) for n in d if d[n] > max(8 * noise[n], 2e-3)}
     med = lambda v: sorted(v)[len(v) // 2]
     return (med(list(d.values())), med(list(noise.values()))), bad, max((d[n] / max(noise[n], 1e-7), n) for n in d)
 
@@ -148,8 +151,16 @@ def test_graphed_training_follows_the_eager_trajectory(model_args, short_sd, bf1
             de = max(de, (p.detach() - pc[n].detach()).abs().max().item())
     print("largest parameter change %.2e; eager vs graphed %.2e, eager vs eager %.2e" % (moved, dg, de))
     assert moved > 0 and dg <= 2 * de + 1e-7
-    # a stale pack would freeze what the kernels see: the graphed model's loss must move like the eager one's
-    assert abs((lb[-1][0] - lb[0][0]) - (la[-1][0] - la[0][0])) <= 0.5 * abs(la[-1][0] - la[0][0]) + 1e-3
+    # the weight packs the captured kernels read ARE the current weights: the replayed forward on the trained model gives the
+    # loss the eager forward gives, bit for bit (DropPath off, and the bf16 forward is reproducible); a pack that only the
+    # eager path rebuilds would be stale inside the graph and show here
+    assert lb[1] != lb[0]
+    lg = [float(x) for x in gs.replay()]
+    ob.zero_grad(set_to_none=True)
+    from emip_amd.train import forward_backward
+    le = [float(x) for x in forward_backward(b, im1, im2, gt)]
+    print("after four steps: replayed forward", lg, "eager forward", le)
+    assert lg == le
 
 
 def test_graphed_step_with_stochastic_depth_draws_new_factors(model_args, short_sd, bf16):
