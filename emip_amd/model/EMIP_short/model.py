@@ -48,6 +48,9 @@ FORK_CNN = False        # with FORK_DEEP: the GMFlow CNN on a third branch besid
 # backward on the stream of its forward, so the backward of those 43 blocks runs beside the backward of the GMFlow half as well.
 # The deferred weight-gradient queue (ops.WgradQueue.flush) and the end of the step (train.train_step) order the two streams.
 FORK_DEEP_TRAIN = True
+# Two more branches were measured inside the captured step and bought nothing (61.55 ms with this fork alone; 61.51 with the frozen
+# GMFlow CNN on a third stream beside PVT stages 1-2, 61.87 with unFlowLoss forward + backward on a side stream, 61.53 with both;
+# tools/train_graph_ab.py, round 4): they are not in the code.
 
 def _detach_tree(v):
     """the same nest of dicts / lists / tuples with every tensor detached"""

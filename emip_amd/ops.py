@@ -283,20 +283,19 @@ WIDE_WGRAD = True      # deferred weight gradients on the 256 x 320 tiles of gem
 WGRADS = WgradQueue()
 
 
-FORK_STREAMS = {}       # device index -> side streams the model enqueues whole branches on (CoUpdater.run: PVT stages 3-4)
+FORK_STREAMS = {}       # (device index, name) -> side streams the model enqueues whole branches on (CoUpdater.run: PVT stages 3-4, ...)
+FORK_USED = set()       # keys of FORK_STREAMS that took work since the last join_forks()
 
 
-FORK_USED = set()       # device indices whose side stream took work since the last join_forks()
-
-
-def fork_stream(device, priority=0):
-    """the side stream of `device` for a forked branch (one per device, created on first use); the caller is about to enqueue
-    on it, so the next join_forks() waits for it"""
+def fork_stream(device, priority=0, name="deep"):
+    """the side stream `name` of `device` for a forked branch (created on first use); the caller is about to enqueue on it, so
+    the next join_forks() waits for it"""
     dev = torch.device(device)
-    st = FORK_STREAMS.get(dev.index)
+    key = (dev.index, name)
+    st = FORK_STREAMS.get(key)
     if st is None:
-        st = FORK_STREAMS[dev.index] = torch.cuda.Stream(device=dev, priority=priority)
-    FORK_USED.add(dev.index)
+        st = FORK_STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
+    FORK_USED.add(key)
     return st
 
 
@@ -304,9 +303,9 @@ def step_streams(device):
     """every stream a training step may have enqueued backward kernels on: the caller's current one and the forked branches'"""
     dev = torch.device(device)
     out = [torch.cuda.current_stream(dev)]
-    st = FORK_STREAMS.get(dev.index)
-    if st is not None:
-        out.append(st)
+    for (idx, _), st in FORK_STREAMS.items():
+        if idx == dev.index:
+            out.append(st)
     main = STEP_STREAM.get(dev.index)
     if main is not None and all(main.cuda_stream != o.cuda_stream for o in out):
         out.append(main)
@@ -319,13 +318,13 @@ STEP_STREAM = {}        # device index -> the stream train_step runs on (GradAre
 def join_forks(device=None):
     """the current stream waits for everything the forked branches hold so far (end of backward, before the optimizer reads the
     gradients / the arena is cleared again / a gradient bucket leaves)"""
-    for idx in sorted(FORK_USED):
+    for key in sorted(FORK_USED):
         # only streams that took work in this step: inside a hipGraph capture a wait on a stream that is not part of the
         # capture would tie the graph to work outside it
-        if device is None or torch.device(device).index == idx:
-            st = FORK_STREAMS[idx]
+        if device is None or torch.device(device).index == key[0]:
+            st = FORK_STREAMS[key]
             torch.cuda.current_stream(st.device).wait_stream(st)
-            FORK_USED.discard(idx)
+            FORK_USED.discard(key)
 
 
 def flush_wgrads():

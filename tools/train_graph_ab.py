@@ -59,5 +59,5 @@ for rnd in range(4):
         last[k] = [round(float(x), 4) for x in loss]
 for k, _ in modes:
     xs = res[k]
-    print("%-14s ms/step: %s   median %.2f  (%.1f pairs/s)  loss %s" % (k, " ".join("%.2f" % x for x in xs), sorted(xs)[len(xs) // 2],
+    print("%-26s ms/step: %s   median %.2f  (%.1f pairs/s)  loss %s" % (k, " ".join("%.2f" % x for x in xs), sorted(xs)[len(xs) // 2],
                                                                       B / sorted(xs)[len(xs) // 2] * 1e3, last[k]), flush=True)
