@@ -48,6 +48,7 @@ FORK_CNN = False        # with FORK_DEEP: the GMFlow CNN on a third branch besid
 # backward on the stream of its forward, so the backward of those 43 blocks runs beside the backward of the GMFlow half as well.
 # The deferred weight-gradient queue (ops.WgradQueue.flush) and the end of the step (train.train_step) order the two streams.
 FORK_DEEP_TRAIN = True
+FORK_TRAIN_PRIORITY = 0     # HIP stream priority of that branch (-1 = high)
 # Two more branches were measured inside the captured step and bought nothing (61.55 ms with this fork alone; 61.51 with the frozen
 # GMFlow CNN on a third stream beside PVT stages 1-2, 61.87 with unFlowLoss forward + backward on a side stream, 61.53 with both;
 # tools/train_graph_ab.py, round 4): they are not in the code.
@@ -222,7 +223,7 @@ class CoUpdater(EmipModule):
         fork = None
         if FORK_DEEP_TRAIN and tail and torch.is_grad_enabled() and self.training and imgs.is_cuda:
             # training step: the same branch on ops.fork_stream (its backward then runs there as well); train_step joins it
-            fork = ops.fork_stream(imgs.device)
+            fork = ops.fork_stream(imgs.device, priority=FORK_TRAIN_PRIORITY, name="deep%d" % FORK_TRAIN_PRIORITY)
         elif FORK_DEEP and tail and not torch.is_grad_enabled() and imgs.is_cuda:
             fork = getattr(self, "_fork", None)
             if fork is None or fork.device != imgs.device:

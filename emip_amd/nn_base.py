@@ -43,13 +43,18 @@ _REC = None            # list while a builder runs under packed(): (src, dst, di
 _REFRESHABLE = {}      # (id(module), cache key) -> weakref(module): the packs die with their module (a strong reference
                        # here kept every discarded model's bf16 / f32 packs in GPU memory for the life of the process)
 _TABLE = {}            # device -> (key, recs tensor, blockmap tensor, nblocks)
+# Packs of TRAINABLE parameters that are not plain permutations (the mask head's weight padded to 8 output rows, ...): the
+# eager forward rebuilds them on first use after an optimizer step -- into NEW tensors.  A captured training step
+# (train.GraphedTrainStep) has no Python forward and holds the OLD addresses: it would train against a frozen copy.
+# refresh_packs() therefore rebuilds these through their builder and copies the result INTO the existing tensors.
+_REBUILD = {}          # (id(module), cache key) -> weakref(module)
 
 
 class _Entry:
-    __slots__ = ("sig", "val", "recs", "tensors", "mode")
+    __slots__ = ("sig", "val", "recs", "tensors", "mode", "builder")
 
-    def __init__(self, sig, val, recs, tensors, mode):
-        self.sig, self.val, self.recs, self.tensors, self.mode = sig, val, recs, tensors, mode
+    def __init__(self, sig, val, recs, tensors, mode, builder=None):
+        self.sig, self.val, self.recs, self.tensors, self.mode, self.builder = sig, val, recs, tensors, mode, builder
 
 
 def _record(src, dst, dims, strides, base=0, valid3=None, scale=1.0):
@@ -122,6 +127,53 @@ def refresh_packs():
             _lib.call("emip_repack", hit[1].data_ptr(), hit[2].data_ptr(), hit[3], torch.cuda.current_stream(dev).cuda_stream)
         for e in ents:
             e.sig = tuple((t.data_ptr(), t._version, t.device) for t in e.tensors) + e.mode
+    _rebuild_in_place()
+
+
+def _rebuild_in_place():
+    """the non-refreshable packs of trainable parameters: builder again, result copied into the tensors the entry already holds
+    (same addresses: a captured graph keeps reading current weights); an entry whose builder now returns another structure
+    is left to the rebuild-on-version-change path"""
+    global _REC
+    for rk, ref in list(_REBUILD.items()):
+        m = ref()
+        e = m._pack_cache.get(rk[1]) if m is not None else None
+        if e is None or e.recs is not None or e.builder is None:
+            del _REBUILD[rk]
+            continue
+        if not any(t.requires_grad for t in e.tensors) or not e.tensors[0].is_cuda:
+            continue
+        sig = tuple((t.data_ptr(), t._version, t.device) for t in e.tensors) + e.mode
+        if sig == e.sig:
+            continue
+        prev, _REC = _REC, []
+        try:
+            with torch.no_grad():
+                new = e.builder(*e.tensors)
+        finally:
+            _REC = prev
+        try:
+            old_t, new_t = _flat_tensors(e.val, []), _flat_tensors(new, [])
+        except TypeError:
+            continue
+        if len(old_t) != len(new_t) or any(o.shape != n.shape or o.dtype != n.dtype for o, n in zip(old_t, new_t)):
+            continue
+        with torch.no_grad():
+            for o, n in zip(old_t, new_t):
+                if o.data_ptr() != n.data_ptr():
+                    o.copy_(n)
+        e.sig = sig
+
+
+def packs_not_kept_current(model):
+    """(module name, cache key) of every pack of a trainable parameter that neither refresh path keeps current in place --
+    what a captured training step would read stale.  Empty for the EMIP modules (tests/test_train_graph_gpu.py)."""
+    out = []
+    for name, m in model.named_modules():
+        for key, e in getattr(m, "_pack_cache", {}).items():
+            if any(t.requires_grad for t in e.tensors) and e.recs is None and (id(m), key) not in _REBUILD:
+                out.append((name, key))
+    return out
 
 
 class EmipModule(nn.Module):
@@ -158,10 +210,12 @@ class EmipModule(nn.Module):
             ok = all(o.data_ptr() in dsts or o.untyped_storage().data_ptr() in srcs for o in _flat_tensors(val, []))
         except TypeError:
             ok = False
-        ent = _Entry(sig, val, recs if ok else None, tuple(tensors), mode)
+        ent = _Entry(sig, val, recs if ok else None, tuple(tensors), mode, builder)
         self._pack_cache[key] = ent
         if ok:
             _REFRESHABLE[(id(self), key)] = weakref.ref(self)
+        elif any(t.requires_grad for t in tensors):
+            _REBUILD[(id(self), key)] = weakref.ref(self)
         return val
 
     def _apply(self, fn, *a, **k):  # .to()/.cuda(): drop packed copies living on the old device

@@ -158,6 +158,8 @@ def test_graphed_training_follows_the_eager_trajectory(model_args, short_sd, bf1
     # loss the eager forward gives, bit for bit (DropPath off, and the bf16 forward is reproducible); a pack that only the
     # eager path rebuilds would be stale inside the graph and show here
     assert lb[1] != lb[0]
+    from emip_amd import nn_base
+    assert nn_base.packs_not_kept_current(b) == []
     lg = [float(x) for x in gs.replay()]
     ob.zero_grad(set_to_none=True)
     from emip_amd.train import forward_backward

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof/bench -- python3 $root/bench.py --no-cpu-baseline --no-sub > $out/prof_bench.log 2>&1
 f=$(find $out/prof/bench -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/${tag}_bench_kernel_stats.csv
 echo "bench stats: $f"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof/train -- python3 $root/bench.py --workload train --steps 17 --warmup 3 > $out/prof_train.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof/train -- python3 $root/bench.py --workload train --train-eager --steps 17 --warmup 3 > $out/prof_train.log 2>&1
 f=$(find $out/prof/train -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/${tag}_train_kernel_stats.csv
 echo "train stats: $f"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/prof/fetch -- python3 $root/bench.py --no-graph --streams 1 --steps 2 --warmup 1 --no-cpu-baseline --no-sub > $out/prof_fetch.log 2>&1
