@@ -203,9 +203,9 @@ def kernel_breakdown(net, im1, im2, splits=1):
     return agg
 
 
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r04_bench_kernel_stats.csv")
-if not os.path.exists(PROFILE_CSV):
-    PROFILE_CSV = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")
+PROFILE_CSV = next((f for f in (os.path.join(ROOT, "profiles", n) for n in (
+    "r04b_bench_kernel_stats.csv", "r04_bench_kernel_stats.csv", "r03_bench_kernel_stats.csv")) if os.path.exists(f)),
+    os.path.join(ROOT, "profiles", "r04b_bench_kernel_stats.csv"))
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 # algorithmic (compulsory) HBM bytes of one 16-pair step, SURVEY.md section 8(d): 18 MB per pair + the 213 MB of bf16 weights once;
 # 15 of the 18 MB were the correlation volume (written by the matching, read by conv_corr), which the product path no longer
@@ -1088,11 +1088,11 @@ def main():
                 # the graphed training step in a process of its own: a capture that goes wrong ends in the runtime, not in a
                 # Python exception, and must not take the headline with it
                 import subprocess
-                out = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "train", "--steps", "6",
-                                      "--warmup", "4"], capture_output=True, text=True, timeout=600)
-                lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
-                if out.returncode != 0 or not lines:
-                    raise RuntimeError("train sub-record: exit %d: %s" % (out.returncode, out.stderr[-200:]))
+                proc = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "train", "--steps", "6",
+                                       "--warmup", "4"], capture_output=True, text=True, timeout=600)
+                lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+                if proc.returncode != 0 or not lines:
+                    raise RuntimeError("train sub-record: exit %d: %s" % (proc.returncode, proc.stderr[-200:]))
                 sub["train"] = json.loads(lines[-1])
             else:
                 sub["train"] = measure_train(32, 6, 4, world, rank, dev, dist, red_dev, args.dp_algo, args.dp_comm, graph=False)
