@@ -132,6 +132,10 @@ class GraphedTrainStep:
 
     def step(self, image1=None, image2=None, gts=None):
         if image1 is not None:
+            for got, buf in ((image1, self.image1), (image2, self.image2), (gts, self.gts)):
+                if got.shape != buf.shape or got.dtype != buf.dtype:
+                    raise ValueError("GraphedTrainStep was captured for %s %s, got %s %s: build a new one for another batch shape"
+                                     % (tuple(buf.shape), buf.dtype, tuple(got.shape), got.dtype))
             self.image1.copy_(image1, non_blocking=True)
             self.image2.copy_(image2, non_blocking=True)
             self.gts.copy_(gts, non_blocking=True)
