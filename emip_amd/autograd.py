@@ -104,6 +104,55 @@ class LinearFn(Function):
         return dx, dw, db, dres, None, None, None, None
 
 
+class FanOutFn(Function):
+    """(x, x W_1^T, ..., x W_k^T) for FROZEN bias-free weights: the token stream of a GMFlow transformer block feeds five
+    projections and the skip connection (transformer.py:160-190, 348-401), and autograd would sum the six gradients that come
+    back with five add launches (46 per step over the 6 blocks).  Here they meet in the residual epilogues of the
+    input-gradient GEMMs: dx = dskip + sum_i dy_i W_i, one GEMM per projection, each adding the running sum.
+    packs: (W_i packed [N, K], W_i^T packed [K, N]) per projection."""
+
+    @staticmethod
+    def forward(ctx, x, *packs):
+        ctx.wts = [wt for _, wt in packs]
+        ctx.set_materialize_grads(False)
+        return (x,) + tuple(ops.gemm(x, wp) for wp, _ in packs)
+
+    @staticmethod
+    def backward(ctx, dskip, *dys):
+        dx, own = dskip, False
+        for dy, wt in zip(dys, ctx.wts):
+            if dy is None:
+                continue
+            dy = dy.contiguous()
+            if dx is None:
+                dx, own = ops.gemm(dy, wt), True
+            elif own:
+                dx = ops.gemm(dy, wt, res=dx, out=dx)           # the running sum is this node's own tensor: in place
+            else:
+                dx, own = ops.gemm(dy, wt, res=dx.contiguous()), True     # dskip may be shared with other nodes: out of place
+        return (dx,) + (None,) * len(ctx.wts)
+
+
+class Linear2Fn(Function):
+    """y = [a | b] W^T for a FROZEN bias-free weight, without the concatenated operand: the forward GEMM walks K over the two
+    sources (emip_gemm's a2), the backward makes the two input gradients from the two row blocks of W^T (GMFlow's FFN input
+    torch.cat([source, message]), transformer.py:201-202: a concat copy forward and a split copy backward per block otherwise).
+    wp: W packed [N, Ka + Kb]; wpt: W^T packed [Ka + Kb, N]."""
+
+    @staticmethod
+    def forward(ctx, a, b, wp, wpt):
+        ctx.wpt, ctx.ka = wpt, a.shape[-1]
+        return ops.gemm(a, wp, a2=b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        wpt, ka = ctx.wpt, ctx.ka
+        da = ops.gemm(dy, wpt[:ka]) if ctx.needs_input_grad[0] else None
+        db = ops.gemm(dy, wpt[ka:]) if ctx.needs_input_grad[1] else None
+        return da, db, None, None
+
+
 class ConvFn(Function):
     """NHWC conv.  wp: forward pack; wdg: pack for the input gradient (flipped + transposed, or W^T for patch convs)."""
 

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from ..... import ops
-from .....autograd import (ActFn, AddFn, ConcatFn, CorrespToFlowFn, FlowPropFn, LayerNormFn, LinearFn,
+from .....autograd import (ActFn, AddFn, ConcatFn, CorrespToFlowFn, FanOutFn, FlowPropFn, LayerNormFn, Linear2Fn, LinearFn,
                            WindowAttentionFn)
 from .....nn_base import EmipModule, f32, pack_linear
 from .tables import window_tables
@@ -60,6 +60,15 @@ class TransformerLayer(EmipModule):
             w = dict(w, **f)
         return w
 
+
+    def tpacks(self, name):
+        """(W packed [N, K], W^T packed [K, N]) of the bias-free Linear `name` in the activation dtype"""
+        mod = self.mlp[int(name[3:])] if name.startswith("mlp") else getattr(self, name)
+        dt = self.cdtype
+        return self.packed("t_" + name, (mod.weight,), lambda a: (pack_linear(a, dt), a.detach().t().to(dt).contiguous()))
+
+    def frozen(self, *names):
+        return not any((self.mlp[int(n[3:])] if n.startswith("mlp") else getattr(self, n)).weight.requires_grad for n in names)
 
     def lin(self, name, x, res=None):
         """differentiable bias-free Linear through the frozen-or-not weight `name`"""
@@ -115,6 +124,7 @@ def _window_attention(q, k, v, B2, h, w, C, ldq, ldk, ldv, shift, splits, kv_rot
     return out
 
 
+TRAIN_FANOUT = True     # training path: FanOutFn / Linear2Fn for the frozen projections (46 autograd adds and 24 concat / split copies per step)
 WATTN_QPROJ = True      # ... and the q projection in its prologue (the fused input GEMM then makes k | v | k' | v' only)
 WATTN_MERGE = True      # emip_window_attention_merge: attention + merge + norm1 (+ residual) in one launch (bf16 inference)
 FFN_BLOCK = True        # emip_ffn_block: mlp[0] + GELU + mlp[2] + norm2 + residual in one launch (bf16 inference)
@@ -144,14 +154,28 @@ class FeatureTransformer(EmipModule):
             shift = sa.with_shift
             # keys / values of the cross attention: the OTHER frame's tokens as they are at block start, read in place from the
             # other half of the batch (kv_rot = B), like the inference path
-            kx, vx = ca.lin("k_proj", c0), ca.lin("v_proj", c0)
-            msg = WindowAttentionFn.apply(sa.lin("q_proj", c0), sa.lin("k_proj", c0), sa.lin("v_proj", c0), h, w, shift,
-                                          attn_num_splits)
+            fused = TRAIN_FANOUT and sa.frozen("q_proj", "k_proj", "v_proj") and ca.frozen("q_proj", "k_proj", "v_proj", "mlp0")
+            if fused:
+                # frozen weights (train.py:340-342: the case the training step runs): the block input's five projections and its
+                # skip connection leave ONE node, whose backward adds the six gradients in GEMM epilogues (autograd.FanOutFn)
+                c0, q, k, v, kx, vx = FanOutFn.apply(c0, sa.tpacks("q_proj"), sa.tpacks("k_proj"), sa.tpacks("v_proj"),
+                                                     ca.tpacks("k_proj"), ca.tpacks("v_proj"))
+            else:
+                kx, vx = ca.lin("k_proj", c0), ca.lin("v_proj", c0)
+                q, k, v = sa.lin("q_proj", c0), sa.lin("k_proj", c0), sa.lin("v_proj", c0)
+            msg = WindowAttentionFn.apply(q, k, v, h, w, shift, attn_num_splits)
             msg = LayerNormFn.apply(sa.lin("merge", msg), sa.norm1.weight, sa.norm1.bias, sa.norm1.eps)
             c1 = AddFn.apply(c0, msg)
-            msg = WindowAttentionFn.apply(ca.lin("q_proj", c1), kx, vx, h, w, shift, attn_num_splits, B)
+            if fused:
+                c1, q1 = FanOutFn.apply(c1, ca.tpacks("q_proj"))
+            else:
+                q1 = ca.lin("q_proj", c1)
+            msg = WindowAttentionFn.apply(q1, kx, vx, h, w, shift, attn_num_splits, B)
             msg = LayerNormFn.apply(ca.lin("merge", msg), ca.norm1.weight, ca.norm1.bias, ca.norm1.eps)
-            hid = ActFn.apply(ca.lin("mlp0", ConcatFn.apply(None, c1, msg)), ops.ACT_GELU)
+            if fused:
+                hid = ActFn.apply(Linear2Fn.apply(c1, msg, *ca.tpacks("mlp0")), ops.ACT_GELU)      # no concatenated copy
+            else:
+                hid = ActFn.apply(ca.lin("mlp0", ConcatFn.apply(None, c1, msg)), ops.ACT_GELU)
             msg = LayerNormFn.apply(ca.lin("mlp2", hid), ca.norm2.weight, ca.norm2.bias, ca.norm2.eps)
             c0 = AddFn.apply(c1, msg)
         return c0
