@@ -143,6 +143,8 @@ def _rebuild_in_place():
             continue
         if not any(t.requires_grad for t in e.tensors) or not e.tensors[0].is_cuda:
             continue
+        if e.mode != (m.cdtype, m.training):
+            continue        # built for the other mode (an eval-only pack such as a folded BatchNorm): rebuilt when that mode uses it again
         sig = tuple((t.data_ptr(), t._version, t.device) for t in e.tensors) + e.mode
         if sig == e.sig:
             continue

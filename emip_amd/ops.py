@@ -69,9 +69,8 @@ class GradArena:
         if self.need and (self.buf is None or self.buf.numel() < self.need or self.buf.device != torch.device(device)):
             self.buf = torch.empty(self.need + (self.need >> 4), dtype=torch.float32, device=device)
         self.limit = min(self.need, self.buf.numel()) if self.buf is not None else 0
-        dev = torch.device(device)
-        if dev.type == "cuda":
-            STEP_STREAM[dev.index if dev.index is not None else torch.cuda.current_device()] = torch.cuda.current_stream(dev)
+        if torch.device(device).type == "cuda":
+            STEP_STREAM[_dev_index(device)] = torch.cuda.current_stream(torch.device(device))
         if self.limit:
             self.buf[:self.limit].zero_()
         self.cursor, self.need, self.active = 0, 0, True
@@ -283,6 +282,11 @@ WIDE_WGRAD = True      # deferred weight gradients on the 256 x 320 tiles of gem
 WGRADS = WgradQueue()
 
 
+def _dev_index(device):
+    dev = torch.device(device)
+    return dev.index if dev.index is not None else torch.cuda.current_device()
+
+
 FORK_STREAMS = {}       # (device index, name) -> side streams the model enqueues whole branches on (CoUpdater.run: PVT stages 3-4, ...)
 FORK_USED = set()       # keys of FORK_STREAMS that took work since the last join_forks()
 
@@ -290,23 +294,22 @@ FORK_USED = set()       # keys of FORK_STREAMS that took work since the last joi
 def fork_stream(device, priority=0, name="deep"):
     """the side stream `name` of `device` for a forked branch (created on first use); the caller is about to enqueue on it, so
     the next join_forks() waits for it"""
-    dev = torch.device(device)
-    key = (dev.index, name)
+    key = (_dev_index(device), name)
     st = FORK_STREAMS.get(key)
     if st is None:
-        st = FORK_STREAMS[key] = torch.cuda.Stream(device=dev, priority=priority)
+        st = FORK_STREAMS[key] = torch.cuda.Stream(device=torch.device("cuda", key[0]), priority=priority)
     FORK_USED.add(key)
     return st
 
 
 def step_streams(device):
     """every stream a training step may have enqueued backward kernels on: the caller's current one and the forked branches'"""
-    dev = torch.device(device)
-    out = [torch.cuda.current_stream(dev)]
+    di = _dev_index(device)
+    out = [torch.cuda.current_stream(torch.device("cuda", di))]
     for (idx, _), st in FORK_STREAMS.items():
-        if idx == dev.index:
+        if idx == di:
             out.append(st)
-    main = STEP_STREAM.get(dev.index)
+    main = STEP_STREAM.get(di)
     if main is not None and all(main.cuda_stream != o.cuda_stream for o in out):
         out.append(main)
     return out
@@ -321,7 +324,7 @@ def join_forks(device=None):
     for key in sorted(FORK_USED):
         # only streams that took work in this step: inside a hipGraph capture a wait on a stream that is not part of the
         # capture would tie the graph to work outside it
-        if device is None or torch.device(device).index == key[0]:
+        if device is None or _dev_index(device) == key[0]:
             st = FORK_STREAMS[key]
             torch.cuda.current_stream(st.device).wait_stream(st)
             FORK_USED.discard(key)

@@ -56,6 +56,12 @@ def forward_backward(model, image1, image2, gts):
             ops.join_forks(image1.device)       # the forked branch (model.FORK_DEEP_TRAIN) before anything reads gradients
         failed = False
     finally:
+        if failed and image1.is_cuda:
+            # whatever a forked branch still runs writes arena slices the next begin() clears: wait for it here as well
+            try:
+                ops.join_forks(image1.device)
+            except Exception:                   # noqa: BLE001 -- the original error is the one to report
+                pass
         ops.ARENA.end(failed)               # on an exception: the deferred queue is dropped, the original error propagates
     return loss.detach(), loss_pred.detach(), loss_flow.detach()
 
