@@ -47,6 +47,20 @@ def graphed(fork):
 eager(False)(3)
 torch.cuda.synchronize()
 modes = [("eager", eager(False)), ("eager + fork", eager(True)), ("graph", graphed(False)), ("graph + fork", graphed(True))]
+if len(sys.argv) > 1:
+    # python tools/train_graph_ab.py "module:ATTR=value,module:ATTR2=value" ...: one captured forked step per setting instead
+    import importlib
+    modes = []
+    for arg in sys.argv[1:]:
+        for part in arg.split(","):
+            target, val = part.split("=")
+            modname, attr = target.split(":")
+            obj = importlib.import_module(modname)
+            path = attr.split(".")
+            for name in path[:-1]:
+                obj = getattr(obj, name)
+            setattr(obj, path[-1], eval(val))
+        modes.append((arg.split(":")[-1][:40], graphed(True)))
 res = {k: [] for k, _ in modes}
 last = {}
 for rnd in range(4):
@@ -59,5 +73,5 @@ for rnd in range(4):
         last[k] = [round(float(x), 4) for x in loss]
 for k, _ in modes:
     xs = res[k]
-    print("%-26s ms/step: %s   median %.2f  (%.1f pairs/s)  loss %s" % (k, " ".join("%.2f" % x for x in xs), sorted(xs)[len(xs) // 2],
+    print("%-42s ms/step: %s   median %.2f  (%.1f pairs/s)  loss %s" % (k, " ".join("%.2f" % x for x in xs), sorted(xs)[len(xs) // 2],
                                                                       B / sorted(xs)[len(xs) // 2] * 1e3, last[k]), flush=True)
